@@ -1,0 +1,184 @@
+/* mcq.h -- C ABI of the MI355X query-path engine for MetaCache-MPI.
+ *
+ * This is the drop-in boundary.  The reference has no
+ * plugin/FFI API; the seam is the per-read body + candidate merge inside
+ * query_batched_parallel2 (reference src/querying.h:792-825 and :867-1073), i.e.
+ *
+ *   database::accumulate_matches(seq, res, offsets)     src/sketch_database.h:826-833
+ *     -> sketcher::operator()(first,last)               src/hash_dna.h:113-152
+ *     -> hash_multimap::find(key)                       src/hash_multimap.h:778-789
+ *   merge_sort(a, offsets, b)                           src/querying.h:88-106
+ *   classification_candidates{db, matches, rules}       src/candidates.h:207-219
+ *   classification_candidates::insert(cand, db, rules)  src/candidates.h:236-285
+ *   MPI tree merge of (qid,taxid,hits) triplets         src/querying.h:867-1073
+ *
+ * Each entry point below says which of these it replaces.  Plain pointers and
+ * sizes only; 0 = success, negative = error (mcq_last_error() gives the text);
+ * nothing throws across the boundary.  All buffers are caller-owned.
+ *
+ * Vocabulary: a *sequence* is one read (or mate); a *query* is one read or one
+ * read pair; a *location* is (target id, window id) packed as (tgt << 32) | win;
+ * a *feature* is one 32-bit min-hash value of a window sketch.
+ */
+#ifndef MCQ_H
+#define MCQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcq_db mcq_db;   /* GPU-resident feature -> locations multimap (one shard) */
+typedef struct mcq_ws mcq_ws;   /* per-caller workspace; one per concurrent mcq_query     */
+
+enum {
+    MCQ_OK = 0,
+    MCQ_E_ARG = -1,        /* bad argument                                            */
+    MCQ_E_HIP = -2,        /* HIP runtime error                                       */
+    MCQ_E_CAPACITY = -3,   /* a query exceeded the workspace's per-query capacity     */
+    MCQ_E_UNSUPPORTED = -4 /* parameter outside what the kernels are built for        */
+};
+
+/* flags */
+enum {
+    MCQ_DEVICE_PTRS = 1u,       /* the pointers in this struct are device pointers     */
+    MCQ_QUIRK_SEQ_DROP = 2u     /* emulate the reference's u32 wire format: a sequence-
+                                   level taxon (key bit 31 set) sent by a non-root rank
+                                   is dropped (src/querying.h:958, :983-985)            */
+};
+
+/* Database description = the union of the reference's P shard tables
+ * (hash_multimap contents, src/hash_multimap.h:923-964) plus the metadata the
+ * candidate step needs.  keys are unique; list i = locs[list_off[i] .. list_off[i+1])
+ * sorted ascending by (tgt,win).  tgt2tax[t] is the taxon key insert() works on for
+ * target t: db.ancestor(taxon_of_target(t), mergeBelow) if it exists, else a key with
+ * bit 31 set that is unique to the target (src/candidates.h:242-245).  Keys are opaque
+ * to the engine except bit 31.
+ * n_shards/shard_id: this handle stores only keys with mcq_owner(key, n_shards) ==
+ * shard_id (the caller may pass all keys; foreign ones are skipped).               */
+typedef struct {
+    uint32_t k;               /* k-mer length, 1..16 (src/hash_dna.h:75)              */
+    uint32_t sketch_size;     /* s, 1..32 (src/mode_build.cpp:66)                     */
+    uint32_t winlen;          /* query window length, <= 128 (src/sketch_database.h:256) */
+    uint32_t winstride;       /* query window stride                                  */
+    uint32_t tgt_winstride;   /* target window stride (range width, classification.cpp:217) */
+    uint32_t n_targets;
+    uint64_t n_keys;
+    uint64_t n_locs;
+    const uint32_t* keys;       /* [n_keys]                                           */
+    const uint64_t* list_off;   /* [n_keys + 1]                                       */
+    const uint64_t* locs;       /* [n_locs]  (tgt << 32) | win                        */
+    const uint32_t* tgt2tax;    /* [n_targets]                                        */
+    uint32_t n_shards;          /* >= 1                                               */
+    uint32_t shard_id;
+    uint32_t flags;             /* MCQ_DEVICE_PTRS                                    */
+    int32_t  device;            /* HIP device ordinal                                 */
+} mcq_db_desc;
+
+/* One batch of sequences: bases[seq_off[i] .. seq_off[i+1]) is sequence i (ASCII,
+ * A/C/G/T any case, anything else is ambiguous: src/dna_encoding.h:326-336).
+ * paired != 0: sequences 2q and 2q+1 are the mates of query q
+ * (sequence_pair_reader::sequence_pair, src/sequence_io.h:204).                     */
+typedef struct {
+    uint64_t n_seqs;
+    const char* bases;
+    const uint64_t* seq_off;    /* [n_seqs + 1] */
+    uint32_t paired;
+    uint32_t flags;             /* MCQ_DEVICE_PTRS */
+} mcq_batch;
+
+/* classification_options / candidate_generation_rules subset that the path uses
+ * (src/query_options.h:123-135, src/candidates.h:89-101).                            */
+typedef struct {
+    uint32_t max_cand;          /* maxNumCandidatesPerQuery, 1..16 and <= 64/emulate_ranks */
+    uint32_t emulate_ranks;     /* P of the reference run to match (fold order of
+                                   src/querying.h:867-1073); 1 = single list, no fold    */
+    uint64_t insert_size_max;   /* insertSizeMax                                         */
+    uint32_t flags;             /* MCQ_QUIRK_SEQ_DROP                                    */
+} mcq_query_opts;
+
+/* match_candidate (src/candidates.h:66-81) with the taxon as its key.  After a fold
+ * (emulate_ranks > 1) window positions are (0,0), as in the reference's wire format. */
+typedef struct {
+    uint32_t tax;
+    uint32_t hits;
+    uint32_t win_beg;
+    uint32_t win_end;
+} mcq_cand;
+
+typedef struct {
+    mcq_cand* cands;            /* [n_queries * max_cand]                              */
+    uint32_t* n_cand;           /* [n_queries]                                         */
+    uint32_t flags;             /* MCQ_DEVICE_PTRS                                     */
+} mcq_result;
+
+/* counters of the last mcq_query on a workspace (for the roofline accounting) */
+typedef struct {
+    uint64_t n_queries;
+    uint64_t n_features;        /* sketch features looked up                           */
+    uint64_t n_hit_features;    /* features with a non-empty list                      */
+    uint64_t n_locations;       /* locations gathered                                  */
+    uint64_t n_cands;           /* candidates written                                  */
+    uint64_t n_overflow;        /* queries that took the block-per-query path          */
+} mcq_stats;
+
+/* replaces sketch_database::read -> hash_multimap::deserialize (the table build) */
+int mcq_db_create(const mcq_db_desc* desc, mcq_db** out);
+int mcq_db_destroy(mcq_db* db);
+/* bytes of HBM held by the handle */
+uint64_t mcq_db_bytes(const mcq_db* db);
+
+/* max_queries / max_bases bound one batch; max_locs_per_query bounds the match list
+ * of a single query on the block-per-query path (0 = default 1<<20).                 */
+int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t max_bases,
+                  uint64_t max_locs_per_query, mcq_ws** out);
+int mcq_ws_destroy(mcq_ws* ws);
+
+/* The whole per-read path for one batch: rows 1-11 of SURVEY.md 8a.  Replaces the
+ * worker body of query_batched_parallel2 (src/querying.h:792-825) and the MPI tree
+ * merge (:867-1073).  stream is a hipStream_t (NULL = default stream).  With device
+ * pointers the call only enqueues work; with host pointers it copies in, runs,
+ * copies out and synchronises the stream.                                           */
+int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, const mcq_query_opts* opt,
+              mcq_result* out, void* stream);
+
+/* Waits for the stream, returns MCQ_E_CAPACITY if any query of the last call on ws
+ * overflowed the workspace, fills stats (may be NULL).                              */
+int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats);
+
+/* ---- staged entry points (feature-sharded multi-GPU path) ---------
+ * mcq_sketch  : rows 1-5.  features[w * sketch_size + i], n_feat[w] for window w of
+ *               the batch; win_query[w] = query index of window w; returns the number
+ *               of windows in *n_windows (device scalar when MCQ_DEVICE_PTRS).
+ * mcq_lookup  : rows 6-7 on the owning shard: for each feature, list length and the
+ *               concatenated lists (two calls: counts, then gather).
+ * mcq_reduce  : rows 8-11 on the home GPU from per-query location segments.          */
+int mcq_count_windows(const mcq_db* db, const mcq_batch* in, uint64_t* win_off /* [n_seqs+1] */, void* stream);
+int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t* win_off,
+               uint32_t* features, uint32_t* n_feat, void* stream);
+int mcq_lookup_count(const mcq_db* db, const uint32_t* features, uint64_t n_features,
+                     uint32_t* list_len, void* stream);
+int mcq_lookup_gather(const mcq_db* db, const uint32_t* features, uint64_t n_features,
+                      const uint64_t* out_off /* [n_features+1] */, uint64_t* out_locs, void* stream);
+int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, const uint64_t* loc_off /* [n_queries+1] */,
+               uint64_t* locs /* sorted in place per query */, const uint32_t* query_len /* [n_queries] sum of mate lengths */,
+               const mcq_query_opts* opt, mcq_result* out, void* stream);
+
+/* shard that owns a feature: a range of h2(f) = thomas_mueller_hash(f)
+ * (src/hash_int.h:39-45), never of f itself                          */
+uint32_t mcq_owner(uint32_t feature, uint32_t n_shards);
+
+/* ---- debug / parity taps (rows 5 and 8 in isolation) ----------------------------- */
+/* sorted match list of every query: match_off[q..q+1) into matches (capacity cap)   */
+int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* in,
+                      uint64_t* match_off /* host [n_queries+1] */, uint64_t* matches /* host */, uint64_t cap);
+
+const char* mcq_last_error(void);
+const char* mcq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCQ_H */

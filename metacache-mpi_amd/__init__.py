@@ -1,0 +1,7 @@
+"""metacache-mpi_amd -- MI355X-native query-path engine for MetaCache-MPI.
+
+Only what the hot path needs lives here: csrc/ (HIP kernels + the C ABI of
+include/mcq.h) and a thin ctypes mirror of that ABI (engine.py).  There is no CPU
+fallback: importing engine without the built HIP library raises.
+"""
+from .build import build_hip, lib_path  # noqa: F401

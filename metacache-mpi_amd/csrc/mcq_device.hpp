@@ -1,0 +1,375 @@
+// mcq_device.hpp -- device-side building blocks of the query path (gfx950, wave64).
+//
+// Everything here is integer work (hashing, compares, shuffles); there is no MFMA on
+// this path.  The unit of parallelism is the wavefront: one wave sketches one window,
+// and one wave (or one 1024-thread workgroup for oversized queries) owns one query
+// from the table probes to the final candidate list, so the match list never leaves
+// LDS on the common path.
+//
+// Reference behaviour restated (file:line relative to the reference root):
+//   tmh / revcomp / canonical        src/hash_int.h:39-45, src/dna_encoding.h:113-121, :187-197
+//   window split                     src/dna_encoding.h:259-276
+//   k-mer extraction + ambiguity     src/dna_encoding.h:303-348, :457-466
+//   unique min-s sketch              src/hash_dna.h:113-152
+//   table lookup                     src/hash_multimap.h:1033-1047 (key -> list only)
+//   accumulate + sort                src/sketch_database.h:804-823, src/querying.h:88-106
+//   contiguous window ranges         src/candidates.h:118-180
+//   bounded top list insert          src/candidates.h:236-285
+//   P-rank tree fold                 src/querying.h:867-1073
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define MCQ_EMPTY 0xFFFFFFFFu
+#define MCQ_MAX_FOLD 64
+
+namespace mcq {
+
+// ------------------------------------------------------------------ structures
+struct DbDev {
+    const uint4* slots;      // {key, len, off_lo, off_hi}; key == MCQ_EMPTY: unused
+    u32 slot_mask;           // nslots - 1 (power of two)
+    const u64* locs;
+    const u32* tgt2tax;
+    u32 n_targets;
+    u32 k, s, winlen, winstride, tgt_winstride;
+};
+
+struct BatchDev {
+    const char* bases;
+    const u64* seq_off;
+    u64 n_seq;
+    u64 nq;
+    u32 paired;
+};
+
+struct OptDev {
+    u32 max_cand;            // M
+    u32 P;                   // emulate_ranks
+    u32 seg;                 // lanes per virtual-rank list = 64 / pow2ceil(P)
+    u32 quirk_seq_drop;
+    u64 insert_size_max;
+    u32 n_fold;              // fold schedule: (snd -> rcv) in the reference's order
+    unsigned char fold_snd[MCQ_MAX_FOLD];
+    unsigned char fold_rcv[MCQ_MAX_FOLD];
+};
+
+struct OutDev {
+    u32* cands;              // nq * M * 4
+    u32* ncand;              // nq
+};
+
+struct CountersDev {         // one block of u64/u32 words, zeroed per call
+    unsigned long long n_features, n_hit_features, n_locations, n_cands;
+    u32 ovf_count;           // queries queued for the block-per-query path
+    u32 err_count;           // queries that exceeded the block path's capacity
+};
+
+// ------------------------------------------------------------------ scalars
+__device__ __forceinline__ u32 tmh(u32 x) {
+    x = ((x >> 16) ^ x) * 0x45d9f3bu;
+    x = ((x >> 16) ^ x) * 0x45d9f3bu;
+    return (x >> 16) ^ x;
+}
+
+__device__ __forceinline__ u32 revcomp(u32 s, u32 k) {
+    s = ((s >> 2) & 0x33333333u) | ((s & 0x33333333u) << 2);
+    s = ((s >> 4) & 0x0F0F0F0Fu) | ((s & 0x0F0F0F0Fu) << 4);
+    s = __builtin_bswap32(s);                 // the 8- and 16-bit swap steps together
+    return (0xFFFFFFFFu - s) >> (32 - 2 * k);
+}
+
+__device__ __forceinline__ u32 canonical(u32 s, u32 k) {
+    u32 r = revcomp(s, k);
+    return s < r ? s : r;
+}
+
+// number of windows of a sequence of n bases (src/dna_encoding.h:259-276)
+__device__ __host__ __forceinline__ u32 num_windows(u64 n, u32 W, u32 S) {
+    if (n <= W) return 1;
+    u64 nfull = (n - W) / S + 1;
+    return (u32)(nfull + ((nfull * S < n) ? 1 : 0));
+}
+// window j of a sequence of n bases -> [beg, beg+len)
+__device__ __forceinline__ void window_of(u64 n, u32 W, u32 S, u32 j, u64& beg, u32& len) {
+    if (n <= W) { beg = 0; len = (u32)n; return; }
+    u64 nfull = (n - W) / S + 1;
+    beg = (u64)j * S;
+    len = (j < nfull) ? W : (u32)(n - beg);
+}
+
+// ------------------------------------------------------------------ wave primitives
+__device__ __forceinline__ u32 lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Orders this wave's LDS/global accesses across lanes.  A wave executes its memory
+// instructions in order, so only the compiler has to be stopped from reordering.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_mov(u32 v) {
+    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+// minimum over the 64 lanes, returned wave-uniform.  All lanes must be active.
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+    u32 t;
+    t = dpp_mov<0xB1>(v);  v = t < v ? t : v;   // quad_perm [1,0,3,2]
+    t = dpp_mov<0x4E>(v);  v = t < v ? t : v;   // quad_perm [2,3,0,1]
+    t = dpp_mov<0x141>(v); v = t < v ? t : v;   // row_half_mirror
+    t = dpp_mov<0x140>(v); v = t < v ? t : v;   // row_mirror: every lane of a row holds the row min
+    u32 a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    u32 c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    a = a < b ? a : b; c = c < d ? c : d;
+    return a < c ? a : c;
+}
+
+// inclusive prefix sum over the wave
+__device__ __forceinline__ u32 wave_incl_scan(u32 v, u32 lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= (u32)d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32 bcast(u32 v, u32 src_lane) {       // src_lane wave-uniform
+    return __builtin_amdgcn_readlane(v, src_lane);
+}
+
+// ------------------------------------------------------------------ rows 2-5: one window, one wave
+// Sketch of seq[0..n), n <= 128, by one full wave.  Lane l encodes bases 2l and 2l+1;
+// 8 lanes form one 16-base word (2 bits per base, first base in the top bits), 16 lanes
+// one 32-base ambiguity word.  Lane l then owns the k-mers starting at l and l+64.
+// Returns the number of features m (wave-uniform, <= min(s, n-k+1)); feature i
+// (ascending) is returned in lane i's `feat`.
+__device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, u32 k, u32 s,
+                                           u32 lane, u32& feat) {
+    feat = MCQ_EMPTY;
+    if (n < k) return 0;
+    u32 cap = n - k + 1;
+    u32 sl = s < cap ? s : cap;
+
+    u32 p = 2 * lane;
+    u32 c0 = (p < n) ? (u32)(unsigned char)seq[p] : (u32)'N';
+    u32 c1 = (p + 1 < n) ? (u32)(unsigned char)seq[p + 1] : (u32)'N';
+    // A/a=0 C/c=1 G/g=2 T/t=3 (src/dna_encoding.h:326-336); anything else ambiguous
+    u32 u0 = c0 & 0xDFu, u1 = c1 & 0xDFu;
+    u32 x0 = (u0 >> 1) & 3u, x1 = (u1 >> 1) & 3u;
+    x0 ^= x0 >> 1; x1 ^= x1 >> 1;
+    u32 a0 = !(u0 == 'A' || u0 == 'C' || u0 == 'G' || u0 == 'T');
+    u32 a1 = !(u1 == 'A' || u1 == 'C' || u1 == 'G' || u1 == 'T');
+
+    u32 w = ((x0 << 2) | x1) << (28 - 4 * (lane & 7));
+    w |= __shfl_xor(w, 1, 64); w |= __shfl_xor(w, 2, 64); w |= __shfl_xor(w, 4, 64);
+    u32 am = ((a0 << 1) | a1) << (30 - 2 * (lane & 15));
+    am |= __shfl_xor(am, 1, 64); am |= __shfl_xor(am, 2, 64);
+    am |= __shfl_xor(am, 4, 64); am |= __shfl_xor(am, 8, 64);
+
+    u32 h[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        u32 pos = lane + 64 * i;
+        u32 wi = pos >> 4, sh = (pos & 15) * 2;
+        u32 w0 = __shfl(w, (int)((wi * 8) & 63), 64);
+        u32 w1 = __shfl(w, (int)(((wi + 1) * 8) & 63), 64);
+        u32 win32 = (u32)((((u64)w0 << 32) | w1) >> (32 - sh));
+        u32 kmer = win32 >> (32 - 2 * k);
+        u32 ai = pos >> 5, ash = pos & 31;
+        u32 m0 = __shfl(am, (int)((ai * 16) & 63), 64);
+        u32 m1 = __shfl(am, (int)(((ai + 1) * 16) & 63), 64);
+        u32 amb32 = (u32)((((u64)m0 << 32) | m1) >> (32 - ash));
+        bool ok = (pos + k <= n) && ((amb32 >> (32 - k)) == 0);
+        h[i] = ok ? tmh(canonical(kmer, k)) : MCQ_EMPTY;
+    }
+
+    // the sl smallest distinct values: repeated wave-min, equal values retire together
+    u32 m = 0;
+    for (; m < sl; ++m) {
+        u32 lo = h[0] < h[1] ? h[0] : h[1];
+        u32 mn = wave_min_u32(lo);
+        if (mn == MCQ_EMPTY) break;
+        if (lane == m) feat = mn;
+        if (h[0] == mn) h[0] = MCQ_EMPTY;
+        if (h[1] == mn) h[1] = MCQ_EMPTY;
+    }
+    return m;
+}
+
+// ------------------------------------------------------------------ row 6: probe
+// Linear probing over 16-byte slots; one 16-B load returns key, list length and offset.
+__device__ __forceinline__ void probe(const DbDev& db, u32 f, u64& off, u32& len) {
+    len = 0; off = 0;
+    if (f == MCQ_EMPTY) return;
+    u32 idx = tmh(f) & db.slot_mask;
+    while (true) {
+        uint4 sl = db.slots[idx];
+        if (sl.x == f) { len = sl.y; off = ((u64)sl.w << 32) | sl.z; return; }
+        if (sl.x == MCQ_EMPTY) return;
+        idx = (idx + 1) & db.slot_mask;
+    }
+}
+
+// ------------------------------------------------------------------ row 8: sort
+// Bitonic sort of buf[0..n) (n a power of two) by G cooperating threads.
+template <class Sync>
+__device__ __forceinline__ void bitonic_sort(u64* buf, u32 n, u32 tid, u32 G, Sync sync) {
+    for (u32 k = 2; k <= n; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 t = tid; t < (n >> 1); t += G) {
+                u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                u32 l = i | j;
+                u64 a = buf[i], b = buf[l];
+                bool up = (i & k) == 0;
+                if ((a > b) == up) { buf[i] = b; buf[l] = a; }
+            }
+            sync();
+        }
+    }
+}
+
+// ------------------------------------------------------------------ row 9: per-target best window range
+// buf[0..T) sorted by (tgt,win).  The thread that owns the first element of a target's
+// run sweeps that run exactly like the reference's two-pointer loop and leaves the
+// target's best hit count in hits[j0]; every other hits[] entry becomes 0.
+__device__ __forceinline__ void walk_targets(const u64* buf, u32* hits, u32 T, u32 numWindows, u32 tid, u32 G) {
+    for (u32 j = tid; j < T; j += G) {
+        u64 key = buf[j];
+        u32 tgt = (u32)(key >> 32);
+        bool head = (j == 0) || ((u32)(buf[j - 1] >> 32) != tgt);
+        u32 best = 0;
+        if (head) {
+            u32 fst = j, cur = 1; best = 1;
+            for (u32 l = j + 1; l < T; ++l) {
+                u64 kk = buf[l];
+                if ((u32)(kk >> 32) != tgt) break;
+                u32 w = (u32)kk;
+                ++cur;
+                while ((u32)(w - (u32)buf[fst]) >= numWindows) { --cur; ++fst; }
+                if (cur > best) best = cur;
+            }
+        }
+        hits[j] = best;
+    }
+}
+
+// window range of the best candidate of the target whose run starts at j0
+// (same sweep, keeping the first strictly-best range)
+__device__ __forceinline__ void walk_range(const u64* buf, u32 T, u32 numWindows, u32 j0, u32& beg, u32& end) {
+    u32 tgt = (u32)(buf[j0] >> 32);
+    u32 fst = j0, cur = 1, best = 1;
+    beg = end = (u32)buf[j0];
+    for (u32 l = j0 + 1; l < T; ++l) {
+        u64 kk = buf[l];
+        if ((u32)(kk >> 32) != tgt) break;
+        u32 w = (u32)kk;
+        ++cur;
+        while ((u32)(w - (u32)buf[fst]) >= numWindows) { --cur; ++fst; }
+        if (cur > best) { best = cur; beg = (u32)buf[fst]; end = w; }
+    }
+}
+
+// ------------------------------------------------------------------ rows 10-11: top lists in lanes
+// The P virtual-rank lists live side by side in one wave: list r occupies lanes
+// [r*seg, r*seg + M).  An entry is (tax, hits, j0); hits == 0 marks an unused lane, and
+// used lanes of a list are always a prefix sorted by hits descending.
+struct TopLists {
+    u32 tax, hits, j0;
+};
+
+// insert candidate (ctax, chits, cj0) -- all wave-uniform -- into list `r`
+__device__ __forceinline__ void top_insert(TopLists& L, u32 lane, u32 r, u32 seg, u32 M,
+                                           u32 ctax, u32 chits, u32 cj0) {
+    const u32 base = r * seg;
+    const bool in_list = (lane >= base) && (lane < base + M);
+    const u32 li = lane - base;                                  // index inside the list
+    const u64 segmask = (M >= 64 ? ~0ull : ((1ull << M) - 1)) << base;
+    u64 same = __ballot(in_list && L.hits > 0 && L.tax == ctax) & segmask;
+    // neighbours one lane to the left (for shifting entries right by one)
+    u32 ptax = __shfl_up(L.tax, 1, 64), phits = __shfl_up(L.hits, 1, 64), pj0 = __shfl_up(L.j0, 1, 64);
+    if (same) {
+        u32 i = (u32)__builtin_ctzll(same) - base;               // position of the taxon
+        u32 ihits = __builtin_amdgcn_readlane(L.hits, (int)(base + i));
+        if (chits > ihits) {
+            // new position: after every earlier entry with hits >= chits
+            u64 ge = __ballot(in_list && li < i && L.hits >= chits) & segmask;
+            u32 jn = (u32)__builtin_popcountll(ge);
+            if (in_list && li > jn && li <= i) { L.tax = ptax; L.hits = phits; L.j0 = pj0; }
+            if (in_list && li == jn) { L.tax = ctax; L.hits = chits; L.j0 = cj0; }
+        }
+        return;
+    }
+    // position = number of entries with hits >= chits (first strictly smaller one)
+    u64 ge = __ballot(in_list && L.hits >= chits) & segmask;
+    u32 jn = (u32)__builtin_popcountll(ge);
+    if (jn >= M) return;                                          // full and not better than the last
+    if (in_list && li > jn) { L.tax = ptax; L.hits = phits; L.j0 = pj0; }   // shift right, last one falls off
+    if (in_list && li == jn) { L.tax = ctax; L.hits = chits; L.j0 = cj0; }
+}
+
+// Builds the P lists from the walked buffer, folds them in the reference's tree order
+// and writes the result for query q.  Executed by ONE full wave.  Returns the number
+// of candidates written (wave-uniform).
+__device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& opt, const OutDev& out,
+                                               const u64* buf, const u32* hits, u32 T, u32 numWindows,
+                                               u64 q, u32 lane) {
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    TopLists L; L.tax = MCQ_EMPTY; L.hits = 0; L.j0 = 0;
+
+    for (u32 base = 0; base < T; base += 64) {
+        u32 j = base + lane;
+        u32 h = (j < T) ? hits[j] : 0;
+        u32 tgt = (j < T) ? (u32)(buf[j] >> 32) : 0;
+        u32 r = (P > 1) ? (tgt % P) : 0;
+        // taxon key of every run head of this chunk, fetched together
+        u32 tax = MCQ_EMPTY;
+        if (h > 0) tax = (tgt < db.n_targets) ? db.tgt2tax[tgt] : MCQ_EMPTY;
+        u64 pending = __ballot(h > 0 && tax != MCQ_EMPTY);
+        while (pending) {
+            // a full list with minimum m ignores every candidate with hits <= m
+            // (list minima never decrease), an open list takes everything
+            u32 thr = __shfl(L.hits, (int)(r * seg + M - 1), 64);
+            pending &= __ballot(h > thr);
+            if (!pending) break;
+            u32 c = (u32)__builtin_ctzll(pending);
+            pending &= pending - 1;
+            u32 ctax = bcast(tax, c), chits = bcast(h, c), cr = bcast(r, c);
+            top_insert(L, lane, cr, seg, M, ctax, chits, base + c);
+        }
+    }
+
+    if (P > 1) {
+        for (u32 f = 0; f < opt.n_fold; ++f) {
+            u32 snd = opt.fold_snd[f], rcv = opt.fold_rcv[f];
+            for (u32 i = 0; i < M; ++i) {
+                u32 sl = snd * seg + i;
+                u32 ctax = bcast(L.tax, sl), chits = bcast(L.hits, sl);
+                if (chits == 0) break;
+                if (opt.quirk_seq_drop && (ctax & 0x80000000u)) continue;
+                top_insert(L, lane, rcv, seg, M, ctax, chits, 0);
+            }
+        }
+    }
+
+    // list 0 is the result
+    u32 n = (u32)__builtin_popcountll(__ballot(lane < M && L.hits > 0));
+    if (lane < n) {
+        u32 beg = 0, end = 0;
+        if (P == 1) walk_range(buf, T, numWindows, L.j0, beg, end);
+        uint4 v; v.x = L.tax; v.y = L.hits; v.z = beg; v.w = end;
+        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
+    }
+    if (lane == 0) out.ncand[q] = n;
+    return n;
+}
+
+} // namespace mcq

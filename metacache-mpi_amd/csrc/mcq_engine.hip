@@ -1,0 +1,649 @@
+// mcq_engine.hip -- kernels + C ABI of the MI355X query-path engine (see include/mcq.h).
+//
+// Two kernels carry the whole per-query path (rows 1-11 of SURVEY.md 8a):
+//
+//   k_query_wave   one wavefront per query.  Sketch (<= 4 windows), 64 parallel table
+//                  probes, list gather into the wave's LDS segment, in-LDS bitonic
+//                  sort, per-target window sweep, lane-resident top lists + tree fold.
+//                  HBM traffic = the algorithmic bytes: read bases, one 16-B slot per
+//                  probe, the location lists once, the candidates out.
+//   k_query_block  one 1024-thread workgroup per query that does not fit a wave's
+//                  budget (long reads with many windows, or > LCAP locations): same
+//                  steps with workgroup barriers, LDS up to 8192 locations, global
+//                  scratch beyond.
+//
+// Queries that overflow the wave budget are queued through a device counter; the block
+// kernel drains the queue, so no host round trip sits inside a batch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "../../include/mcq.h"
+#include "mcq_device.hpp"
+
+using namespace mcq;
+
+// ------------------------------------------------------------------ error handling
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    return fail(MCQ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+extern "C" const char* mcq_last_error(void) { return g_err.c_str(); }
+extern "C" const char* mcq_version(void) { return "mcq 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------ handles
+struct mcq_db {
+    DbDev d;
+    int device;
+    u64 nslots;
+    u64 n_keys_local, n_locs_local;
+    uint4* slots;
+    u64* locs;
+    u32* tgt2tax;
+    u32 n_shards, shard_id;
+    u64 bytes;
+};
+
+struct ScratchDev {
+    u32* feat; u32* fpos; u64* foff; u64* gbuf; u32* ghits;
+    u32 fmax; u32 lmax;
+};
+
+struct DebugDev {
+    int mode;                 // 0 off, 1 = write match counts, 2 = write matches
+    u64* match_cnt;           // [nq]
+    const u64* match_off;     // [nq+1]
+    u64* matches;
+};
+
+struct mcq_ws {
+    int device;
+    u64 max_queries, max_bases;
+    CountersDev* ctr;         // device
+    CountersDev* ctr_host;    // pinned
+    u32* ovf_list;            // [max_queries]
+    ScratchDev sc;
+    int n_block_wgs;
+    // staging for host-pointer calls
+    char* d_bases; u64* d_seq_off; u32* d_cands; u32* d_ncand;
+    u64 last_nq;
+};
+
+// ------------------------------------------------------------------ kernels: table build
+__global__ void k_fill_slots(uint4* slots, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i] = make_uint4(MCQ_EMPTY, 0, 0, 0);
+}
+
+// one thread per key: claim a slot with CAS on the key word, then fill length/offset.
+// new_off[i] = offset of key i's list in the handle's own location array.
+__global__ void k_insert_keys(uint4* slots, u32 mask, const u32* keys, const u64* new_off, u64 n_keys,
+                              u32 n_shards, u32 shard_id) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_keys) return;
+    u32 key = keys[i];
+    u64 b = new_off[i], e = new_off[i + 1];
+    if (e == b) return;                                   // foreign or empty
+    (void)n_shards; (void)shard_id;
+    u32 idx = tmh(key) & mask;
+    while (true) {
+        u32 prev = atomicCAS(reinterpret_cast<u32*>(&slots[idx]), MCQ_EMPTY, key);
+        if (prev == MCQ_EMPTY) {
+            u32* w = reinterpret_cast<u32*>(&slots[idx]);
+            w[1] = (u32)(e - b); w[2] = (u32)b; w[3] = (u32)(b >> 32);
+            return;
+        }
+        idx = (idx + 1) & mask;
+    }
+}
+
+// list length per key if owned by this shard, else 0
+__global__ void k_owned_len(const u32* keys, const u64* list_off, u64 n_keys, u32 n_shards, u32 shard_id, u64* out_len) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_keys) return;
+    u32 own = (u32)(((u64)tmh(keys[i]) * n_shards) >> 32);
+    out_len[i] = (own == shard_id) ? (list_off[i + 1] - list_off[i]) : 0;
+}
+
+// copy owned lists into the compacted location array
+__global__ void k_copy_lists(const u64* list_off, const u64* new_off, const u64* locs, u64* out, u64 n_keys) {
+    // one wave per key
+    u64 key = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    u32 lane = threadIdx.x & 63;
+    if (key >= n_keys) return;
+    u64 b = new_off[key], n = new_off[key + 1] - b, src = list_off[key];
+    for (u64 t = lane; t < n; t += 64) out[b + t] = locs[src + t];
+}
+
+// exclusive scan of u64 array (single workgroup, used only at DB build)
+__global__ __launch_bounds__(1024) void k_scan_u64(const u64* in, u64* out, u64 n) {
+    __shared__ u64 s_w[16];
+    __shared__ u64 s_carry;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < n; base += 1024) {
+        u64 i = base + tid;
+        u64 v = (i < n) ? in[i] : 0, x = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            u64 t = __shfl_up(x, d, 64);
+            if (lane >= (u32)d) x += t;
+        }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        u64 woff = 0;
+        for (u32 w = 0; w < wave; ++w) woff += s_w[w];
+        u64 carry = s_carry;
+        if (i < n) out[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = s_carry;
+}
+
+// ------------------------------------------------------------------ kernel: wave per query
+__device__ __forceinline__ u32 pow2ceil(u32 x) { return x <= 1 ? 1u : 1u << (32 - __builtin_clz(x - 1)); }
+
+template <int LCAP>
+__global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
+                                                    CountersDev* ctr, u32* ovf_list, int force_block) {
+    __shared__ u64 s_buf[4][LCAP];
+    __shared__ u32 s_hits[4][LCAP];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u64* buf = s_buf[wave];
+    u32* hits = s_hits[wave];
+    const u32 W = db.winlen, S = db.winstride;
+    const u64 nwaves = (u64)gridDim.x * 4;
+    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
+
+    for (u64 q = (u64)blockIdx.x * 4 + wave; q < b.nq; q += nwaves) {
+        const u64 a = b.paired ? 2 * q : q;
+        const u64 o0 = b.seq_off[a], o1 = b.seq_off[a + 1];
+        const u64 o2 = b.paired ? b.seq_off[a + 2] : o1;
+        const u64 n1 = o1 - o0, n2 = o2 - o1;
+        const u32 nw1 = num_windows(n1, W, S), nw2 = b.paired ? num_windows(n2, W, S) : 0;
+        bool ovf = force_block || ((u64)(nw1 + nw2) * db.s > 64);
+        u32 myf = MCQ_EMPTY, nfeat = 0, T = 0, len = 0, pos = 0;
+        u64 off = 0;
+        if (!ovf) {
+            for (u32 w = 0; w < nw1 + nw2; ++w) {
+                const bool m2 = w >= nw1;
+                const u64 n = m2 ? n2 : n1;
+                const u64 sb = m2 ? o1 : o0;
+                u64 beg; u32 wl;
+                window_of(n, W, S, m2 ? w - nw1 : w, beg, wl);
+                u32 f;
+                u32 m = wave_sketch(b.bases + sb + beg, wl, db.k, db.s, lane, f);
+                u32 g = __shfl(f, (int)((lane - nfeat) & 63), 64);
+                if (lane >= nfeat && lane < nfeat + m) myf = g;
+                nfeat += m;
+            }
+            probe(db, myf, off, len);
+            u32 incl = wave_incl_scan(len, lane);
+            pos = incl - len;
+            T = bcast(incl, 63);
+            if (T > (u32)LCAP) ovf = true;
+        }
+        if (ovf) {
+            if (lane == 0) { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
+            continue;
+        }
+        st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
+        if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
+
+        // gather the lists: element t belongs to the last feature lane j with pos_j <= t
+        const u32 n2p = pow2ceil(T);
+        for (u32 base = 0; base < n2p; base += 64) {
+            const u32 t = base + lane;
+            const u32 tt = t < T ? t : T - 1;
+            u32 lo = 0;
+#pragma unroll
+            for (u32 step = 32; step > 0; step >>= 1) {
+                u32 c = lo + step;
+                u32 pc = __shfl(pos, (int)(c & 63), 64);
+                if (c < 64 && pc <= tt) lo = c;
+            }
+            u32 pj = __shfl(pos, (int)lo, 64);
+            u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
+            u64 v = ~0ull;
+            if (t < T) v = db.locs[(((u64)ohi << 32) | olo) + (tt - pj)];
+            if (t < n2p) buf[t] = v;
+        }
+        wave_sync();
+        bitonic_sort(buf, n2p, lane, 64u, [] { wave_sync(); });
+        const u32 numWindows = (u32)(2 + (n1 + n2 > opt.insert_size_max ? n1 + n2 : opt.insert_size_max) / db.tgt_winstride);
+        walk_targets(buf, hits, T, numWindows, lane, 64u);
+        wave_sync();
+        st_cand += topk_fold_write(db, opt, out, buf, hits, T, numWindows, q, lane);
+    }
+    if (lane == 0 && (st_feat | st_loc)) {
+        atomicAdd(&ctr->n_features, st_feat);
+        atomicAdd(&ctr->n_hit_features, st_hit);
+        atomicAdd(&ctr->n_locations, st_loc);
+        atomicAdd(&ctr->n_cands, st_cand);
+    }
+}
+
+// ------------------------------------------------------------------ kernel: workgroup per query
+// exclusive scan of a[0..n) in place by the whole workgroup; returns the total
+__device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w /* >= 18 words */) {
+    const u32 lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_w[17] = 0;
+    __syncthreads();
+    for (u32 base = 0; base < n; base += 1024) {
+        u32 i = base + tid;
+        u32 v = (i < n) ? a[i] : 0;
+        u32 x = wave_incl_scan(v, lane);
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        u32 woff = 0;
+        for (u32 w = 0; w < wave; ++w) woff += s_w[w];
+        u32 carry = s_w[17];
+        if (i < n) a[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) s_w[17] = carry + woff + x;
+        __syncthreads();
+    }
+    return s_w[17];
+}
+
+template <bool kLds>
+__device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
+                                           u64* B, u32* H, const u32* fpos, const u64* foff, u32 F, u32 T,
+                                           u32 numWindows, u64 q, u32 tid, const DebugDev& dbg) {
+    const u32 n2p = pow2ceil(T);
+    for (u32 t = tid; t < n2p; t += 1024) {
+        u64 v = ~0ull;
+        if (t < T) {
+            u32 lo = 0, hi = F;                       // last j in [0,F) with fpos[j] <= t
+            while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (fpos[mid] <= t) lo = mid; else hi = mid; }
+            v = db.locs[foff[lo] + (t - fpos[lo])];
+        }
+        B[t] = v;
+    }
+    __syncthreads();
+    bitonic_sort(B, n2p, tid, 1024u, [] { __syncthreads(); });
+    if (dbg.mode == 2) {
+        for (u32 t = tid; t < T; t += 1024) dbg.matches[dbg.match_off[q] + t] = B[t];
+    }
+    walk_targets(B, H, T, numWindows, tid, 1024u);
+    __syncthreads();
+    if (tid < 64) {
+        u32 n = topk_fold_write(db, opt, out, B, H, T, numWindows, q, tid);
+        if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
+    }
+    __syncthreads();
+}
+
+template <int LCAPB>
+__global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
+                                                      CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg) {
+    __shared__ u64 s_buf[LCAPB];
+    __shared__ u32 s_hits[LCAPB];
+    __shared__ u32 s_w[20];
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 W = db.winlen, S = db.winstride;
+    u32* feat = sc.feat + (u64)blockIdx.x * sc.fmax;
+    u32* fpos = sc.fpos + (u64)blockIdx.x * ((u64)sc.fmax + 1);
+    u64* foff = sc.foff + (u64)blockIdx.x * sc.fmax;
+    u64* gbuf = sc.gbuf + (u64)blockIdx.x * sc.lmax;
+    u32* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
+    const u32 n_ovf = ctr->ovf_count;
+
+    for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
+        const u64 q = ovf_list[it];
+        const u64 a = b.paired ? 2 * q : q;
+        const u64 o0 = b.seq_off[a], o1 = b.seq_off[a + 1];
+        const u64 o2 = b.paired ? b.seq_off[a + 2] : o1;
+        const u64 n1 = o1 - o0, n2 = o2 - o1;
+        const u32 nw1 = num_windows(n1, W, S), nw2 = b.paired ? num_windows(n2, W, S) : 0;
+        const u64 NW = (u64)nw1 + nw2;
+        if (NW * db.s > sc.fmax) {                        // beyond the workspace: flag, no result
+            if (tid == 0) { out.ncand[q] = 0; atomicAdd(&ctr->err_count, 1u); if (dbg.mode == 1) dbg.match_cnt[q] = 0; }
+            continue;
+        }
+        if (tid == 0) { s_w[18] = 0; s_w[19] = 0; }
+        __syncthreads();
+        for (u32 w = wave; w < (u32)NW; w += 16) {
+            const bool m2 = w >= nw1;
+            const u64 n = m2 ? n2 : n1;
+            const u64 sb = m2 ? o1 : o0;
+            u64 beg; u32 wl;
+            window_of(n, W, S, m2 ? w - nw1 : w, beg, wl);
+            u32 f;
+            u32 m = wave_sketch(b.bases + sb + beg, wl, db.k, db.s, lane, f);
+            u32 base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_w[18], m);
+            base = bcast(base, 0);
+            if (lane < m) feat[base + lane] = f;
+        }
+        __syncthreads();
+        const u32 F = s_w[18];
+        u32 nhit = 0;
+        for (u32 i = tid; i < F; i += 1024) {
+            u64 off; u32 len;
+            probe(db, feat[i], off, len);
+            foff[i] = off; fpos[i] = len; nhit += (len > 0);
+        }
+        nhit = wave_incl_scan(nhit, lane);
+        if (lane == 63 && nhit) atomicAdd(&s_w[19], nhit);
+        __syncthreads();
+        const u32 T = block_excl_scan(fpos, F, tid, s_w);
+        if (tid == 0) {
+            atomicAdd(&ctr->n_features, (unsigned long long)F); atomicAdd(&ctr->n_locations, (unsigned long long)T);
+            atomicAdd(&ctr->n_hit_features, (unsigned long long)s_w[19]);
+        }
+        if (dbg.mode == 1) { if (tid == 0) dbg.match_cnt[q] = T; }
+        if (T == 0) { if (tid == 0) out.ncand[q] = 0; continue; }
+        if (T > sc.lmax || pow2ceil(T) > sc.lmax) {
+            if (tid == 0) { out.ncand[q] = 0; atomicAdd(&ctr->err_count, 1u); }
+            continue;
+        }
+        const u32 numWindows = (u32)(2 + (n1 + n2 > opt.insert_size_max ? n1 + n2 : opt.insert_size_max) / db.tgt_winstride);
+        if (pow2ceil(T) <= (u32)LCAPB) block_tail<true>(db, opt, out, ctr, s_buf, s_hits, fpos, foff, F, T, numWindows, q, tid, dbg);
+        else                           block_tail<false>(db, opt, out, ctr, gbuf, ghits, fpos, foff, F, T, numWindows, q, tid, dbg);
+    }
+}
+
+// ------------------------------------------------------------------ host helpers
+static u64 pow2ceil64(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
+
+// Fold schedule of the reference's merge loop (src/querying.h:867-1073): senders = odd
+// ranks, receivers = even ranks, i-th sender -> i-th receiver; used senders retire, every
+// second used receiver becomes a sender; floor(log2 P) rounds.
+static void fold_schedule(u32 P, std::vector<std::pair<u32, u32>>& sched) {
+    std::vector<u32> snd, rcv;
+    for (u32 i = 0; i < P; ++i) (i % 2 ? snd : rcv).push_back(i);
+    for (u32 k = P; k > 1; k /= 2) {
+        size_t np = std::min(snd.size(), rcv.size());
+        std::vector<u32> us(snd.begin(), snd.begin() + np), ur(rcv.begin(), rcv.begin() + np);
+        for (size_t i = 0; i < np; ++i) sched.emplace_back(us[i], ur[i]);
+        std::vector<u32> ns(snd.begin() + np, snd.end()), nr;
+        for (size_t i = 0; i < rcv.size(); ++i) {
+            if (i < np && (i % 2) == 1) ns.push_back(rcv[i]); else nr.push_back(rcv[i]);
+        }
+        std::sort(ns.begin(), ns.end());
+        snd.swap(ns); rcv.swap(nr);
+    }
+}
+
+static int make_opt(const mcq_query_opts* o, OptDev& d) {
+    if (!o) return fail(MCQ_E_ARG, "opts is null");
+    u32 P = o->emulate_ranks ? o->emulate_ranks : 1;
+    if (P > 64) return fail(MCQ_E_UNSUPPORTED, "emulate_ranks > 64");
+    u32 p2 = (u32)pow2ceil64(P);
+    u32 seg = 64 / p2;
+    if (o->max_cand < 1 || o->max_cand > 16 || o->max_cand > seg)
+        return fail(MCQ_E_UNSUPPORTED, "max_cand must be in 1..16 and <= 64/pow2ceil(emulate_ranks)");
+    memset(&d, 0, sizeof(d));
+    d.max_cand = o->max_cand; d.P = P; d.seg = seg;
+    d.quirk_seq_drop = (o->flags & MCQ_QUIRK_SEQ_DROP) ? 1 : 0;
+    d.insert_size_max = o->insert_size_max;
+    std::vector<std::pair<u32, u32>> sched;
+    fold_schedule(P, sched);
+    if (sched.size() > MCQ_MAX_FOLD) return fail(MCQ_E_UNSUPPORTED, "fold schedule too long");
+    d.n_fold = (u32)sched.size();
+    for (size_t i = 0; i < sched.size(); ++i) { d.fold_snd[i] = (unsigned char)sched[i].first; d.fold_rcv[i] = (unsigned char)sched[i].second; }
+    return MCQ_OK;
+}
+
+extern "C" uint32_t mcq_owner(uint32_t feature, uint32_t n_shards) {
+    u32 x = feature;
+    x = ((x >> 16) ^ x) * 0x45d9f3bu; x = ((x >> 16) ^ x) * 0x45d9f3bu; x = (x >> 16) ^ x;
+    return (u32)(((u64)x * (n_shards ? n_shards : 1)) >> 32);
+}
+
+// ------------------------------------------------------------------ db
+extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
+    if (!desc || !out) return fail(MCQ_E_ARG, "null argument");
+    if (desc->k < 1 || desc->k > 16) return fail(MCQ_E_UNSUPPORTED, "k must be 1..16");
+    if (desc->sketch_size < 1 || desc->sketch_size > 32) return fail(MCQ_E_UNSUPPORTED, "sketch_size must be 1..32");
+    if (desc->winlen < desc->k || desc->winlen > 128) return fail(MCQ_E_UNSUPPORTED, "winlen must be k..128");
+    if (desc->winstride < 1) return fail(MCQ_E_ARG, "winstride must be >= 1");
+    u32 n_shards = desc->n_shards ? desc->n_shards : 1;
+    if (desc->shard_id >= n_shards) return fail(MCQ_E_ARG, "shard_id >= n_shards");
+    HIPCHK(hipSetDevice(desc->device));
+
+    const bool dev = (desc->flags & MCQ_DEVICE_PTRS) != 0;
+    const u64 nk = desc->n_keys, nl = desc->n_locs;
+    const u32* d_keys = desc->keys; const u64* d_off = desc->list_off; const u64* d_locs = desc->locs;
+    u32* t_keys = nullptr; u64* t_off = nullptr; u64* t_locs = nullptr;
+    if (!dev) {
+        HIPCHK(hipMalloc(&t_keys, std::max<u64>(1, nk) * 4));
+        HIPCHK(hipMalloc(&t_off, (nk + 1) * 8));
+        HIPCHK(hipMalloc(&t_locs, std::max<u64>(1, nl) * 8));
+        if (nk) HIPCHK(hipMemcpy(t_keys, desc->keys, nk * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(t_off, desc->list_off, (nk + 1) * 8, hipMemcpyHostToDevice));
+        if (nl) HIPCHK(hipMemcpy(t_locs, desc->locs, nl * 8, hipMemcpyHostToDevice));
+        d_keys = t_keys; d_off = t_off; d_locs = t_locs;
+    }
+
+    mcq_db* db = new mcq_db();
+    memset(db, 0, sizeof(*db));
+    db->device = desc->device; db->n_shards = n_shards; db->shard_id = desc->shard_id;
+
+    // owned list lengths -> compacted offsets
+    u64 *d_len = nullptr, *d_new = nullptr;
+    HIPCHK(hipMalloc(&d_len, std::max<u64>(1, nk) * 8));
+    HIPCHK(hipMalloc(&d_new, (nk + 1) * 8));
+    const u32 TB = 256;
+    if (nk) hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id, d_len);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, 0, d_len, d_new, nk);
+    u64 nl_local = 0;
+    HIPCHK(hipMemcpy(&nl_local, d_new + nk, 8, hipMemcpyDeviceToHost));
+    // number of owned non-empty keys (for the table size) -- count on host from lengths
+    u64 nk_local = 0;
+    {
+        std::vector<u64> h_len(nk);
+        if (nk) HIPCHK(hipMemcpy(h_len.data(), d_len, nk * 8, hipMemcpyDeviceToHost));
+        for (u64 i = 0; i < nk; ++i) nk_local += h_len[i] > 0;
+    }
+    db->n_keys_local = nk_local; db->n_locs_local = nl_local;
+    db->nslots = std::max<u64>(1024, pow2ceil64(nk_local * 2));      // load factor <= 0.5
+    if (db->nslots > (1ull << 32)) { return fail(MCQ_E_UNSUPPORTED, "table too large"); }
+    HIPCHK(hipMalloc(&db->slots, db->nslots * sizeof(uint4)));
+    HIPCHK(hipMalloc(&db->locs, std::max<u64>(1, nl_local) * 8));
+    HIPCHK(hipMalloc(&db->tgt2tax, std::max<u32>(1, desc->n_targets) * 4));
+    if (desc->n_targets)
+        HIPCHK(hipMemcpy(db->tgt2tax, desc->tgt2tax, (u64)desc->n_targets * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fill_slots, dim3((u32)((db->nslots + TB - 1) / TB)), dim3(TB), 0, 0, db->slots, db->nslots);
+    if (nk) {
+        hipLaunchKernelGGL(k_insert_keys, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, db->slots, (u32)(db->nslots - 1),
+                           d_keys, d_new, nk, n_shards, desc->shard_id);
+        hipLaunchKernelGGL(k_copy_lists, dim3((u32)((nk * 64 + TB - 1) / TB)), dim3(TB), 0, 0, d_off, d_new, d_locs, db->locs, nk);
+    }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipGetLastError());
+    (void)hipFree(d_len); (void)hipFree(d_new);
+    if (t_keys) (void)hipFree(t_keys);
+    if (t_off) (void)hipFree(t_off);
+    if (t_locs) (void)hipFree(t_locs);
+
+    db->d.slots = db->slots; db->d.slot_mask = (u32)(db->nslots - 1); db->d.locs = db->locs;
+    db->d.tgt2tax = db->tgt2tax; db->d.n_targets = desc->n_targets;
+    db->d.k = desc->k; db->d.s = desc->sketch_size; db->d.winlen = desc->winlen; db->d.winstride = desc->winstride;
+    db->d.tgt_winstride = desc->tgt_winstride ? desc->tgt_winstride : desc->winstride;
+    db->bytes = db->nslots * sizeof(uint4) + std::max<u64>(1, nl_local) * 8 + (u64)desc->n_targets * 4;
+    *out = db;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_db_destroy(mcq_db* db) {
+    if (!db) return MCQ_OK;
+    (void)hipSetDevice(db->device);
+    (void)hipFree(db->slots); (void)hipFree(db->locs); (void)hipFree(db->tgt2tax);
+    delete db;
+    return MCQ_OK;
+}
+
+extern "C" uint64_t mcq_db_bytes(const mcq_db* db) { return db ? db->bytes : 0; }
+
+// ------------------------------------------------------------------ workspace
+extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t max_bases,
+                             uint64_t max_locs_per_query, mcq_ws** out) {
+    if (!db || !out) return fail(MCQ_E_ARG, "null argument");
+    if (max_queries >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "max_queries must be < 2^32 per batch");
+    HIPCHK(hipSetDevice(db->device));
+    mcq_ws* ws = new mcq_ws();
+    memset(ws, 0, sizeof(*ws));
+    ws->device = db->device; ws->max_queries = max_queries; ws->max_bases = max_bases;
+    u64 lmax = max_locs_per_query ? pow2ceil64(max_locs_per_query) : (1ull << 20);
+    if (lmax > (1ull << 30)) return fail(MCQ_E_UNSUPPORTED, "max_locs_per_query too large");
+    ws->sc.lmax = (u32)lmax;
+    ws->sc.fmax = 1u << 15;
+    ws->n_block_wgs = 256;
+    const u64 nb = (u64)ws->n_block_wgs;
+    HIPCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
+    HIPCHK(hipHostMalloc(&ws->ctr_host, sizeof(CountersDev)));
+    HIPCHK(hipMalloc(&ws->ovf_list, std::max<u64>(1, max_queries) * 4));
+    HIPCHK(hipMalloc(&ws->sc.feat, nb * ws->sc.fmax * 4));
+    HIPCHK(hipMalloc(&ws->sc.fpos, nb * ((u64)ws->sc.fmax + 1) * 4));
+    HIPCHK(hipMalloc(&ws->sc.foff, nb * ws->sc.fmax * 8));
+    HIPCHK(hipMalloc(&ws->sc.gbuf, nb * lmax * 8));
+    HIPCHK(hipMalloc(&ws->sc.ghits, nb * lmax * 4));
+    *out = ws;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_ws_destroy(mcq_ws* ws) {
+    if (!ws) return MCQ_OK;
+    (void)hipSetDevice(ws->device);
+    (void)hipFree(ws->ctr); (void)hipHostFree(ws->ctr_host); (void)hipFree(ws->ovf_list);
+    (void)hipFree(ws->sc.feat); (void)hipFree(ws->sc.fpos); (void)hipFree(ws->sc.foff); (void)hipFree(ws->sc.gbuf); (void)hipFree(ws->sc.ghits);
+    if (ws->d_bases) (void)hipFree(ws->d_bases);
+    if (ws->d_seq_off) (void)hipFree(ws->d_seq_off);
+    if (ws->d_cands) (void)hipFree(ws->d_cands);
+    if (ws->d_ncand) (void)hipFree(ws->d_ncand);
+    delete ws;
+    return MCQ_OK;
+}
+
+static int ensure_staging(mcq_ws* ws) {
+    if (ws->d_bases) return MCQ_OK;
+    HIPCHK(hipMalloc(&ws->d_bases, std::max<u64>(1, ws->max_bases)));
+    HIPCHK(hipMalloc(&ws->d_seq_off, (2 * ws->max_queries + 2) * 8));
+    HIPCHK(hipMalloc(&ws->d_cands, std::max<u64>(1, ws->max_queries) * 16 * 16));
+    HIPCHK(hipMalloc(&ws->d_ncand, std::max<u64>(1, ws->max_queries) * 4));
+    return MCQ_OK;
+}
+
+static const int kLcapWave = 512;
+static const int kLcapBlock = 8192;
+
+static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const OptDev& od, const OutDev& o,
+                        hipStream_t st, int force_block, const DebugDev& dbg) {
+    HIPCHK(hipMemsetAsync(ws->ctr, 0, sizeof(CountersDev), st));
+    if (b.nq == 0) return MCQ_OK;
+    u64 want = (b.nq + 3) / 4;
+    u32 grid = (u32)std::min<u64>(want, 256ull * 24);
+    hipLaunchKernelGGL((k_query_wave<kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
+    hipLaunchKernelGGL((k_query_block<kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
+                       (const u32*)ws->ovf_list, ws->sc, dbg);
+    HIPCHK(hipGetLastError());
+    ws->last_nq = b.nq;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, const mcq_query_opts* opt,
+                         mcq_result* out, void* stream) {
+    if (!db || !ws || !in || !opt || !out) return fail(MCQ_E_ARG, "null argument");
+    OptDev od;
+    int rc = make_opt(opt, od);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(db->device));
+    hipStream_t st = (hipStream_t)stream;
+    const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
+    if (nq > ws->max_queries) return fail(MCQ_E_ARG, "batch has more queries than the workspace allows");
+    const bool dev_in = (in->flags & MCQ_DEVICE_PTRS) != 0, dev_out = (out->flags & MCQ_DEVICE_PTRS) != 0;
+    BatchDev b; b.n_seq = in->n_seqs; b.nq = nq; b.paired = in->paired ? 1 : 0;
+    OutDev o;
+    u64 nbases = 0;
+    if (!dev_in) {
+        nbases = in->n_seqs ? in->seq_off[in->n_seqs] - in->seq_off[0] : 0;
+        if (nbases > ws->max_bases) return fail(MCQ_E_ARG, "batch has more bases than the workspace allows");
+        if (in->n_seqs && in->seq_off[0] != 0) return fail(MCQ_E_ARG, "host batches must start at offset 0");
+    }
+    if (!dev_in || !dev_out) { rc = ensure_staging(ws); if (rc) return rc; }
+    if (!dev_in) {
+        if (nbases) HIPCHK(hipMemcpyAsync(ws->d_bases, in->bases, nbases, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ws->d_seq_off, in->seq_off, (in->n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
+        b.bases = ws->d_bases; b.seq_off = ws->d_seq_off;
+    } else { b.bases = in->bases; b.seq_off = in->seq_off; }
+    if (!dev_out) { o.cands = ws->d_cands; o.ncand = ws->d_ncand; }
+    else { o.cands = (u32*)out->cands; o.ncand = out->n_cand; }
+    DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
+    rc = launch_query(db, ws, b, od, o, st, (opt->flags & 0x100u) ? 1 : 0, dbg);
+    if (rc) return rc;
+    if (!dev_out && nq) {
+        HIPCHK(hipMemcpyAsync(out->cands, ws->d_cands, nq * od.max_cand * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(out->n_cand, ws->d_ncand, nq * 4, hipMemcpyDeviceToHost, st));
+    }
+    if (!dev_in || !dev_out) return mcq_ws_sync(ws, stream, nullptr);
+    return MCQ_OK;
+}
+
+extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
+    if (!ws) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ws->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(ws->ctr_host, ws->ctr, sizeof(CountersDev), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (stats) {
+        stats->n_queries = ws->last_nq;
+        stats->n_features = ws->ctr_host->n_features; stats->n_hit_features = ws->ctr_host->n_hit_features;
+        stats->n_locations = ws->ctr_host->n_locations; stats->n_cands = ws->ctr_host->n_cands;
+        stats->n_overflow = ws->ctr_host->ovf_count;
+    }
+    if (ws->ctr_host->err_count)
+        return fail(MCQ_E_CAPACITY, std::to_string(ws->ctr_host->err_count) + " queries exceeded the workspace's per-query capacity");
+    return MCQ_OK;
+}
+
+// ------------------------------------------------------------------ debug tap: sorted match lists
+extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* in,
+                                 uint64_t* match_off, uint64_t* matches, uint64_t cap) {
+    if (!db || !ws || !in || !match_off) return fail(MCQ_E_ARG, "null argument");
+    if (in->flags & MCQ_DEVICE_PTRS) return fail(MCQ_E_ARG, "debug tap takes host batches");
+    HIPCHK(hipSetDevice(db->device));
+    const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
+    if (nq > ws->max_queries) return fail(MCQ_E_ARG, "batch too large");
+    int rc = ensure_staging(ws); if (rc) return rc;
+    const u64 nbases = in->n_seqs ? in->seq_off[in->n_seqs] : 0;
+    if (nbases > ws->max_bases) return fail(MCQ_E_ARG, "batch too large");
+    if (nbases) HIPCHK(hipMemcpy(ws->d_bases, in->bases, nbases, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ws->d_seq_off, in->seq_off, (in->n_seqs + 1) * 8, hipMemcpyHostToDevice));
+    mcq_query_opts qo; qo.max_cand = 1; qo.emulate_ranks = 1; qo.insert_size_max = 0; qo.flags = 0;
+    OptDev od; rc = make_opt(&qo, od); if (rc) return rc;
+    BatchDev b; b.bases = ws->d_bases; b.seq_off = ws->d_seq_off; b.n_seq = in->n_seqs; b.nq = nq; b.paired = in->paired ? 1 : 0;
+    OutDev o; o.cands = ws->d_cands; o.ncand = ws->d_ncand;
+    u64 *d_cnt = nullptr, *d_off = nullptr, *d_m = nullptr;
+    HIPCHK(hipMalloc(&d_cnt, std::max<u64>(1, nq) * 8));
+    HIPCHK(hipMalloc(&d_off, (nq + 1) * 8));
+    DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
+    dbg.mode = 1; dbg.match_cnt = d_cnt;
+    rc = launch_query(db, ws, b, od, o, 0, 1, dbg); if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<u64> cnt(nq);
+    if (nq) HIPCHK(hipMemcpy(cnt.data(), d_cnt, nq * 8, hipMemcpyDeviceToHost));
+    match_off[0] = 0;
+    for (u64 q = 0; q < nq; ++q) match_off[q + 1] = match_off[q] + cnt[q];
+    if (matches && match_off[nq] <= cap && match_off[nq] > 0) {
+        HIPCHK(hipMalloc(&d_m, match_off[nq] * 8));
+        HIPCHK(hipMemcpy(d_off, match_off, (nq + 1) * 8, hipMemcpyHostToDevice));
+        dbg.mode = 2; dbg.match_off = d_off; dbg.matches = d_m;
+        rc = launch_query(db, ws, b, od, o, 0, 1, dbg); if (rc) return rc;
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipMemcpy(matches, d_m, match_off[nq] * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(d_m);
+    }
+    (void)hipFree(d_cnt); (void)hipFree(d_off);
+    return MCQ_OK;
+}

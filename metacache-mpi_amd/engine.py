@@ -1,0 +1,188 @@
+"""ctypes mirror of include/mcq.h.  Names and argument meaning follow the header.
+
+Device buffers are passed as raw pointers (e.g. torch.Tensor.data_ptr()); host
+buffers as numpy arrays.  The HIP library is mandatory: there is no fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import lib_path
+
+MCQ_DEVICE_PTRS = 1
+MCQ_QUIRK_SEQ_DROP = 2
+MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-query path
+
+MCQ_OK, MCQ_E_ARG, MCQ_E_HIP, MCQ_E_CAPACITY, MCQ_E_UNSUPPORTED = 0, -1, -2, -3, -4
+
+
+class McqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mcq error %d: %s" % (code, msg))
+        self.code = code
+
+
+class DbDesc(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("sketch_size", C.c_uint32), ("winlen", C.c_uint32), ("winstride", C.c_uint32),
+                ("tgt_winstride", C.c_uint32), ("n_targets", C.c_uint32), ("n_keys", C.c_uint64), ("n_locs", C.c_uint64),
+                ("keys", C.c_void_p), ("list_off", C.c_void_p), ("locs", C.c_void_p), ("tgt2tax", C.c_void_p),
+                ("n_shards", C.c_uint32), ("shard_id", C.c_uint32), ("flags", C.c_uint32), ("device", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("n_seqs", C.c_uint64), ("bases", C.c_void_p), ("seq_off", C.c_void_p),
+                ("paired", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class QueryOpts(C.Structure):
+    _fields_ = [("max_cand", C.c_uint32), ("emulate_ranks", C.c_uint32), ("insert_size_max", C.c_uint64),
+                ("flags", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("cands", C.c_void_p), ("n_cand", C.c_void_p), ("flags", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("n_features", C.c_uint64), ("n_hit_features", C.c_uint64),
+                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Loads libmcq_hip.so; raises if it has not been built (no CPU fallback)."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError("HIP library %s missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % p)
+        L = C.CDLL(p)
+        L.mcq_last_error.restype = C.c_char_p
+        L.mcq_version.restype = C.c_char_p
+        L.mcq_db_create.argtypes = [C.POINTER(DbDesc), C.POINTER(C.c_void_p)]
+        L.mcq_db_destroy.argtypes = [C.c_void_p]
+        L.mcq_db_bytes.restype = C.c_uint64; L.mcq_db_bytes.argtypes = [C.c_void_p]
+        L.mcq_ws_create.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_void_p)]
+        L.mcq_ws_destroy.argtypes = [C.c_void_p]
+        L.mcq_query.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
+        L.mcq_ws_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.mcq_owner.restype = C.c_uint32; L.mcq_owner.argtypes = [C.c_uint32, C.c_uint32]
+        L.mcq_debug_matches.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise McqError(rc, lib().mcq_last_error().decode())
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Database:
+    """GPU-resident feature -> locations multimap (one shard).  Mirrors the query half
+    of the reference's sketch_database: built from the union of its shard tables."""
+
+    def __init__(self, keys, list_off, locs, tgt2tax, k=16, sketch_size=16, winlen=128, winstride=113,
+                 tgt_winstride=0, n_shards=1, shard_id=0, device=0, device_ptrs=None):
+        """keys/list_off/locs/tgt2tax: numpy arrays (host) -- or, with device_ptrs=dict(
+        keys=ptr, list_off=ptr, locs=ptr, tgt2tax=ptr, n_keys=, n_locs=, n_targets=), raw device pointers."""
+        d = DbDesc()
+        d.k, d.sketch_size, d.winlen, d.winstride, d.tgt_winstride = k, sketch_size, winlen, winstride, tgt_winstride
+        d.n_shards, d.shard_id, d.device = n_shards, shard_id, device
+        if device_ptrs is None:
+            self._keep = (np.ascontiguousarray(keys, np.uint32), np.ascontiguousarray(list_off, np.uint64),
+                          np.ascontiguousarray(locs, np.uint64), np.ascontiguousarray(tgt2tax, np.uint32))
+            kk, oo, ll, tt = self._keep
+            assert len(oo) == len(kk) + 1
+            d.n_keys, d.n_locs, d.n_targets = len(kk), len(ll), len(tt)
+            d.keys, d.list_off, d.locs, d.tgt2tax = _np_ptr(kk), _np_ptr(oo), _np_ptr(ll), _np_ptr(tt)
+            d.flags = 0
+        else:
+            p = device_ptrs
+            d.n_keys, d.n_locs, d.n_targets = p["n_keys"], p["n_locs"], p["n_targets"]
+            d.keys, d.list_off, d.locs, d.tgt2tax = p["keys"], p["list_off"], p["locs"], p["tgt2tax"]
+            d.flags = MCQ_DEVICE_PTRS
+        self.k, self.sketch_size, self.winlen, self.winstride = k, sketch_size, winlen, winstride
+        self.device = device
+        h = C.c_void_p()
+        _chk(lib().mcq_db_create(C.byref(d), C.byref(h)))
+        self.h = h
+
+    def bytes(self):
+        return int(lib().mcq_db_bytes(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcq_db_destroy(self.h); self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class Workspace:
+    def __init__(self, db, max_queries, max_bases, max_locs_per_query=0):
+        self.db = db
+        self.max_queries = max_queries
+        h = C.c_void_p()
+        _chk(lib().mcq_ws_create(db.h, max_queries, max_bases, max_locs_per_query, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcq_ws_destroy(self.h); self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def sync(self, stream=None):
+        st = Stats()
+        _chk(lib().mcq_ws_sync(self.h, stream, C.byref(st)))
+        return st.as_dict()
+
+    # ---- host-buffer call: numpy in, numpy out (copies + sync inside) -------------
+    def query_host(self, bases, seq_off, paired, max_cand=2, emulate_ranks=1, insert_size_max=0, flags=0):
+        seq_off = np.ascontiguousarray(seq_off, np.uint64)
+        n_seqs = len(seq_off) - 1
+        nq = n_seqs // 2 if paired else n_seqs
+        bases_arr = np.frombuffer(bases, dtype=np.uint8) if not isinstance(bases, np.ndarray) else bases
+        bases_arr = np.ascontiguousarray(bases_arr)
+        b = Batch(n_seqs, _np_ptr(bases_arr) if len(bases_arr) else None, _np_ptr(seq_off), 1 if paired else 0, 0)
+        o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
+        cands = np.zeros((max(nq, 1), max_cand, 4), np.uint32)
+        ncand = np.zeros(max(nq, 1), np.uint32)
+        r = Result(_np_ptr(cands), _np_ptr(ncand), 0)
+        _chk(lib().mcq_query(self.db.h, self.h, C.byref(b), C.byref(o), C.byref(r), None))
+        return cands[:nq], ncand[:nq]
+
+    # ---- device-buffer call: raw pointers, enqueue only --------------------------
+    def query_device(self, bases_ptr, seq_off_ptr, n_seqs, paired, cands_ptr, ncand_ptr, max_cand=2,
+                     emulate_ranks=1, insert_size_max=0, flags=0, stream=None):
+        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 1 if paired else 0, MCQ_DEVICE_PTRS)
+        o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
+        r = Result(cands_ptr, ncand_ptr, MCQ_DEVICE_PTRS)
+        _chk(lib().mcq_query(self.db.h, self.h, C.byref(b), C.byref(o), C.byref(r), stream))
+
+    def debug_matches(self, bases, seq_off, paired):
+        seq_off = np.ascontiguousarray(seq_off, np.uint64)
+        n_seqs = len(seq_off) - 1
+        nq = n_seqs // 2 if paired else n_seqs
+        bases_arr = np.ascontiguousarray(np.frombuffer(bases, dtype=np.uint8))
+        b = Batch(n_seqs, _np_ptr(bases_arr) if len(bases_arr) else None, _np_ptr(seq_off), 1 if paired else 0, 0)
+        moff = np.zeros(nq + 1, np.uint64)
+        _chk(lib().mcq_debug_matches(self.db.h, self.h, C.byref(b), _np_ptr(moff), None, 0))
+        m = np.zeros(max(1, int(moff[nq])), np.uint64)
+        _chk(lib().mcq_debug_matches(self.db.h, self.h, C.byref(b), _np_ptr(moff), _np_ptr(m), len(m)))
+        return moff, m[:int(moff[nq])]
+
+
+def owner(feature, n_shards):
+    return int(lib().mcq_owner(feature, n_shards))

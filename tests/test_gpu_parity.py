@@ -1,0 +1,98 @@
+"""HIP engine (through the C ABI) vs the oracle and the reference's own outputs.
+Everything here needs a real MI355X."""
+import importlib
+
+import numpy as np
+import pytest
+
+from golden_util import Fixture
+from oracle import dbfile
+from oracle import mc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("mini", 2), ("mini", 4), ("mini", 8), ("tie", 2), ("tie", 4), ("noanc", 2), ("noanc", 4)]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    return importlib.import_module("metacache-mpi_amd.engine")
+
+
+def _dbs(eng, fx, shards=None):
+    keys, off, locs = dbfile.union_shards(fx.shards if shards is None else shards)
+    p = fx.params
+    kw = dict(k=p["qk"], winlen=p["qwinlen"], winstride=p["qwinstride"], tgt_winstride=p["winstride"])
+    t2t = fx.tgt2tax()
+    return (eng.Database(keys, off, locs, t2t, sketch_size=p["qs"], **kw),
+            orc.OracleDb(keys, off, locs, t2t, s=p["qs"], **kw))
+
+
+def _same(cands, ncand, oc, on):
+    assert np.array_equal(ncand, on), np.nonzero(ncand != on)[0][:10]
+    for q in range(len(on)):
+        assert np.array_equal(cands[q, :on[q]], oc[q, :on[q]]), (q, cands[q, :on[q]], oc[q, :on[q]])
+
+
+@pytest.mark.parametrize("tag,P", CASES)
+@pytest.mark.parametrize("block", [False, True], ids=["wave", "block"])
+def test_final_vs_reference_cli(eng, tag, P, block):
+    fx = Fixture(tag, P)
+    db, odb = _dbs(eng, fx)
+    bases, seq_off = orc.pack_reads(fx.interleaved())
+    ws = eng.Workspace(db, len(fx.names), len(bases))
+    flags = eng.MCQ_QUIRK_SEQ_DROP | (eng.MCQ_FORCE_BLOCK_PATH if block else 0)
+    cands, ncand = ws.query_host(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=P, flags=flags)
+    for q, name in enumerate(fx.names):
+        mine = [[fx.tax.id_of_key(c[0]), int(c[1])] for c in cands[q, :ncand[q]]]
+        assert mine == fx.final[name]["tophits"], (name, mine, fx.final[name])
+    oc, on = odb.query(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=P, quirk_seq_drop=1)
+    _same(cands, ncand, oc, on)
+    st = ws.sync()
+    assert st["n_overflow"] == (len(fx.names) if block else st["n_overflow"])
+
+
+@pytest.mark.parametrize("tag,P", [("mini", 2), ("mini", 8), ("tie", 4)])
+def test_per_rank_candidates_with_positions(eng, tag, P):
+    # emulate_ranks = 1 on a single reference shard: the reference's own per-rank
+    # top list including window ranges (ref_query dump 'C')
+    fx = Fixture(tag, P)
+    bases, seq_off = orc.pack_reads(fx.interleaved())
+    for r in range(P):
+        db, odb = _dbs(eng, fx, [fx.shards[r]])
+        ws = eng.Workspace(db, len(fx.names), len(bases))
+        for flags in (0, eng.MCQ_FORCE_BLOCK_PATH):
+            cands, ncand = ws.query_host(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=1, flags=flags)
+            for q in range(len(fx.names)):
+                Cx = fx.ranks["C"][str(q)][str(r)]
+                mine = [[fx.tax.id_of_key(c[0]), int(c[1]), int(c[2]), int(c[3])] for c in cands[q, :ncand[q]]]
+                assert mine == Cx, (q, r, flags)
+
+
+@pytest.mark.parametrize("tag,P", [("mini", 4)])
+def test_sorted_match_lists(eng, tag, P):
+    fx = Fixture(tag, P)
+    bases, seq_off = orc.pack_reads(fx.interleaved())
+    for r in range(P):
+        db, odb = _dbs(eng, fx, [fx.shards[r]])
+        ws = eng.Workspace(db, len(fx.names), len(bases))
+        moff, m = ws.debug_matches(bases, seq_off, True)
+        for q in range(len(fx.names)):
+            M = fx.ranks["M"][str(q)][str(r)]
+            got = m[int(moff[q]):int(moff[q + 1])]
+            assert [[int(x >> np.uint64(32)), int(x & np.uint64(0xFFFFFFFF))] for x in got] == M, (q, r)
+
+
+def test_single_end_and_empty(eng):
+    fx = Fixture("mini", 2)
+    db, odb = _dbs(eng, fx)
+    seqs = fx.r1 + ["", "ACGT", "N" * 200]
+    bases, seq_off = orc.pack_reads(seqs)
+    ws = eng.Workspace(db, len(seqs), len(bases) + 1)
+    for P in (1, 2):
+        cands, ncand = ws.query_host(bases, seq_off, False, max_cand=4, emulate_ranks=P)
+        oc, on = odb.query(bases, seq_off, False, max_cand=4, emulate_ranks=P)
+        _same(cands, ncand, oc, on)
+    # empty batch
+    c, n = ws.query_host(b"", np.zeros(1, np.uint64), False)
+    assert len(n) == 0
