@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- query reads/sec of the MI355X query-path engine on BASELINE.json's configs.
+
+One step = one pass of the hot path (sketch -> probe -> gather -> sort -> candidates ->
+fold) over one batch of synthetic reads already resident in HBM.  N=1 runs config[1]
+("1xMI355X: DB from ~500 bacterial-size genomes in HBM, 50 M synthetic 150 bp reads,
+k=16 s=16"): the default --steps x --batch covers 50 M reads.  Prints ONE JSON line.
+
+  python bench.py --gpus 1 --steps 48 --warmup 2
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1 << 20, help="reads per step per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--species", type=int, default=50)
+    ap.add_argument("--strains", type=int, default=10)
+    ap.add_argument("--genome-min", type=int, default=2_000_000)
+    ap.add_argument("--genome-max", type=int, default=6_000_000)
+    ap.add_argument("--divergence", type=float, default=0.02)
+    ap.add_argument("--emulate-ranks", type=int, default=2, help="reference rank count whose results are reproduced")
+    ap.add_argument("--max-cand", type=int, default=2)
+    ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"])
+    ap.add_argument("--small", action="store_true", help="tiny DB / few reads (plumbing check)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--distinct-batches", type=int, default=0, help="0 = one per step (capped by memory)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(n_bases, st):
+    # B = L_bases + 16 B x features (one slot per probe) + 8 B x locations + 16 B x candidates
+    return n_bases + 16 * st["n_features"] + 8 * st["n_locations"] + 16 * st["n_cands"]
+
+
+def main():
+    a = parse()
+    if a.small:
+        a.species, a.strains, a.genome_min, a.genome_max = 6, 4, 150_000, 300_000
+        a.batch = min(a.batch, 1 << 16)
+        a.steps = min(a.steps, 4)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    pkg = importlib.import_module("metacache-mpi_amd")
+    pkg.build_hip()
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    synth = importlib.import_module("metacache-mpi_amd.synth")
+
+    mode = a.mode
+    if mode == "auto":
+        mode = "single" if world == 1 else "sharded"
+    if world == 1:
+        mode = "single"
+
+    # ---- database: same seeded genomes on every rank; each rank keeps its hash-range shard
+    t_setup = time.time()
+    gen_bases, gen_off, species = synth.make_genomes(a.species, a.strains, a.genome_min, a.genome_max,
+                                                     a.divergence, seed=3, device=dev)
+    keys, list_off, locs, _ = dbbuild.build_table(gen_bases, gen_off, emulate_ranks=a.emulate_ranks)
+    n_shards, shard_id = (world, rank) if mode == "sharded" else (1, 0)
+    db = dbbuild.make_database(keys, list_off, locs, species, n_shards=n_shards, shard_id=shard_id)
+    n_keys, n_locs, n_targets = keys.numel(), locs.numel(), species.numel()
+    db_bp = int(gen_off[-1].item())
+
+    # ---- reads (distinct batches, resident in HBM before the clock starts)
+    L, B = a.read_len, a.batch
+    nb = a.distinct_batches or a.steps
+    free = torch.cuda.mem_get_info(dev)[0]
+    nb = max(1, min(nb, int(free * 0.5) // (B * L * 3)))
+    batches = []
+    for i in range(nb):
+        r, off, _ = synth.sample_reads(gen_bases, gen_off, B, L, 0.005, 0.001, seed=1000 + 7919 * rank + i)
+        batches.append(r)
+    read_off = off
+    sharded = None
+    if mode == "sharded":
+        sh = importlib.import_module("metacache-mpi_amd.sharded")
+        sharded = sh.ShardedQuery(db, world, rank, dev, max_queries=B, max_bases=B * L, read_len_hint=L)
+    ws = eng.Workspace(db, B, B * L)
+    cands = torch.zeros((B, a.max_cand, 4), dtype=torch.int32, device=dev)
+    ncand = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    torch.cuda.synchronize(dev)
+    t_setup = time.time() - t_setup
+
+    def step(i):
+        r = batches[i % nb]
+        if sharded is not None:
+            sharded.query(r, read_off, B, False, cands, ncand, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks)
+        else:
+            ws.query_device(r.data_ptr(), read_off.data_ptr(), B, False, cands.data_ptr(), ncand.data_ptr(),
+                            max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, stream=stream)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    ws.timing(True)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = (sharded.last_stats() if sharded is not None else ws.sync())
+    kms, kn = ws.kernel_time()
+    ws.timing(False)
+
+    total_reads = a.steps * B * world
+    value = total_reads / elapsed
+    out = {
+        "metric": "query reads/sec (whole node)", "value": value, "unit": "reads/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE configs[1]: %d synthetic genomes (%d species x %d strains, %.1f%% divergence, %.2f Gbp) in HBM, "
+                        "%d x %d bp single-end reads per step per GPU, k=16 s=16 w=128/113" %
+                        (n_targets, a.species, a.strains, 100 * a.divergence, db_bp / 1e9, B, L),
+            "reads_total": total_reads, "db_keys": n_keys, "db_locations": n_locs, "db_hbm_bytes": db.bytes(),
+            "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "distinct_batches": nb,
+            "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
+                            "sharded": "feature table hash-range-sharded over %d GPUs, all-to-all of features and hits" % world}[mode],
+            "setup_s": round(t_setup, 1),
+        },
+    }
+    if sharded is None and kn > 0:
+        algo = algorithmic_bytes(B * L, st)
+        avg_ms = kms / kn
+        ach = algo / (avg_ms * 1e-3) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "k_query_wave", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": avg_ms, "launches_timed": kn,
+                           "bytes_per_read": algo / B,
+                           "per_launch": {k: st[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow")}}
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches[(a.warmup + a.steps - 1) % nb], read_off,
+                                           cands, ncand, B, L)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, keys, list_off, locs, species, reads, read_off, cands, ncand, B, L):
+    """The oracle (bit-exact CPU restatement of the reference path) timed on this box's
+    host cores, on a bounded sample of the same batch, checked against the GPU result."""
+    from oracle import mc_oracle as orc
+    cores = os.cpu_count() or 1
+    odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), list_off.cpu().numpy().astype(np.uint64),
+                       locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
+    n0 = min(B, 20000)
+    rb = reads[: n0 * L].cpu().numpy().tobytes()
+    ro = read_off[: n0 + 1].cpu().numpy().astype(np.uint64)
+    t0 = time.perf_counter()
+    odb.query(rb, ro, False, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, threads=cores)
+    rate0 = n0 / (time.perf_counter() - t0)
+    n1 = int(max(n0, min(B, rate0 * a.cpu_seconds)))
+    rb = reads[: n1 * L].cpu().numpy().tobytes()
+    ro = read_off[: n1 + 1].cpu().numpy().astype(np.uint64)
+    t0 = time.perf_counter()
+    oc, on = odb.query(rb, ro, False, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, threads=cores)
+    dt = time.perf_counter() - t0
+    gc = cands[:n1].cpu().numpy().view(np.uint32); gn = ncand[:n1].cpu().numpy().view(np.uint32)
+    ok = bool(np.array_equal(gn, on))
+    if ok:
+        mask = np.arange(a.max_cand)[None, :] < on[:, None]
+        ok = bool(np.array_equal(gc[mask], oc[mask]))
+    return {"value": n1 / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the last timed batch, %d threads, DB build excluded" % (n1, cores),
+            "seconds": dt, "gpu_matches_cpu_on_sample": ok}
+
+
+if __name__ == "__main__":
+    main()

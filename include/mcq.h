@@ -44,9 +44,10 @@ enum {
 /* flags */
 enum {
     MCQ_DEVICE_PTRS = 1u,       /* the pointers in this struct are device pointers     */
-    MCQ_QUIRK_SEQ_DROP = 2u     /* emulate the reference's u32 wire format: a sequence-
+    MCQ_QUIRK_SEQ_DROP = 2u,    /* emulate the reference's u32 wire format: a sequence-
                                    level taxon (key bit 31 set) sent by a non-root rank
                                    is dropped (src/querying.h:958, :983-985)            */
+    MCQ_FORCE_BLOCK_PATH = 0x100u /* test hook: every query takes the workgroup path     */
 };
 
 /* Database description = the union of the reference's P shard tables
@@ -169,6 +170,12 @@ int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, const uint64_t*
 /* shard that owns a feature: a range of h2(f) = thomas_mueller_hash(f)
  * (src/hash_int.h:39-45), never of f itself                          */
 uint32_t mcq_owner(uint32_t feature, uint32_t n_shards);
+
+/* Per-kernel timing of the fused query kernel (HIP events on the call's stream), for the
+ * roofline line of bench.py.  enable != 0 starts recording; mcq_ws_kernel_time returns the
+ * summed duration and launch count since enabling (synchronises the recorded events).   */
+int mcq_ws_timing(mcq_ws* ws, int enable);
+int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_launches);
 
 /* ---- debug / parity taps (rows 5 and 8 in isolation) ----------------------------- */
 /* sorted match list of every query: match_off[q..q+1) into matches (capacity cap)   */

@@ -72,6 +72,11 @@ struct mcq_ws {
     // staging for host-pointer calls
     char* d_bases; u64* d_seq_off; u32* d_cands; u32* d_ncand;
     u64 last_nq;
+    // optional per-launch timing of the wave kernel
+    int timing;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev_used;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev_free;
+    double timed_ms; u64 timed_launches;
 };
 
 // ------------------------------------------------------------------ kernels: table build
@@ -254,20 +259,13 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
     return s_w[17];
 }
 
-template <bool kLds>
+// Tail of the workgroup path: fill B[0..n2p) through `load(t)`, sort, sweep, top lists.
+template <bool kLds, class Load>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
-                                           u64* B, u32* H, const u32* fpos, const u64* foff, u32 F, u32 T,
-                                           u32 numWindows, u64 q, u32 tid, const DebugDev& dbg) {
+                                           u64* B, u32* H, u32 T, u32 numWindows, u64 q, u32 tid,
+                                           const DebugDev& dbg, Load load) {
     const u32 n2p = pow2ceil(T);
-    for (u32 t = tid; t < n2p; t += 1024) {
-        u64 v = ~0ull;
-        if (t < T) {
-            u32 lo = 0, hi = F;                       // last j in [0,F) with fpos[j] <= t
-            while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (fpos[mid] <= t) lo = mid; else hi = mid; }
-            v = db.locs[foff[lo] + (t - fpos[lo])];
-        }
-        B[t] = v;
-    }
+    for (u32 t = tid; t < n2p; t += 1024) B[t] = (t < T) ? load(t) : ~0ull;
     __syncthreads();
     bitonic_sort(B, n2p, tid, 1024u, [] { __syncthreads(); });
     if (dbg.mode == 2) {
@@ -348,8 +346,138 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
             continue;
         }
         const u32 numWindows = (u32)(2 + (n1 + n2 > opt.insert_size_max ? n1 + n2 : opt.insert_size_max) / db.tgt_winstride);
-        if (pow2ceil(T) <= (u32)LCAPB) block_tail<true>(db, opt, out, ctr, s_buf, s_hits, fpos, foff, F, T, numWindows, q, tid, dbg);
-        else                           block_tail<false>(db, opt, out, ctr, gbuf, ghits, fpos, foff, F, T, numWindows, q, tid, dbg);
+        auto load = [&](u32 t) -> u64 {
+            u32 lo = 0, hi = F;                       // last j in [0,F) with fpos[j] <= t
+            while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (fpos[mid] <= t) lo = mid; else hi = mid; }
+            return db.locs[foff[lo] + (t - fpos[lo])];
+        };
+        if (pow2ceil(T) <= (u32)LCAPB) block_tail<true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, q, tid, dbg, load);
+        else                           block_tail<false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, q, tid, dbg, load);
+    }
+}
+
+// ------------------------------------------------------------------ staged kernels (sharded path, DB build)
+__global__ void k_count_windows(const u64* seq_off, u64 n_seqs, u32 W, u32 S, u64* cnt) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_seqs) cnt[i] = num_windows(seq_off[i + 1] - seq_off[i], W, S);
+}
+
+// one wave per window: window w belongs to the last sequence i with win_off[i] <= w
+__global__ __launch_bounds__(256) void k_sketch_windows(DbDev db, const char* bases, const u64* seq_off, u64 n_seqs,
+                                                        const u64* win_off, u32* features, u32* n_feat) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 n_win = win_off[n_seqs];
+    const u64 nwaves = (u64)gridDim.x * 4;
+    for (u64 w = (u64)blockIdx.x * 4 + wave; w < n_win; w += nwaves) {
+        u64 lo = 0, hi = n_seqs;
+        while (hi - lo > 1) { u64 mid = (lo + hi) >> 1; if (win_off[mid] <= w) lo = mid; else hi = mid; }
+        const u64 o0 = seq_off[lo], n = seq_off[lo + 1] - o0;
+        u64 beg; u32 wl;
+        window_of(n, db.winlen, db.winstride, (u32)(w - win_off[lo]), beg, wl);
+        u32 f;
+        u32 m = wave_sketch(bases + o0 + beg, wl, db.k, db.s, lane, f);
+        if (lane < db.s) features[w * db.s + lane] = (lane < m) ? f : MCQ_EMPTY;
+        if (lane == 0) n_feat[w] = m;
+    }
+}
+
+__global__ void k_lookup_count(DbDev db, const u32* features, u64 n, u32* list_len) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 off; u32 len;
+    probe(db, features[i], off, len);
+    list_len[i] = len;
+}
+
+// one wave per 64 consecutive features: probe again, then copy the lists cooperatively
+__global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* features, u64 n, const u64* out_off, u64* out_locs) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 ngroups = (n + 63) / 64, nwaves = (u64)gridDim.x * 4;
+    for (u64 g = (u64)blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
+        const u64 i = g * 64 + lane;
+        u64 off = 0; u32 len = 0;
+        if (i < n) probe(db, features[i], off, len);
+        const u64 obase = out_off[g * 64];
+        u32 incl = wave_incl_scan(len, lane);
+        u32 pos = incl - len;
+        const u32 T = bcast(incl, 63);
+        for (u32 base = 0; base < T; base += 64) {
+            const u32 t = base + lane;
+            const u32 tt = t < T ? t : T - 1;
+            u32 lo = 0;
+#pragma unroll
+            for (u32 step = 32; step > 0; step >>= 1) {
+                u32 c = lo + step;
+                u32 pc = __shfl(pos, (int)(c & 63), 64);
+                if (c < 64 && pc <= tt) lo = c;
+            }
+            u32 pj = __shfl(pos, (int)lo, 64);
+            u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
+            if (t < T) out_locs[obase + t] = db.locs[(((u64)ohi << 32) | olo) + (tt - pj)];
+        }
+    }
+}
+
+// rows 8-11 from per-query location segments (home GPU of the sharded path)
+template <int LCAP>
+__global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, u32* ovf_list,
+                                                     u64 nq, const u64* loc_off, const u64* locs, const u32* query_len) {
+    __shared__ u64 s_buf[4][LCAP];
+    __shared__ u32 s_hits[4][LCAP];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u64* buf = s_buf[wave];
+    u32* hits = s_hits[wave];
+    const u64 nwaves = (u64)gridDim.x * 4;
+    unsigned long long st_loc = 0, st_cand = 0;
+    for (u64 q = (u64)blockIdx.x * 4 + wave; q < nq; q += nwaves) {
+        const u64 b0 = loc_off[q], T64 = loc_off[q + 1] - b0;
+        if (T64 > (u64)LCAP) {
+            if (lane == 0) { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
+            continue;
+        }
+        const u32 T = (u32)T64;
+        st_loc += T;
+        if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
+        const u32 n2p = pow2ceil(T);
+        for (u32 t = lane; t < n2p; t += 64) buf[t] = (t < T) ? locs[b0 + t] : ~0ull;
+        wave_sync();
+        bitonic_sort(buf, n2p, lane, 64u, [] { wave_sync(); });
+        const u64 ql = query_len[q];
+        const u32 numWindows = (u32)(2 + (ql > opt.insert_size_max ? ql : opt.insert_size_max) / db.tgt_winstride);
+        walk_targets(buf, hits, T, numWindows, lane, 64u);
+        wave_sync();
+        st_cand += topk_fold_write(db, opt, out, buf, hits, T, numWindows, q, lane);
+    }
+    if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
+}
+
+template <int LCAPB>
+__global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
+                                                       ScratchDev sc, const u64* loc_off, const u64* locs, const u32* query_len) {
+    __shared__ u64 s_buf[LCAPB];
+    __shared__ u32 s_hits[LCAPB];
+    const u32 tid = threadIdx.x;
+    u64* gbuf = sc.gbuf + (u64)blockIdx.x * sc.lmax;
+    u32* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
+    const u32 n_ovf = ctr->ovf_count;
+    DebugDev dbg; dbg.mode = 0; dbg.match_cnt = nullptr; dbg.match_off = nullptr; dbg.matches = nullptr;
+    for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
+        const u64 q = ovf_list[it];
+        const u64 b0 = loc_off[q], T64 = loc_off[q + 1] - b0;
+        if (T64 > sc.lmax) {
+            if (tid == 0) { out.ncand[q] = 0; atomicAdd(&ctr->err_count, 1u); }
+            continue;
+        }
+        const u32 T = (u32)T64;
+        if (tid == 0) atomicAdd(&ctr->n_locations, (unsigned long long)T);
+        const u64 ql = query_len[q];
+        const u32 numWindows = (u32)(2 + (ql > opt.insert_size_max ? ql : opt.insert_size_max) / db.tgt_winstride);
+        auto load = [&](u32 t) -> u64 { return locs[b0 + t]; };
+        if (pow2ceil(T) <= (u32)LCAPB) block_tail<true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, q, tid, dbg, load);
+        else                           block_tail<false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, q, tid, dbg, load);
     }
 }
 
@@ -500,6 +628,8 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     ws->sc.lmax = (u32)lmax;
     ws->sc.fmax = 1u << 15;
     ws->n_block_wgs = 256;
+    ws->ev_used = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
+    ws->ev_free = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     const u64 nb = (u64)ws->n_block_wgs;
     HIPCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
     HIPCHK(hipHostMalloc(&ws->ctr_host, sizeof(CountersDev)));
@@ -522,6 +652,10 @@ extern "C" int mcq_ws_destroy(mcq_ws* ws) {
     if (ws->d_seq_off) (void)hipFree(ws->d_seq_off);
     if (ws->d_cands) (void)hipFree(ws->d_cands);
     if (ws->d_ncand) (void)hipFree(ws->d_ncand);
+    for (auto* v : {ws->ev_used, ws->ev_free}) {
+        for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        delete v;
+    }
     delete ws;
     return MCQ_OK;
 }
@@ -544,7 +678,14 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     if (b.nq == 0) return MCQ_OK;
     u64 want = (b.nq + 3) / 4;
     u32 grid = (u32)std::min<u64>(want, 256ull * 24);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ws->timing) {
+        if (!ws->ev_free->empty()) { e0 = ws->ev_free->back().first; e1 = ws->ev_free->back().second; ws->ev_free->pop_back(); }
+        else { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); }
+        HIPCHK(hipEventRecord(e0, st));
+    }
     hipLaunchKernelGGL((k_query_wave<kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
+    if (ws->timing) { HIPCHK(hipEventRecord(e1, st)); ws->ev_used->emplace_back(e0, e1); }
     hipLaunchKernelGGL((k_query_block<kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
                        (const u32*)ws->ovf_list, ws->sc, dbg);
     HIPCHK(hipGetLastError());
@@ -645,5 +786,109 @@ extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* 
         (void)hipFree(d_m);
     }
     (void)hipFree(d_cnt); (void)hipFree(d_off);
+    return MCQ_OK;
+}
+
+// ------------------------------------------------------------------ staged entry points (device pointers only)
+extern "C" int mcq_count_windows(const mcq_db* db, const mcq_batch* in, uint64_t* win_off, void* stream) {
+    if (!db || !in || !win_off) return fail(MCQ_E_ARG, "null argument");
+    if (!(in->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "staged entry points take device pointers");
+    HIPCHK(hipSetDevice(db->device));
+    hipStream_t st = (hipStream_t)stream;
+    const u64 n = in->n_seqs;
+    u64* cnt = nullptr;
+    HIPCHK(hipMallocAsync((void**)&cnt, std::max<u64>(1, n) * 8, st));
+    if (n) hipLaunchKernelGGL(k_count_windows, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, in->seq_off, n, db->d.winlen, db->d.winstride, cnt);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, (const u64*)cnt, win_off, n);
+    HIPCHK(hipFreeAsync(cnt, st));
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+extern "C" int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t* win_off,
+                          uint32_t* features, uint32_t* n_feat, void* stream) {
+    if (!db || !in || !win_off || !features || !n_feat) return fail(MCQ_E_ARG, "null argument");
+    if (!(in->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "staged entry points take device pointers");
+    HIPCHK(hipSetDevice(db->device));
+    if (in->n_seqs == 0) return MCQ_OK;
+    hipLaunchKernelGGL(k_sketch_windows, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, db->d, in->bases, in->seq_off,
+                       in->n_seqs, win_off, features, n_feat);
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+extern "C" int mcq_lookup_count(const mcq_db* db, const uint32_t* features, uint64_t n_features,
+                                uint32_t* list_len, void* stream) {
+    if (!db || (n_features && (!features || !list_len))) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(db->device));
+    if (n_features == 0) return MCQ_OK;
+    hipLaunchKernelGGL(k_lookup_count, dim3((u32)((n_features + 255) / 256)), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, list_len);
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+extern "C" int mcq_lookup_gather(const mcq_db* db, const uint32_t* features, uint64_t n_features,
+                                 const uint64_t* out_off, uint64_t* out_locs, void* stream) {
+    if (!db || (n_features && (!features || !out_off))) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(db->device));
+    if (n_features == 0) return MCQ_OK;
+    u64 groups = (n_features + 63) / 64;
+    u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
+    hipLaunchKernelGGL(k_lookup_gather, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, out_off, out_locs);
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, const uint64_t* loc_off,
+                          uint64_t* locs, const uint32_t* query_len, const mcq_query_opts* opt, mcq_result* out, void* stream) {
+    if (!db || !ws || !opt || !out || (n_queries && (!loc_off || !query_len))) return fail(MCQ_E_ARG, "null argument");
+    if (!(out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "staged entry points take device pointers");
+    if (n_queries > ws->max_queries) return fail(MCQ_E_ARG, "more queries than the workspace allows");
+    OptDev od;
+    int rc = make_opt(opt, od);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(db->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(ws->ctr, 0, sizeof(CountersDev), st));
+    ws->last_nq = n_queries;
+    if (n_queries == 0) return MCQ_OK;
+    OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
+    u32 grid = (u32)std::min<u64>((n_queries + 3) / 4, 256ull * 24);
+    hipLaunchKernelGGL((k_reduce_wave<kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
+                       n_queries, loc_off, (const u64*)locs, query_len);
+    hipLaunchKernelGGL((k_reduce_block<kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+// ------------------------------------------------------------------ per-kernel timing
+static int drain_events(mcq_ws* ws) {
+    for (auto& e : *ws->ev_used) {
+        HIPCHK(hipEventSynchronize(e.second));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+        ws->timed_ms += ms; ws->timed_launches += 1;
+        ws->ev_free->push_back(e);
+    }
+    ws->ev_used->clear();
+    return MCQ_OK;
+}
+
+extern "C" int mcq_ws_timing(mcq_ws* ws, int enable) {
+    if (!ws) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ws->device));
+    int rc = drain_events(ws); if (rc) return rc;
+    ws->timing = enable ? 1 : 0;
+    if (enable) { ws->timed_ms = 0; ws->timed_launches = 0; }
+    return MCQ_OK;
+}
+
+extern "C" int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_launches) {
+    if (!ws) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(ws->device));
+    int rc = drain_events(ws); if (rc) return rc;
+    if (total_ms) *total_ms = ws->timed_ms;
+    if (n_launches) *n_launches = ws->timed_launches;
     return MCQ_OK;
 }

@@ -74,6 +74,14 @@ def lib():
         L.mcq_ws_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.mcq_owner.restype = C.c_uint32; L.mcq_owner.argtypes = [C.c_uint32, C.c_uint32]
         L.mcq_debug_matches.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mcq_ws_timing.argtypes = [C.c_void_p, C.c_int]
+        L.mcq_ws_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mcq_count_windows.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
+        L.mcq_sketch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_lookup_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.mcq_lookup_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         _lib = L
     return _lib
 
@@ -119,6 +127,21 @@ class Database:
 
     def bytes(self):
         return int(lib().mcq_db_bytes(self.h))
+
+    # ---- staged entry points (device pointers only) -------------------------------
+    def count_windows(self, bases_ptr, seq_off_ptr, n_seqs, win_off_ptr, stream=None):
+        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 0, MCQ_DEVICE_PTRS)
+        _chk(lib().mcq_count_windows(self.h, C.byref(b), win_off_ptr, stream))
+
+    def sketch(self, bases_ptr, seq_off_ptr, n_seqs, win_off_ptr, features_ptr, n_feat_ptr, stream=None):
+        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 0, MCQ_DEVICE_PTRS)
+        _chk(lib().mcq_sketch(self.h, C.byref(b), win_off_ptr, features_ptr, n_feat_ptr, stream))
+
+    def lookup_count(self, features_ptr, n, list_len_ptr, stream=None):
+        _chk(lib().mcq_lookup_count(self.h, features_ptr, n, list_len_ptr, stream))
+
+    def lookup_gather(self, features_ptr, n, out_off_ptr, out_locs_ptr, stream=None):
+        _chk(lib().mcq_lookup_gather(self.h, features_ptr, n, out_off_ptr, out_locs_ptr, stream))
 
     def close(self):
         if getattr(self, "h", None):
@@ -170,6 +193,20 @@ class Workspace:
         o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
         r = Result(cands_ptr, ncand_ptr, MCQ_DEVICE_PTRS)
         _chk(lib().mcq_query(self.db.h, self.h, C.byref(b), C.byref(o), C.byref(r), stream))
+
+    def timing(self, enable):
+        _chk(lib().mcq_ws_timing(self.h, 1 if enable else 0))
+
+    def kernel_time(self):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        _chk(lib().mcq_ws_kernel_time(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
+
+    def reduce_device(self, n_queries, loc_off_ptr, locs_ptr, query_len_ptr, cands_ptr, ncand_ptr, max_cand=2,
+                      emulate_ranks=1, insert_size_max=0, flags=0, stream=None):
+        o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
+        r = Result(cands_ptr, ncand_ptr, MCQ_DEVICE_PTRS)
+        _chk(lib().mcq_reduce(self.db.h, self.h, n_queries, loc_off_ptr, locs_ptr, query_len_ptr, C.byref(o), C.byref(r), stream))
 
     def debug_matches(self, bases, seq_off, paired):
         seq_off = np.ascontiguousarray(seq_off, np.uint64)
