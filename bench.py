@@ -187,7 +187,7 @@ def cpu_baseline(a, keys, list_off, locs, species, reads, read_off, cands, ncand
     """The oracle (bit-exact CPU restatement of the reference path) timed on this box's
     host cores, on a bounded sample of the same batch, checked against the GPU result."""
     from oracle import mc_oracle as orc
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), list_off.cpu().numpy().astype(np.uint64),
                        locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
     n0 = min(B, 20000)

@@ -81,8 +81,8 @@ struct mcq_ws {
 
 // ------------------------------------------------------------------ kernels: table build
 __global__ void k_fill_slots(uint4* slots, u64 n) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) slots[i] = make_uint4(MCQ_EMPTY, 0, 0, 0);
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) slots[i] = make_uint4(MCQ_EMPTY, 0, 0, 0);
 }
 
 // one thread per key: claim a slot with CAS on the key word, then fill length/offset.
@@ -117,12 +117,13 @@ __global__ void k_owned_len(const u32* keys, const u64* list_off, u64 n_keys, u3
 
 // copy owned lists into the compacted location array
 __global__ void k_copy_lists(const u64* list_off, const u64* new_off, const u64* locs, u64* out, u64 n_keys) {
-    // one wave per key
-    u64 key = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    u32 lane = threadIdx.x & 63;
-    if (key >= n_keys) return;
-    u64 b = new_off[key], n = new_off[key + 1] - b, src = list_off[key];
-    for (u64 t = lane; t < n; t += 64) out[b + t] = locs[src + t];
+    // one wave per key, grid-stride (the grid is bounded: total threads must stay < 2^32)
+    const u32 lane = threadIdx.x & 63;
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 key = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; key < n_keys; key += nwaves) {
+        u64 b = new_off[key], n = new_off[key + 1] - b, src = list_off[key];
+        for (u64 t = lane; t < n; t += 64) out[b + t] = locs[src + t];
+    }
 }
 
 // exclusive scan of u64 array (single workgroup, used only at DB build)
@@ -582,14 +583,15 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     HIPCHK(hipMalloc(&db->tgt2tax, std::max<u32>(1, desc->n_targets) * 4));
     if (desc->n_targets)
         HIPCHK(hipMemcpy(db->tgt2tax, desc->tgt2tax, (u64)desc->n_targets * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fill_slots, dim3((u32)((db->nslots + TB - 1) / TB)), dim3(TB), 0, 0, db->slots, db->nslots);
+    hipLaunchKernelGGL(k_fill_slots, dim3((u32)std::min<u64>((db->nslots + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, db->slots, db->nslots);
     if (nk) {
         hipLaunchKernelGGL(k_insert_keys, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, db->slots, (u32)(db->nslots - 1),
                            d_keys, d_new, nk, n_shards, desc->shard_id);
-        hipLaunchKernelGGL(k_copy_lists, dim3((u32)((nk * 64 + TB - 1) / TB)), dim3(TB), 0, 0, d_off, d_new, d_locs, db->locs, nk);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_copy_lists, dim3((u32)std::min<u64>((nk * 64 + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, d_off, d_new, d_locs, db->locs, nk);
+        HIPCHK(hipGetLastError());
     }
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipGetLastError());
     (void)hipFree(d_len); (void)hipFree(d_new);
     if (t_keys) (void)hipFree(t_keys);
     if (t_off) (void)hipFree(t_off);

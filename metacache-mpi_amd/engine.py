@@ -148,7 +148,10 @@ class Database:
             lib().mcq_db_destroy(self.h); self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
 
 class Workspace:
@@ -164,7 +167,10 @@ class Workspace:
             lib().mcq_ws_destroy(self.h); self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown
+            pass
 
     def sync(self, stream=None):
         st = Stats()

@@ -101,8 +101,11 @@ class OracleDb:
                                      len(self.tgt2tax), _p(self.tgt2tax, u32p), k, s, winlen, winstride, tgt_winstride)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_db_destroy(self.h); self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().orc_db_destroy(self.h); self.h = None
+        except Exception:       # interpreter shutdown
+            pass
 
     def query(self, bases, off, paired, max_cand=2, emulate_ranks=1, insert_size_max=0, quirk_seq_drop=0,
               threads=1, want_stats=False):

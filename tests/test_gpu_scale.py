@@ -1,0 +1,110 @@
+"""At-scale parity on seeded synthetic data: HIP engine vs the oracle on a database big
+enough to have long location lists, many targets per read and overflowing queries."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    synth = importlib.import_module("metacache-mpi_amd.synth")
+    dev = torch.device("cuda", 0)
+    gb, goff, species = synth.make_genomes(6, 12, 200_000, 400_000, 0.02, seed=5, device=dev)
+    out = {}
+    for P in (1, 2, 4):
+        keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=P)
+        db = dbbuild.make_database(keys, off, locs, species)
+        odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), off.cpu().numpy().astype(np.uint64),
+                           locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
+        out[P] = (db, odb)
+    return eng, synth, gb, goff, out
+
+
+def _compare(cands, ncand, oc, on, what):
+    bad = np.nonzero(ncand != on)[0]
+    assert len(bad) == 0, (what, "ncand differs at", bad[:5], ncand[bad[:5]], on[bad[:5]])
+    mask = np.arange(cands.shape[1])[None, :] < on[:, None]
+    neq = np.any((cands != oc) & mask[:, :, None], axis=(1, 2))
+    bad = np.nonzero(neq)[0]
+    assert len(bad) == 0, (what, "cands differ at", bad[:5], cands[bad[0]], oc[bad[0]])
+
+
+@pytest.mark.parametrize("P,M", [(1, 4), (2, 2), (2, 8), (4, 4)])
+def test_short_reads(world, P, M):
+    eng, synth, gb, goff, dbs = world
+    db, odb = dbs[P]
+    n, L = 60000, 150
+    reads, off, _ = synth.sample_reads(gb, goff, n, L, 0.01, 0.002, seed=11 + P)
+    ws = eng.Workspace(db, n, n * L)
+    rb = reads.cpu().numpy().tobytes(); ro = off.cpu().numpy().astype(np.uint64)
+    cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P)
+    oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, threads=8)
+    _compare(cands, ncand, oc, on, "single-end P=%d M=%d" % (P, M))
+    st = ws.sync()
+    assert st["n_locations"] > 0
+    # paired: the same reads taken as mates
+    cands, ncand = ws.query_host(rb, ro, True, max_cand=M, emulate_ranks=P)
+    oc, on = odb.query(rb, ro, True, max_cand=M, emulate_ranks=P, threads=8)
+    _compare(cands, ncand, oc, on, "paired P=%d M=%d" % (P, M))
+
+
+def test_long_reads_take_the_block_path(world):
+    eng, synth, gb, goff, dbs = world
+    db, odb = dbs[2]
+    n, L = 300, 6000
+    reads, off, _ = synth.sample_reads(gb, goff, n, L, 0.05, 0.001, seed=99)
+    ws = eng.Workspace(db, n, n * L)
+    rb = reads.cpu().numpy().tobytes(); ro = off.cpu().numpy().astype(np.uint64)
+    cands, ncand = ws.query_host(rb, ro, False, max_cand=4, emulate_ranks=2)
+    oc, on = odb.query(rb, ro, False, max_cand=4, emulate_ranks=2, threads=8)
+    _compare(cands, ncand, oc, on, "long")
+    st = ws.sync()
+    assert st["n_overflow"] == n
+
+
+def test_db_roundtrip_lookup(world):
+    """every key's list comes back from the GPU table exactly (mcq_lookup_count/_gather)"""
+    eng, synth, gb, goff, dbs = world
+    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dev = torch.device("cuda", 0)
+    keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=2)
+    species = torch.zeros(goff.numel() - 1, dtype=torch.int64, device=dev)
+    for n_shards in (1, 3):
+        total = 0
+        for sid in range(n_shards):
+            db = dbbuild.make_database(keys, off, locs, species, n_shards=n_shards, shard_id=sid)
+            k32 = torch.where(keys >= (1 << 31), keys - (1 << 32), keys).to(torch.int32).contiguous()
+            # plus some absent keys and the reserved value
+            probe = torch.cat([k32, torch.tensor([-1, 5, 7], dtype=torch.int32, device=dev)])
+            n = probe.numel()
+            lens = torch.zeros(n, dtype=torch.int32, device=dev)
+            st = torch.cuda.current_stream(dev).cuda_stream
+            db.lookup_count(probe.data_ptr(), n, lens.data_ptr(), st)
+            ooff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(lens.to(torch.int64), 0, out=ooff[1:])
+            out = torch.zeros(int(ooff[-1].item()) + 1, dtype=torch.int64, device=dev)
+            db.lookup_gather(probe.data_ptr(), n, ooff.data_ptr(), out.data_ptr(), st)
+            torch.cuda.synchronize()
+            own = torch.tensor([eng.owner(int(k) & 0xFFFFFFFF, n_shards) == sid for k in keys[:2000].tolist()])
+            exp_len = (off[1:] - off[:-1])
+            got = lens[:keys.numel()].to(torch.int64)
+            assert torch.equal(got[:2000][own.to(dev)], exp_len[:2000][own.to(dev)])
+            assert torch.all((got == exp_len) | (got == 0))
+            mine = got > 0
+            total += int(mine.sum().item())
+            # gathered lists equal the source lists of the owned keys
+            src_idx = torch.repeat_interleave(torch.arange(keys.numel(), device=dev)[mine], exp_len[mine])
+            assert out[:-1].numel() == src_idx.numel()
+            starts = off[:-1][mine]
+            within = torch.arange(src_idx.numel(), device=dev) - torch.repeat_interleave(ooff[:-1][:keys.numel()][mine], exp_len[mine])
+            src = locs[torch.repeat_interleave(starts, exp_len[mine]) + within]
+            assert torch.equal(out[:-1], src)
+        assert total == keys.numel()
