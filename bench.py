@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--small", action="store_true", help="tiny DB / few reads (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--stop-stage", type=int, default=0, help="profiling: stop the fused kernel after stage 1..5 (results invalid)")
     ap.add_argument("--distinct-batches", type=int, default=0, help="0 = one per step (capped by memory)")
     return ap.parse_args()
 
@@ -119,7 +120,7 @@ def main():
             sharded.query(r, read_off, B, False, cands, ncand, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks)
         else:
             ws.query_device(r.data_ptr(), read_off.data_ptr(), B, False, cands.data_ptr(), ncand.data_ptr(),
-                            max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, stream=stream)
+                            max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=(a.stop_stage & 15) << 12, stream=stream)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -173,7 +174,9 @@ def main():
                            "bytes_per_read": algo / B,
                            "per_launch": {k: st[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow")}}
 
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if a.stop_stage:
+        out["INVALID_profiling_stop_stage"] = a.stop_stage
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stop_stage:
         out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches[(a.warmup + a.steps - 1) % nb], read_off,
                                            cands, ncand, B, L)
     if rank == 0:

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev
         const u64 o2 = b.paired ? b.seq_off[a + 2] : o1;
         const u64 n1 = o1 - o0, n2 = o2 - o1;
         const u32 nw1 = num_windows(n1, W, S), nw2 = b.paired ? num_windows(n2, W, S) : 0;
-        bool ovf = force_block || ((u64)(nw1 + nw2) * db.s > 64);
+        const int stop = force_block >> 4;          // profiling hook: 0 = run everything
+        bool ovf = (force_block & 1) || ((u64)(nw1 + nw2) * db.s > 64);
         u32 myf = MCQ_EMPTY, nfeat = 0, T = 0, len = 0, pos = 0;
         u64 off = 0;
         if (!ovf) {
@@ -191,7 +192,9 @@ __global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev
                 if (lane >= nfeat && lane < nfeat + m) myf = g;
                 nfeat += m;
             }
+            if (stop == 1) { if (myf == 12345u) out.ncand[q] = nfeat; continue; }
             probe(db, myf, off, len);
+            if (stop == 2) { if (len == 0x7FFFFFFFu) out.ncand[q] = (u32)off; continue; }
             u32 incl = wave_incl_scan(len, lane);
             pos = incl - len;
             T = bcast(incl, 63);
@@ -223,10 +226,13 @@ __global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev
             if (t < n2p) buf[t] = v;
         }
         wave_sync();
+        if (stop == 3) { if (buf[lane & (n2p - 1)] == 0x1234ull) out.ncand[q] = 1; continue; }
         bitonic_sort(buf, n2p, lane, 64u, [] { wave_sync(); });
+        if (stop == 4) { if (buf[lane & (n2p - 1)] == 0x1234ull) out.ncand[q] = 1; continue; }
         const u32 numWindows = (u32)(2 + (n1 + n2 > opt.insert_size_max ? n1 + n2 : opt.insert_size_max) / db.tgt_winstride);
         walk_targets(buf, hits, T, numWindows, lane, 64u);
         wave_sync();
+        if (stop == 5) { if (hits[lane & (n2p - 1)] == 0x12345u) out.ncand[q] = 1; continue; }
         st_cand += topk_fold_write(db, opt, out, buf, hits, T, numWindows, q, lane);
     }
     if (lane == 0 && (st_feat | st_loc)) {
@@ -723,7 +729,7 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     if (!dev_out) { o.cands = ws->d_cands; o.ncand = ws->d_ncand; }
     else { o.cands = (u32*)out->cands; o.ncand = out->n_cand; }
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
-    rc = launch_query(db, ws, b, od, o, st, (opt->flags & 0x100u) ? 1 : 0, dbg);
+    rc = launch_query(db, ws, b, od, o, st, ((opt->flags & 0x100u) ? 1 : 0) | (int)((opt->flags >> 12) & 0xFu) << 4, dbg);
     if (rc) return rc;
     if (!dev_out && nq) {
         HIPCHK(hipMemcpyAsync(out->cands, ws->d_cands, nq * od.max_cand * 16, hipMemcpyDeviceToHost, st));
