@@ -36,6 +36,7 @@ struct DbDev {
     const u32* tgt2tax;
     u32 n_targets;
     u32 k, s, winlen, winstride, tgt_winstride;
+    u32 magic_stride, magic_tgt_stride;   // floor(2^32 / stride): udiv_magic
 };
 
 struct BatchDev {
@@ -101,6 +102,30 @@ __device__ __forceinline__ void window_of(u64 n, u32 W, u32 S, u32 j, u64& beg, 
     len = (j < nfull) ? W : (u32)(n - beg);
 }
 
+// 32-bit variants for sequences shorter than 2^31 bases; magic = floor(2^32 / S)
+__device__ __forceinline__ u32 udiv_magic(u32 n, u32 d, u32 magic) {
+    u32 q = __umulhi(n, magic);
+    if (n - q * d >= d) ++q;
+    return q;
+}
+__device__ __forceinline__ u32 num_windows32(u32 n, u32 W, u32 S, u32 magic) {
+    if (n <= W) return 1;
+    u32 nfull = udiv_magic(n - W, S, magic) + 1;
+    return nfull + ((nfull * S < n) ? 1u : 0u);
+}
+__device__ __forceinline__ void window_of32(u32 n, u32 W, u32 S, u32 magic, u32 j, u32& beg, u32& len) {
+    if (n <= W) { beg = 0; len = n; return; }
+    u32 nfull = udiv_magic(n - W, S, magic) + 1;
+    beg = j * S;
+    len = (j < nfull) ? W : (n - beg);
+}
+// row 9's range width: 2 + max(len1+len2, insertSizeMax) / target stride (src/classification.cpp:217-219)
+__device__ __forceinline__ u32 range_width(u64 qlen, u64 insert_size_max, u32 tgt_stride, u32 magic) {
+    u64 m = qlen > insert_size_max ? qlen : insert_size_max;
+    if (m < (1ull << 31)) return 2 + udiv_magic((u32)m, tgt_stride, magic);
+    return (u32)(2 + m / tgt_stride);
+}
+
 // ------------------------------------------------------------------ wave primitives
 __device__ __forceinline__ u32 lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -147,14 +172,53 @@ __device__ __forceinline__ u32 bcast(u32 v, u32 src_lane) {       // src_lane wa
 }
 
 // ------------------------------------------------------------------ rows 2-5: one window, one wave
+// value of lane (l ^ J), J a power of two < 64, without touching LDS memory
+template <int J>
+__device__ __forceinline__ u32 xor_lane(u32 v) {
+    if constexpr (J == 1) return dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
+    else if constexpr (J == 4) return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);   // bitmode xor 4
+    else if constexpr (J == 8) return dpp_mov<0x128>(v);                 // row_ror:8
+    else if constexpr (J == 16) return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);  // bitmode xor 16
+    else return (u32)__shfl_xor((int)v, 32, 64);
+}
+
+template <int K, int J>
+__device__ __forceinline__ u32 bitonic_step(u32 v, u32 lane) {
+    u32 o = xor_lane<J>(v);
+    bool up = (K >= 64) || ((lane & K) == 0);
+    bool lower = (lane & J) == 0;
+    u32 mn = v < o ? v : o, mx = v < o ? o : v;
+    return (lower == up) ? mn : mx;
+}
+
+// ascending sort of one u32 per lane across the wave (21 compare-exchange stages)
+__device__ __forceinline__ u32 wave_sort64(u32 v, u32 lane) {
+    v = bitonic_step<2, 1>(v, lane);
+    v = bitonic_step<4, 2>(v, lane);  v = bitonic_step<4, 1>(v, lane);
+    v = bitonic_step<8, 4>(v, lane);  v = bitonic_step<8, 2>(v, lane);  v = bitonic_step<8, 1>(v, lane);
+    v = bitonic_step<16, 8>(v, lane); v = bitonic_step<16, 4>(v, lane); v = bitonic_step<16, 2>(v, lane);
+    v = bitonic_step<16, 1>(v, lane);
+    v = bitonic_step<32, 16>(v, lane); v = bitonic_step<32, 8>(v, lane); v = bitonic_step<32, 4>(v, lane);
+    v = bitonic_step<32, 2>(v, lane);  v = bitonic_step<32, 1>(v, lane);
+    v = bitonic_step<64, 32>(v, lane); v = bitonic_step<64, 16>(v, lane); v = bitonic_step<64, 8>(v, lane);
+    v = bitonic_step<64, 4>(v, lane);  v = bitonic_step<64, 2>(v, lane);  v = bitonic_step<64, 1>(v, lane);
+    return v;
+}
+
 // Sketch of seq[0..n), n <= 128, by one full wave.  Lane l encodes bases 2l and 2l+1;
 // 8 lanes form one 16-base word (2 bits per base, first base in the top bits), 16 lanes
 // one 32-base ambiguity word.  Lane l then owns the k-mers starting at l and l+64.
-// Returns the number of features m (wave-uniform, <= min(s, n-k+1)); feature i
-// (ascending) is returned in lane i's `feat`.
+// The min(s, n-k+1) smallest DISTINCT hashes (ascending) are written to dst[0..m);
+// returns m (wave-uniform).  tmp: 64 words of this wave's LDS scratch (dst != tmp).
+//
+// Selection: hashes are ~uniform, so the s smallest of c > 64 values are all below
+// thr = 40/c of the hash range except with negligible probability.  Values below thr
+// (all values if c <= 64) are compacted to one per lane, sorted by a 21-stage in-register
+// bitonic network and de-duplicated.  If the filter let through more than 64 values or
+// fewer than s distinct ones, the exact repeated-wave-min selection runs instead.
 __device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, u32 k, u32 s,
-                                           u32 lane, u32& feat) {
-    feat = MCQ_EMPTY;
+                                           u32 lane, u32* tmp, u32* dst) {
     if (n < k) return 0;
     u32 cap = n - k + 1;
     u32 sl = s < cap ? s : cap;
@@ -170,10 +234,9 @@ __device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, 
     u32 a1 = !(u1 == 'A' || u1 == 'C' || u1 == 'G' || u1 == 'T');
 
     u32 w = ((x0 << 2) | x1) << (28 - 4 * (lane & 7));
-    w |= __shfl_xor(w, 1, 64); w |= __shfl_xor(w, 2, 64); w |= __shfl_xor(w, 4, 64);
+    w |= xor_lane<1>(w); w |= xor_lane<2>(w); w |= xor_lane<4>(w);
     u32 am = ((a0 << 1) | a1) << (30 - 2 * (lane & 15));
-    am |= __shfl_xor(am, 1, 64); am |= __shfl_xor(am, 2, 64);
-    am |= __shfl_xor(am, 4, 64); am |= __shfl_xor(am, 8, 64);
+    am |= xor_lane<1>(am); am |= xor_lane<2>(am); am |= xor_lane<4>(am); am |= xor_lane<8>(am);
 
     u32 h[2];
 #pragma unroll
@@ -192,16 +255,46 @@ __device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, 
         h[i] = ok ? tmh(canonical(kmer, k)) : MCQ_EMPTY;
     }
 
-    // the sl smallest distinct values: repeated wave-min, equal values retire together
+    // ---- filter + compact + sort
+    const u32 c = (u32)__builtin_popcountll(__ballot(h[0] != MCQ_EMPTY)) + (u32)__builtin_popcountll(__ballot(h[1] != MCQ_EMPTY));
+    if (c == 0) return 0;
+    const bool all_in = c <= 64;
+    const u32 thr = all_in ? MCQ_EMPTY : (0xFFFFFFFFu / c) * 40u;
+    const bool s0 = h[0] < thr, s1 = h[1] < thr;
+    const u64 m0 = __ballot(s0), m1 = __ballot(s1);
+    const u32 n0 = (u32)__builtin_popcountll(m0), cnt = n0 + (u32)__builtin_popcountll(m1);
+    bool fallback = cnt > 64;
     u32 m = 0;
-    for (; m < sl; ++m) {
-        u32 lo = h[0] < h[1] ? h[0] : h[1];
-        u32 mn = wave_min_u32(lo);
-        if (mn == MCQ_EMPTY) break;
-        if (lane == m) feat = mn;
-        if (h[0] == mn) h[0] = MCQ_EMPTY;
-        if (h[1] == mn) h[1] = MCQ_EMPTY;
+    if (!fallback) {
+        const u64 below = (1ull << lane) - 1;
+        if (s0) tmp[(u32)__builtin_popcountll(m0 & below)] = h[0];
+        if (s1) tmp[n0 + (u32)__builtin_popcountll(m1 & below)] = h[1];
+        wave_sync();
+        u32 v = lane < cnt ? tmp[lane] : MCQ_EMPTY;
+        v = wave_sort64(v, lane);
+        u32 prev = __shfl_up(v, 1, 64);
+        bool keep = (v != MCQ_EMPTY) && (lane == 0 || v != prev);
+        u64 km = __ballot(keep);
+        u32 D = (u32)__builtin_popcountll(km);
+        if (!all_in && D < sl) fallback = true;
+        else {
+            m = D < sl ? D : sl;
+            u32 rank = (u32)__builtin_popcountll(km & below);
+            if (keep && rank < m) dst[rank] = v;
+        }
     }
+    if (fallback) {
+        // exact selection: repeated wave-min, equal values retire together
+        for (m = 0; m < sl; ++m) {
+            u32 lo = h[0] < h[1] ? h[0] : h[1];
+            u32 mn = wave_min_u32(lo);
+            if (mn == MCQ_EMPTY) break;
+            if (lane == 0) dst[m] = mn;
+            if (h[0] == mn) h[0] = MCQ_EMPTY;
+            if (h[1] == mn) h[1] = MCQ_EMPTY;
+        }
+    }
+    wave_sync();
     return m;
 }
 
@@ -238,44 +331,49 @@ __device__ __forceinline__ void bitonic_sort(u64* buf, u32 n, u32 tid, u32 G, Sy
 }
 
 // ------------------------------------------------------------------ row 9: per-target best window range
-// buf[0..T) sorted by (tgt,win).  The thread that owns the first element of a target's
-// run sweeps that run exactly like the reference's two-pointer loop and leaves the
-// target's best hit count in hits[j0]; every other hits[] entry becomes 0.
-__device__ __forceinline__ void walk_targets(const u64* buf, u32* hits, u32 T, u32 numWindows, u32 tid, u32 G) {
+// buf[0..T) sorted by (tgt,win).  The reference's two-pointer sweep keeps, for the run of
+// one target, the first range [fst,lst] with the most entries and win[lst]-win[fst] <
+// numWindows.  Because the run is sorted, fst(lst) is simply the first entry of the run
+// with win >= win[lst]-numWindows+1, so every entry finds its own count with one binary
+// search: hits(j) = j - lower_bound(tgt, win_j - numWindows + 1) + 1.  The run's best is
+// the maximum of (hits, -j): folded with an LDS atomic max into H[first entry of the run]
+// (found by a second lower_bound that shares the loop).
+//   H[j0] = (hits << JB) | (JMASK - jbest) for run heads, 0 elsewhere.
+template <class HT, int JB, class Sync>
+__device__ __forceinline__ void sweep_targets(const u64* buf, HT* H, u32 T, u32 numWindows, u32 tid, u32 G,
+                                              Sync sync) {
+    const HT JMASK = ((HT)1 << JB) - 1;
+    for (u32 j = tid; j < T; j += G) H[j] = 0;
+    sync();
     for (u32 j = tid; j < T; j += G) {
-        u64 key = buf[j];
-        u32 tgt = (u32)(key >> 32);
-        bool head = (j == 0) || ((u32)(buf[j - 1] >> 32) != tgt);
-        u32 best = 0;
-        if (head) {
-            u32 fst = j, cur = 1; best = 1;
-            for (u32 l = j + 1; l < T; ++l) {
-                u64 kk = buf[l];
-                if ((u32)(kk >> 32) != tgt) break;
-                u32 w = (u32)kk;
-                ++cur;
-                while ((u32)(w - (u32)buf[fst]) >= numWindows) { --cur; ++fst; }
-                if (cur > best) best = cur;
-            }
+        const u64 key = buf[j];
+        const u32 win = (u32)key;
+        const u64 headkey = key & 0xFFFFFFFF00000000ull;
+        const u64 lowkey = headkey | (u64)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+        u32 lo1 = 0, hi1 = j, lo2 = 0, hi2 = j;          // buf[j] >= both keys
+        while (lo1 < hi1 || lo2 < hi2) {
+            u32 mid1 = (lo1 + hi1) >> 1, mid2 = (lo2 + hi2) >> 1;
+            u64 v1 = buf[mid1], v2 = buf[mid2];
+            if (lo1 < hi1) { if (v1 < lowkey) lo1 = mid1 + 1; else hi1 = mid1; }
+            if (lo2 < hi2) { if (v2 < headkey) lo2 = mid2 + 1; else hi2 = mid2; }
         }
-        hits[j] = best;
+        const HT packed = ((HT)(j - lo1 + 1) << JB) | (JMASK - (HT)j);
+        atomicMax(&H[lo2], packed);
     }
+    sync();
 }
 
-// window range of the best candidate of the target whose run starts at j0
-// (same sweep, keeping the first strictly-best range)
-__device__ __forceinline__ void walk_range(const u64* buf, u32 T, u32 numWindows, u32 j0, u32& beg, u32& end) {
-    u32 tgt = (u32)(buf[j0] >> 32);
-    u32 fst = j0, cur = 1, best = 1;
-    beg = end = (u32)buf[j0];
-    for (u32 l = j0 + 1; l < T; ++l) {
-        u64 kk = buf[l];
-        if ((u32)(kk >> 32) != tgt) break;
-        u32 w = (u32)kk;
-        ++cur;
-        while ((u32)(w - (u32)buf[fst]) >= numWindows) { --cur; ++fst; }
-        if (cur > best) { best = cur; beg = (u32)buf[fst]; end = w; }
-    }
+// window range [beg,end] of the best candidate whose packed word is hv (run head j0 irrelevant)
+template <class HT, int JB>
+__device__ __forceinline__ void best_range(const u64* buf, HT hv, u32 numWindows, u32& beg, u32& end) {
+    const HT JMASK = ((HT)1 << JB) - 1;
+    const u32 j = (u32)(JMASK - (hv & JMASK));
+    const u64 key = buf[j];
+    const u32 win = (u32)key;
+    const u64 lowkey = (key & 0xFFFFFFFF00000000ull) | (u64)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+    u32 lo = 0, hi = j;
+    while (lo < hi) { u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
+    beg = (u32)buf[lo]; end = win;
 }
 
 // ------------------------------------------------------------------ rows 10-11: top lists in lanes
@@ -316,34 +414,49 @@ __device__ __forceinline__ void top_insert(TopLists& L, u32 lane, u32 r, u32 seg
     if (in_list && li == jn) { L.tax = ctax; L.hits = chits; L.j0 = cj0; }
 }
 
-// Builds the P lists from the walked buffer, folds them in the reference's tree order
+// Builds the P lists from the swept buffer, folds them in the reference's tree order
 // and writes the result for query q.  Executed by ONE full wave.  Returns the number
 // of candidates written (wave-uniform).
+//
+// Parallel pre-filter (exact): a candidate changes nothing if (a) its list is full and
+// its hits do not exceed the list minimum -- minima of a full list never decrease -- or
+// (b) its taxon was already inserted into the same list with at least as many hits (if
+// that entry has been evicted since, (a) covers it).  Only survivors reach top_insert.
+template <class HT, int JB>
 __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& opt, const OutDev& out,
-                                               const u64* buf, const u32* hits, u32 T, u32 numWindows,
+                                               const u64* buf, const HT* H, u32 T, u32 numWindows,
                                                u64 q, u32 lane) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    const bool p2 = (P & (P - 1)) == 0;
     TopLists L; L.tax = MCQ_EMPTY; L.hits = 0; L.j0 = 0;
 
     for (u32 base = 0; base < T; base += 64) {
         u32 j = base + lane;
-        u32 h = (j < T) ? hits[j] : 0;
+        HT hv = (j < T) ? H[j] : 0;
+        u32 h = (u32)(hv >> JB);
         u32 tgt = (j < T) ? (u32)(buf[j] >> 32) : 0;
-        u32 r = (P > 1) ? (tgt % P) : 0;
+        u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
         // taxon key of every run head of this chunk, fetched together
         u32 tax = MCQ_EMPTY;
         if (h > 0) tax = (tgt < db.n_targets) ? db.tgt2tax[tgt] : MCQ_EMPTY;
+        // best hits already in my list for my taxon (lists persist across chunks)
+        u32 dom = 0;
+        if (base > 0) {
+            for (u32 i = 0; i < M; ++i) {
+                u32 et = __shfl(L.tax, (int)(r * seg + i), 64), eh = __shfl(L.hits, (int)(r * seg + i), 64);
+                if (eh > 0 && et == tax) dom = eh;
+            }
+        }
         u64 pending = __ballot(h > 0 && tax != MCQ_EMPTY);
         while (pending) {
-            // a full list with minimum m ignores every candidate with hits <= m
-            // (list minima never decrease), an open list takes everything
             u32 thr = __shfl(L.hits, (int)(r * seg + M - 1), 64);
-            pending &= __ballot(h > thr);
+            pending &= __ballot(h > thr && h > dom);
             if (!pending) break;
             u32 c = (u32)__builtin_ctzll(pending);
             pending &= pending - 1;
             u32 ctax = bcast(tax, c), chits = bcast(h, c), cr = bcast(r, c);
             top_insert(L, lane, cr, seg, M, ctax, chits, base + c);
+            if (r == cr && tax == ctax && chits > dom) dom = chits;
         }
     }
 
@@ -364,7 +477,7 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
     u32 n = (u32)__builtin_popcountll(__ballot(lane < M && L.hits > 0));
     if (lane < n) {
         u32 beg = 0, end = 0;
-        if (P == 1) walk_range(buf, T, numWindows, L.j0, beg, end);
+        if (P == 1) best_range<HT, JB>(buf, H[L.j0], numWindows, beg, end);
         uint4 v; v.x = L.tax; v.y = L.hits; v.z = beg; v.w = end;
         reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
     }

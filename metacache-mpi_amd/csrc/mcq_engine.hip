@@ -50,7 +50,7 @@ struct mcq_db {
 };
 
 struct ScratchDev {
-    u32* feat; u32* fpos; u64* foff; u64* gbuf; u32* ghits;
+    u32* feat; u32* fpos; u64* foff; u64* gbuf; u64* ghits;
     u32 fmax; u32 lmax;
 };
 
@@ -159,39 +159,43 @@ __device__ __forceinline__ u32 pow2ceil(u32 x) { return x <= 1 ? 1u : 1u << (32 
 template <int LCAP>
 __global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                     CountersDev* ctr, u32* ovf_list, int force_block) {
+    static_assert(LCAP >= 128 && LCAP <= 512, "wave path packs the entry index into 9 bits");
     __shared__ u64 s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u64* buf = s_buf[wave];
     u32* hits = s_hits[wave];
+    u32* sk_tmp = hits;                // sketch scratch aliases the (not yet used) hit words
+    u32* feat = hits + 64;
     const u32 W = db.winlen, S = db.winstride;
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
 
     for (u64 q = (u64)blockIdx.x * 4 + wave; q < b.nq; q += nwaves) {
+        const int stop = force_block >> 4;          // profiling hook: 0 = run everything
         const u64 a = b.paired ? 2 * q : q;
         const u64 o0 = b.seq_off[a], o1 = b.seq_off[a + 1];
         const u64 o2 = b.paired ? b.seq_off[a + 2] : o1;
-        const u64 n1 = o1 - o0, n2 = o2 - o1;
-        const u32 nw1 = num_windows(n1, W, S), nw2 = b.paired ? num_windows(n2, W, S) : 0;
-        const int stop = force_block >> 4;          // profiling hook: 0 = run everything
-        bool ovf = (force_block & 1) || ((u64)(nw1 + nw2) * db.s > 64);
+        const u64 l1 = o1 - o0, l2 = o2 - o1;
+        bool ovf = (force_block & 1) || ((l1 | l2) >> 20) != 0;
+        const u32 n1 = (u32)l1, n2 = (u32)l2;
+        u32 nw1 = 0, nw2 = 0;
+        if (!ovf) {
+            nw1 = num_windows32(n1, W, S, db.magic_stride);
+            nw2 = b.paired ? num_windows32(n2, W, S, db.magic_stride) : 0;
+            ovf = (nw1 + nw2) * db.s > 64;
+        }
         u32 myf = MCQ_EMPTY, nfeat = 0, T = 0, len = 0, pos = 0;
         u64 off = 0;
         if (!ovf) {
             for (u32 w = 0; w < nw1 + nw2; ++w) {
                 const bool m2 = w >= nw1;
-                const u64 n = m2 ? n2 : n1;
-                const u64 sb = m2 ? o1 : o0;
-                u64 beg; u32 wl;
-                window_of(n, W, S, m2 ? w - nw1 : w, beg, wl);
-                u32 f;
-                u32 m = wave_sketch(b.bases + sb + beg, wl, db.k, db.s, lane, f);
-                u32 g = __shfl(f, (int)((lane - nfeat) & 63), 64);
-                if (lane >= nfeat && lane < nfeat + m) myf = g;
-                nfeat += m;
+                u32 beg, wl;
+                window_of32(m2 ? n2 : n1, W, S, db.magic_stride, m2 ? w - nw1 : w, beg, wl);
+                nfeat += wave_sketch(b.bases + (m2 ? o1 : o0) + beg, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
             }
+            if (lane < nfeat) myf = feat[lane];
             if (stop == 1) { if (myf == 12345u) out.ncand[q] = nfeat; continue; }
             probe(db, myf, off, len);
             if (stop == 2) { if (len == 0x7FFFFFFFu) out.ncand[q] = (u32)off; continue; }
@@ -229,11 +233,11 @@ __global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev
         if (stop == 3) { if (buf[lane & (n2p - 1)] == 0x1234ull) out.ncand[q] = 1; continue; }
         bitonic_sort(buf, n2p, lane, 64u, [] { wave_sync(); });
         if (stop == 4) { if (buf[lane & (n2p - 1)] == 0x1234ull) out.ncand[q] = 1; continue; }
-        const u32 numWindows = (u32)(2 + (n1 + n2 > opt.insert_size_max ? n1 + n2 : opt.insert_size_max) / db.tgt_winstride);
-        walk_targets(buf, hits, T, numWindows, lane, 64u);
-        wave_sync();
+        const u32 numWindows = range_width(l1 + l2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
+        sweep_targets<u32, 9>(buf, hits, T, numWindows, lane, 64u, [] { wave_sync(); });
         if (stop == 5) { if (hits[lane & (n2p - 1)] == 0x12345u) out.ncand[q] = 1; continue; }
-        st_cand += topk_fold_write(db, opt, out, buf, hits, T, numWindows, q, lane);
+        st_cand += topk_fold_write<u32, 9>(db, opt, out, buf, hits, T, numWindows, q, lane);
+        wave_sync();
     }
     if (lane == 0 && (st_feat | st_loc)) {
         atomicAdd(&ctr->n_features, st_feat);
@@ -269,7 +273,7 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
 // Tail of the workgroup path: fill B[0..n2p) through `load(t)`, sort, sweep, top lists.
 template <bool kLds, class Load>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
-                                           u64* B, u32* H, u32 T, u32 numWindows, u64 q, u32 tid,
+                                           u64* B, u64* H, u32 T, u32 numWindows, u64 q, u32 tid,
                                            const DebugDev& dbg, Load load) {
     const u32 n2p = pow2ceil(T);
     for (u32 t = tid; t < n2p; t += 1024) B[t] = (t < T) ? load(t) : ~0ull;
@@ -278,10 +282,9 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
     if (dbg.mode == 2) {
         for (u32 t = tid; t < T; t += 1024) dbg.matches[dbg.match_off[q] + t] = B[t];
     }
-    walk_targets(B, H, T, numWindows, tid, 1024u);
-    __syncthreads();
+    sweep_targets<u64, 32>(B, H, T, numWindows, tid, 1024u, [] { __syncthreads(); });
     if (tid < 64) {
-        u32 n = topk_fold_write(db, opt, out, B, H, T, numWindows, q, tid);
+        u32 n = topk_fold_write<u64, 32>(db, opt, out, B, H, T, numWindows, q, tid);
         if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
     }
     __syncthreads();
@@ -291,7 +294,7 @@ template <int LCAPB>
 __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                       CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg) {
     __shared__ u64 s_buf[LCAPB];
-    __shared__ u32 s_hits[LCAPB];
+    __shared__ u64 s_hits[LCAPB];
     __shared__ u32 s_w[20];
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,8 +303,9 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
     u32* fpos = sc.fpos + (u64)blockIdx.x * ((u64)sc.fmax + 1);
     u64* foff = sc.foff + (u64)blockIdx.x * sc.fmax;
     u64* gbuf = sc.gbuf + (u64)blockIdx.x * sc.lmax;
-    u32* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
+    u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
     const u32 n_ovf = ctr->ovf_count;
+    u32* sk = reinterpret_cast<u32*>(s_hits) + wave * 128;     // per-wave sketch scratch (hit words unused yet)
 
     for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
         const u64 q = ovf_list[it];
@@ -323,12 +327,12 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
             const u64 sb = m2 ? o1 : o0;
             u64 beg; u32 wl;
             window_of(n, W, S, m2 ? w - nw1 : w, beg, wl);
-            u32 f;
-            u32 m = wave_sketch(b.bases + sb + beg, wl, db.k, db.s, lane, f);
+            u32 m = wave_sketch(b.bases + sb + beg, wl, db.k, db.s, lane, sk, sk + 64);
             u32 base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_w[18], m);
             base = bcast(base, 0);
-            if (lane < m) feat[base + lane] = f;
+            if (lane < m) feat[base + lane] = sk[64 + lane];
+            wave_sync();
         }
         __syncthreads();
         const u32 F = s_w[18];
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
             if (tid == 0) { out.ncand[q] = 0; atomicAdd(&ctr->err_count, 1u); }
             continue;
         }
-        const u32 numWindows = (u32)(2 + (n1 + n2 > opt.insert_size_max ? n1 + n2 : opt.insert_size_max) / db.tgt_winstride);
+        const u32 numWindows = range_width(n1 + n2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         auto load = [&](u32 t) -> u64 {
             u32 lo = 0, hi = F;                       // last j in [0,F) with fpos[j] <= t
             while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (fpos[mid] <= t) lo = mid; else hi = mid; }
@@ -376,16 +380,18 @@ __global__ __launch_bounds__(256) void k_sketch_windows(DbDev db, const char* ba
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u64 n_win = win_off[n_seqs];
     const u64 nwaves = (u64)gridDim.x * 4;
+    __shared__ u32 s_sk[4][128];
+    u32* sk = s_sk[wave];
     for (u64 w = (u64)blockIdx.x * 4 + wave; w < n_win; w += nwaves) {
         u64 lo = 0, hi = n_seqs;
         while (hi - lo > 1) { u64 mid = (lo + hi) >> 1; if (win_off[mid] <= w) lo = mid; else hi = mid; }
         const u64 o0 = seq_off[lo], n = seq_off[lo + 1] - o0;
         u64 beg; u32 wl;
         window_of(n, db.winlen, db.winstride, (u32)(w - win_off[lo]), beg, wl);
-        u32 f;
-        u32 m = wave_sketch(bases + o0 + beg, wl, db.k, db.s, lane, f);
-        if (lane < db.s) features[w * db.s + lane] = (lane < m) ? f : MCQ_EMPTY;
+        u32 m = wave_sketch(bases + o0 + beg, wl, db.k, db.s, lane, sk, sk + 64);
+        if (lane < db.s) features[w * db.s + lane] = (lane < m) ? sk[64 + lane] : MCQ_EMPTY;
         if (lane == 0) n_feat[w] = m;
+        wave_sync();
     }
 }
 
@@ -452,11 +458,10 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         for (u32 t = lane; t < n2p; t += 64) buf[t] = (t < T) ? locs[b0 + t] : ~0ull;
         wave_sync();
         bitonic_sort(buf, n2p, lane, 64u, [] { wave_sync(); });
-        const u64 ql = query_len[q];
-        const u32 numWindows = (u32)(2 + (ql > opt.insert_size_max ? ql : opt.insert_size_max) / db.tgt_winstride);
-        walk_targets(buf, hits, T, numWindows, lane, 64u);
+        const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
+        sweep_targets<u32, 9>(buf, hits, T, numWindows, lane, 64u, [] { wave_sync(); });
+        st_cand += topk_fold_write<u32, 9>(db, opt, out, buf, hits, T, numWindows, q, lane);
         wave_sync();
-        st_cand += topk_fold_write(db, opt, out, buf, hits, T, numWindows, q, lane);
     }
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
 }
@@ -465,10 +470,10 @@ template <int LCAPB>
 __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
                                                        ScratchDev sc, const u64* loc_off, const u64* locs, const u32* query_len) {
     __shared__ u64 s_buf[LCAPB];
-    __shared__ u32 s_hits[LCAPB];
+    __shared__ u64 s_hits[LCAPB];
     const u32 tid = threadIdx.x;
     u64* gbuf = sc.gbuf + (u64)blockIdx.x * sc.lmax;
-    u32* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
+    u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
     const u32 n_ovf = ctr->ovf_count;
     DebugDev dbg; dbg.mode = 0; dbg.match_cnt = nullptr; dbg.match_off = nullptr; dbg.matches = nullptr;
     for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
@@ -480,8 +485,7 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
         }
         const u32 T = (u32)T64;
         if (tid == 0) atomicAdd(&ctr->n_locations, (unsigned long long)T);
-        const u64 ql = query_len[q];
-        const u32 numWindows = (u32)(2 + (ql > opt.insert_size_max ? ql : opt.insert_size_max) / db.tgt_winstride);
+        const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         auto load = [&](u32 t) -> u64 { return locs[b0 + t]; };
         if (pow2ceil(T) <= (u32)LCAPB) block_tail<true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, q, tid, dbg, load);
         else                           block_tail<false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, q, tid, dbg, load);
@@ -607,6 +611,8 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     db->d.tgt2tax = db->tgt2tax; db->d.n_targets = desc->n_targets;
     db->d.k = desc->k; db->d.s = desc->sketch_size; db->d.winlen = desc->winlen; db->d.winstride = desc->winstride;
     db->d.tgt_winstride = desc->tgt_winstride ? desc->tgt_winstride : desc->winstride;
+    db->d.magic_stride = (u32)std::min<u64>((1ull << 32) / db->d.winstride, 0xFFFFFFFFull);
+    db->d.magic_tgt_stride = (u32)std::min<u64>((1ull << 32) / db->d.tgt_winstride, 0xFFFFFFFFull);
     db->bytes = db->nslots * sizeof(uint4) + std::max<u64>(1, nl_local) * 8 + (u64)desc->n_targets * 4;
     *out = db;
     return MCQ_OK;
@@ -646,7 +652,7 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     HIPCHK(hipMalloc(&ws->sc.fpos, nb * ((u64)ws->sc.fmax + 1) * 4));
     HIPCHK(hipMalloc(&ws->sc.foff, nb * ws->sc.fmax * 8));
     HIPCHK(hipMalloc(&ws->sc.gbuf, nb * lmax * 8));
-    HIPCHK(hipMalloc(&ws->sc.ghits, nb * lmax * 4));
+    HIPCHK(hipMalloc(&ws->sc.ghits, nb * lmax * 8));
     *out = ws;
     return MCQ_OK;
 }
