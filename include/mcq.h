@@ -47,7 +47,9 @@ enum {
     MCQ_QUIRK_SEQ_DROP = 2u,    /* emulate the reference's u32 wire format: a sequence-
                                    level taxon (key bit 31 set) sent by a non-root rank
                                    is dropped (src/querying.h:958, :983-985)            */
-    MCQ_FORCE_BLOCK_PATH = 0x100u /* test hook: every query takes the workgroup path     */
+    MCQ_FORCE_BLOCK_PATH = 0x100u, /* test hook: every query takes the workgroup path    */
+    MCQ_DB_LOCS_64 = 0x200u     /* mcq_db_desc.flags: keep 64-bit locations in HBM even when
+                                   (tgt,win) would fit the compact 32-bit form           */
 };
 
 /* Database description = the union of the reference's P shard tables

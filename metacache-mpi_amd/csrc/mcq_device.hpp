@@ -32,7 +32,9 @@ namespace mcq {
 struct DbDev {
     const uint4* slots;      // {key, len, off_lo, off_hi}; key == MCQ_EMPTY: unused
     u32 slot_mask;           // nslots - 1 (power of two)
-    const u64* locs;
+    const void* locs;        // u64 (tgt<<32)|win, or u32 (tgt<<wb)|win when `compact`
+    u32 wb;                  // window-id bits inside a location word (32 for u64 locations)
+    u32 compact;
     const u32* tgt2tax;
     u32 n_targets;
     u32 k, s, winlen, winstride, tgt_winstride;
@@ -314,14 +316,14 @@ __device__ __forceinline__ void probe(const DbDev& db, u32 f, u64& off, u32& len
 
 // ------------------------------------------------------------------ row 8: sort
 // Bitonic sort of buf[0..n) (n a power of two) by G cooperating threads.
-template <class Sync>
-__device__ __forceinline__ void bitonic_sort(u64* buf, u32 n, u32 tid, u32 G, Sync sync) {
+template <class KeyT, class Sync>
+__device__ __forceinline__ void bitonic_sort(KeyT* buf, u32 n, u32 tid, u32 G, Sync sync) {
     for (u32 k = 2; k <= n; k <<= 1) {
         for (u32 j = k >> 1; j > 0; j >>= 1) {
             for (u32 t = tid; t < (n >> 1); t += G) {
                 u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 u32 l = i | j;
-                u64 a = buf[i], b = buf[l];
+                KeyT a = buf[i], b = buf[l];
                 bool up = (i & k) == 0;
                 if ((a > b) == up) { buf[i] = b; buf[l] = a; }
             }
@@ -329,6 +331,65 @@ __device__ __forceinline__ void bitonic_sort(u64* buf, u32 n, u32 tid, u32 G, Sy
         }
     }
 }
+
+// ------------------------------------------------------------------ row 8 in registers
+// Bitonic network over n = 64*E keys held as r[e] = element e*64 + lane.  Exchanges at
+// distance j < 64 cross lanes (DPP / swizzle / permlane32_swap, no LDS memory); distance
+// j >= 64 pairs two registers of the same lane.  Fully unrolled: every index is static.
+__device__ __forceinline__ u64 xor_lane64_32(u64 v, u32 lane) {      // value of lane ^ 32
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    u32 olo = (lane & 32) ? a[0] : a[1], ohi = (lane & 32) ? b[0] : b[1];
+    return ((u64)ohi << 32) | olo;
+}
+template <int J>
+__device__ __forceinline__ u32 xlane(u32 v, u32 lane) {
+    if constexpr (J == 32) { auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? a[0] : a[1]; }
+    else return xor_lane<J>(v);
+}
+template <int J>
+__device__ __forceinline__ u64 xlane(u64 v, u32 lane) {
+    if constexpr (J == 32) return xor_lane64_32(v, lane);
+    else return ((u64)xor_lane<J>((u32)(v >> 32)) << 32) | xor_lane<J>((u32)v);
+}
+
+template <class KeyT, int E, int K, int J>
+__device__ __forceinline__ void regsort_stage(KeyT (&r)[E], u32 lane) {
+    if constexpr (J >= 64) {
+        constexpr int D = J / 64;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if ((e & D) == 0) {
+                const bool up = ((e * 64) & K) == 0;            // K >= 128 here: lane bits do not matter
+                KeyT a = r[e], b = r[e | D];
+                const bool sw = (a > b) == up;
+                r[e] = sw ? b : a; r[e | D] = sw ? a : b;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            KeyT o = xlane<J>(r[e], lane);
+            const bool up = (K >= 64) ? (((e * 64) & K) == 0) : ((lane & K) == 0);   // bit 6+ of the index lives in e
+            const bool lower = (lane & J) == 0;
+            KeyT mn = r[e] < o ? r[e] : o, mx = r[e] < o ? o : r[e];
+            r[e] = (lower == up) ? mn : mx;
+        }
+    }
+}
+template <class KeyT, int E, int K, int J>
+__device__ __forceinline__ void regsort_merge(KeyT (&r)[E], u32 lane) {
+    regsort_stage<KeyT, E, K, J>(r, lane);
+    if constexpr (J > 1) regsort_merge<KeyT, E, K, J / 2>(r, lane);
+}
+template <class KeyT, int E, int K>
+__device__ __forceinline__ void regsort_levels(KeyT (&r)[E], u32 lane) {
+    if constexpr (K > 2) regsort_levels<KeyT, E, K / 2>(r, lane);
+    regsort_merge<KeyT, E, K, K / 2>(r, lane);
+}
+template <class KeyT, int E>
+__device__ __forceinline__ void wave_regsort(KeyT (&r)[E], u32 lane) { regsort_levels<KeyT, E, 64 * E>(r, lane); }
 
 // ------------------------------------------------------------------ row 9: per-target best window range
 // buf[0..T) sorted by (tgt,win).  The reference's two-pointer sweep keeps, for the run of
@@ -339,21 +400,22 @@ __device__ __forceinline__ void bitonic_sort(u64* buf, u32 n, u32 tid, u32 G, Sy
 // the maximum of (hits, -j): folded with an LDS atomic max into H[first entry of the run]
 // (found by a second lower_bound that shares the loop).
 //   H[j0] = (hits << JB) | (JMASK - jbest) for run heads, 0 elsewhere.
-template <class HT, int JB, class Sync>
-__device__ __forceinline__ void sweep_targets(const u64* buf, HT* H, u32 T, u32 numWindows, u32 tid, u32 G,
+template <class KeyT, class HT, int JB, class Sync>
+__device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32 numWindows, u32 wb, u32 tid, u32 G,
                                               Sync sync) {
     const HT JMASK = ((HT)1 << JB) - 1;
+    const KeyT winmask = (((KeyT)1) << wb) - 1;
     for (u32 j = tid; j < T; j += G) H[j] = 0;
     sync();
     for (u32 j = tid; j < T; j += G) {
-        const u64 key = buf[j];
-        const u32 win = (u32)key;
-        const u64 headkey = key & 0xFFFFFFFF00000000ull;
-        const u64 lowkey = headkey | (u64)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+        const KeyT key = buf[j];
+        const u32 win = (u32)(key & winmask);
+        const KeyT headkey = key & ~winmask;
+        const KeyT lowkey = headkey | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
         u32 lo1 = 0, hi1 = j, lo2 = 0, hi2 = j;          // buf[j] >= both keys
         while (lo1 < hi1 || lo2 < hi2) {
             u32 mid1 = (lo1 + hi1) >> 1, mid2 = (lo2 + hi2) >> 1;
-            u64 v1 = buf[mid1], v2 = buf[mid2];
+            KeyT v1 = buf[mid1], v2 = buf[mid2];
             if (lo1 < hi1) { if (v1 < lowkey) lo1 = mid1 + 1; else hi1 = mid1; }
             if (lo2 < hi2) { if (v2 < headkey) lo2 = mid2 + 1; else hi2 = mid2; }
         }
@@ -364,16 +426,17 @@ __device__ __forceinline__ void sweep_targets(const u64* buf, HT* H, u32 T, u32 
 }
 
 // window range [beg,end] of the best candidate whose packed word is hv (run head j0 irrelevant)
-template <class HT, int JB>
-__device__ __forceinline__ void best_range(const u64* buf, HT hv, u32 numWindows, u32& beg, u32& end) {
+template <class KeyT, class HT, int JB>
+__device__ __forceinline__ void best_range(const KeyT* buf, HT hv, u32 numWindows, u32 wb, u32& beg, u32& end) {
     const HT JMASK = ((HT)1 << JB) - 1;
+    const KeyT winmask = (((KeyT)1) << wb) - 1;
     const u32 j = (u32)(JMASK - (hv & JMASK));
-    const u64 key = buf[j];
-    const u32 win = (u32)key;
-    const u64 lowkey = (key & 0xFFFFFFFF00000000ull) | (u64)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+    const KeyT key = buf[j];
+    const u32 win = (u32)(key & winmask);
+    const KeyT lowkey = (key & ~winmask) | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
     u32 lo = 0, hi = j;
     while (lo < hi) { u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
-    beg = (u32)buf[lo]; end = win;
+    beg = (u32)(buf[lo] & winmask); end = win;
 }
 
 // ------------------------------------------------------------------ rows 10-11: top lists in lanes
@@ -422,9 +485,9 @@ __device__ __forceinline__ void top_insert(TopLists& L, u32 lane, u32 r, u32 seg
 // its hits do not exceed the list minimum -- minima of a full list never decrease -- or
 // (b) its taxon was already inserted into the same list with at least as many hits (if
 // that entry has been evicted since, (a) covers it).  Only survivors reach top_insert.
-template <class HT, int JB>
+template <class KeyT, class HT, int JB>
 __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& opt, const OutDev& out,
-                                               const u64* buf, const HT* H, u32 T, u32 numWindows,
+                                               const KeyT* buf, const HT* H, u32 T, u32 numWindows, u32 wb,
                                                u64 q, u32 lane) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
@@ -434,7 +497,7 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
         u32 j = base + lane;
         HT hv = (j < T) ? H[j] : 0;
         u32 h = (u32)(hv >> JB);
-        u32 tgt = (j < T) ? (u32)(buf[j] >> 32) : 0;
+        u32 tgt = (j < T) ? (u32)(buf[j] >> wb) : 0;
         u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
         // taxon key of every run head of this chunk, fetched together
         u32 tax = MCQ_EMPTY;
@@ -477,7 +540,7 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
     u32 n = (u32)__builtin_popcountll(__ballot(lane < M && L.hits > 0));
     if (lane < n) {
         u32 beg = 0, end = 0;
-        if (P == 1) best_range<HT, JB>(buf, H[L.j0], numWindows, beg, end);
+        if (P == 1) best_range<KeyT, HT, JB>(buf, H[L.j0], numWindows, wb, beg, end);
         uint4 v; v.x = L.tax; v.y = L.hits; v.z = beg; v.w = end;
         reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
     }

@@ -43,7 +43,7 @@ struct mcq_db {
     u64 nslots;
     u64 n_keys_local, n_locs_local;
     uint4* slots;
-    u64* locs;
+    void* locs;
     u32* tgt2tax;
     u32 n_shards, shard_id;
     u64 bytes;
@@ -116,14 +116,27 @@ __global__ void k_owned_len(const u32* keys, const u64* list_off, u64 n_keys, u3
 }
 
 // copy owned lists into the compacted location array
-__global__ void k_copy_lists(const u64* list_off, const u64* new_off, const u64* locs, u64* out, u64 n_keys) {
+template <class KeyT>
+__global__ void k_copy_lists(const u64* list_off, const u64* new_off, const u64* locs, KeyT* out, u64 n_keys, u32 wb) {
     // one wave per key, grid-stride (the grid is bounded: total threads must stay < 2^32)
     const u32 lane = threadIdx.x & 63;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 key = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; key < n_keys; key += nwaves) {
         u64 b = new_off[key], n = new_off[key + 1] - b, src = list_off[key];
-        for (u64 t = lane; t < n; t += 64) out[b + t] = locs[src + t];
+        for (u64 t = lane; t < n; t += 64) {
+            u64 l = locs[src + t];
+            out[b + t] = (KeyT)(((l >> 32) << wb) | (l & 0xFFFFFFFFull));
+        }
     }
+}
+
+// largest window id over all locations (decides whether locations fit 32 bits)
+__global__ void k_max_win(const u64* locs, u64 n, u32* out) {
+    u32 m = 0;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) { u32 w = (u32)locs[i]; m = w > m ? w : m; }
+    for (int d = 32; d > 0; d >>= 1) { u32 o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
 // exclusive scan of u64 array (single workgroup, used only at DB build)
@@ -156,15 +169,50 @@ __global__ __launch_bounds__(1024) void k_scan_u64(const u64* in, u64* out, u64 
 // ------------------------------------------------------------------ kernel: wave per query
 __device__ __forceinline__ u32 pow2ceil(u32 x) { return x <= 1 ? 1u : 1u << (32 - __builtin_clz(x - 1)); }
 
-template <int LCAP>
+template <class KeyT> __device__ __forceinline__ KeyT key_pad() { return ~(KeyT)0; }
+// location word -> the public (tgt << 32) | win form
+template <class KeyT> __device__ __forceinline__ u64 key_expand(KeyT k, u32 wb) {
+    const KeyT winmask = (((KeyT)1) << wb) - 1;
+    return ((u64)(k >> wb) << 32) | (u64)(k & winmask);
+}
+
+// Gather E*64 list elements into registers (r[e] = element e*64 + lane), sort them there,
+// and leave the sorted keys in the wave's LDS segment for the sweep.
+// Element t belongs to the last feature lane j with pos_j <= t (6-step shuffle search).
+template <class KeyT, int E>
+__device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u32 T, u32 pos, u64 off, u32 lane, int stop) {
+    KeyT r[E];
+    const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 t = e * 64 + lane;
+        const u32 tt = t < T ? t : T - 1;
+        u32 lo = 0;
+#pragma unroll
+        for (u32 step = 32; step > 0; step >>= 1) {
+            u32 c = lo + step;
+            u32 pc = __shfl(pos, (int)(c & 63), 64);
+            if (c < 64 && pc <= tt) lo = c;
+        }
+        u32 pj = __shfl(pos, (int)lo, 64);
+        u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
+        r[e] = key_pad<KeyT>();
+        if (t < T) r[e] = locs[(((u64)ohi << 32) | olo) + (tt - pj)];
+    }
+    if (stop != 3) wave_regsort<KeyT, E>(r, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) buf[e * 64 + lane] = r[e];
+}
+
+template <class KeyT, int LCAP>
 __global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                     CountersDev* ctr, u32* ovf_list, int force_block) {
-    static_assert(LCAP >= 128 && LCAP <= 512, "wave path packs the entry index into 9 bits");
-    __shared__ u64 s_buf[4][LCAP];
+    static_assert(LCAP == 512, "wave path: 8 keys per lane at most, entry index packed into 9 bits");
+    __shared__ KeyT s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    u64* buf = s_buf[wave];
+    KeyT* buf = s_buf[wave];
     u32* hits = s_hits[wave];
     u32* sk_tmp = hits;                // sketch scratch aliases the (not yet used) hit words
     u32* feat = hits + 64;
@@ -211,32 +259,17 @@ __global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev
         st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
 
-        // gather the lists: element t belongs to the last feature lane j with pos_j <= t
-        const u32 n2p = pow2ceil(T);
-        for (u32 base = 0; base < n2p; base += 64) {
-            const u32 t = base + lane;
-            const u32 tt = t < T ? t : T - 1;
-            u32 lo = 0;
-#pragma unroll
-            for (u32 step = 32; step > 0; step >>= 1) {
-                u32 c = lo + step;
-                u32 pc = __shfl(pos, (int)(c & 63), 64);
-                if (c < 64 && pc <= tt) lo = c;
-            }
-            u32 pj = __shfl(pos, (int)lo, 64);
-            u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
-            u64 v = ~0ull;
-            if (t < T) v = db.locs[(((u64)ohi << 32) | olo) + (tt - pj)];
-            if (t < n2p) buf[t] = v;
-        }
+        wave_sync();                                   // feat[] (aliasing hits) has been consumed
+        if (T <= 64)       gather_sort_store<KeyT, 1>(db, buf, T, pos, off, lane, stop);
+        else if (T <= 128) gather_sort_store<KeyT, 2>(db, buf, T, pos, off, lane, stop);
+        else if (T <= 256) gather_sort_store<KeyT, 4>(db, buf, T, pos, off, lane, stop);
+        else               gather_sort_store<KeyT, 8>(db, buf, T, pos, off, lane, stop);
         wave_sync();
-        if (stop == 3) { if (buf[lane & (n2p - 1)] == 0x1234ull) out.ncand[q] = 1; continue; }
-        bitonic_sort(buf, n2p, lane, 64u, [] { wave_sync(); });
-        if (stop == 4) { if (buf[lane & (n2p - 1)] == 0x1234ull) out.ncand[q] = 1; continue; }
+        if (stop == 3 || stop == 4) { if (buf[lane] == (KeyT)0x1234) out.ncand[q] = 1; continue; }
         const u32 numWindows = range_width(l1 + l2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        sweep_targets<u32, 9>(buf, hits, T, numWindows, lane, 64u, [] { wave_sync(); });
-        if (stop == 5) { if (hits[lane & (n2p - 1)] == 0x12345u) out.ncand[q] = 1; continue; }
-        st_cand += topk_fold_write<u32, 9>(db, opt, out, buf, hits, T, numWindows, q, lane);
+        sweep_targets<KeyT, u32, 9>(buf, hits, T, numWindows, db.wb, lane, 64u, [] { wave_sync(); });
+        if (stop == 5) { if (hits[lane] == 0x12345u) out.ncand[q] = 1; continue; }
+        st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
     }
     if (lane == 0 && (st_feat | st_loc)) {
@@ -271,29 +304,29 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
 }
 
 // Tail of the workgroup path: fill B[0..n2p) through `load(t)`, sort, sweep, top lists.
-template <bool kLds, class Load>
+template <class KeyT, bool kLds, class Load>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
-                                           u64* B, u64* H, u32 T, u32 numWindows, u64 q, u32 tid,
+                                           KeyT* B, u64* H, u32 T, u32 numWindows, u32 wb, u64 q, u32 tid,
                                            const DebugDev& dbg, Load load) {
     const u32 n2p = pow2ceil(T);
-    for (u32 t = tid; t < n2p; t += 1024) B[t] = (t < T) ? load(t) : ~0ull;
+    for (u32 t = tid; t < n2p; t += 1024) B[t] = (t < T) ? load(t) : key_pad<KeyT>();
     __syncthreads();
     bitonic_sort(B, n2p, tid, 1024u, [] { __syncthreads(); });
     if (dbg.mode == 2) {
-        for (u32 t = tid; t < T; t += 1024) dbg.matches[dbg.match_off[q] + t] = B[t];
+        for (u32 t = tid; t < T; t += 1024) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], wb);
     }
-    sweep_targets<u64, 32>(B, H, T, numWindows, tid, 1024u, [] { __syncthreads(); });
+    sweep_targets<KeyT, u64, 32>(B, H, T, numWindows, wb, tid, 1024u, [] { __syncthreads(); });
     if (tid < 64) {
-        u32 n = topk_fold_write<u64, 32>(db, opt, out, B, H, T, numWindows, q, tid);
+        u32 n = topk_fold_write<KeyT, u64, 32>(db, opt, out, B, H, T, numWindows, wb, q, tid);
         if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
     }
     __syncthreads();
 }
 
-template <int LCAPB>
+template <class KeyT, int LCAPB>
 __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                       CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg) {
-    __shared__ u64 s_buf[LCAPB];
+    __shared__ KeyT s_buf[LCAPB];
     __shared__ u64 s_hits[LCAPB];
     __shared__ u32 s_w[20];
     const u32 tid = threadIdx.x, lane = tid & 63;
@@ -302,8 +335,9 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
     u32* feat = sc.feat + (u64)blockIdx.x * sc.fmax;
     u32* fpos = sc.fpos + (u64)blockIdx.x * ((u64)sc.fmax + 1);
     u64* foff = sc.foff + (u64)blockIdx.x * sc.fmax;
-    u64* gbuf = sc.gbuf + (u64)blockIdx.x * sc.lmax;
+    KeyT* gbuf = reinterpret_cast<KeyT*>(sc.gbuf + (u64)blockIdx.x * sc.lmax);
     u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
+    const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
     const u32 n_ovf = ctr->ovf_count;
     u32* sk = reinterpret_cast<u32*>(s_hits) + wave * 128;     // per-wave sketch scratch (hit words unused yet)
 
@@ -357,13 +391,13 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
             continue;
         }
         const u32 numWindows = range_width(n1 + n2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        auto load = [&](u32 t) -> u64 {
+        auto load = [&](u32 t) -> KeyT {
             u32 lo = 0, hi = F;                       // last j in [0,F) with fpos[j] <= t
             while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (fpos[mid] <= t) lo = mid; else hi = mid; }
-            return db.locs[foff[lo] + (t - fpos[lo])];
+            return locs[foff[lo] + (t - fpos[lo])];
         };
-        if (pow2ceil(T) <= (u32)LCAPB) block_tail<true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, q, tid, dbg, load);
-        else                           block_tail<false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, q, tid, dbg, load);
+        if (pow2ceil(T) <= (u32)LCAPB) block_tail<KeyT, true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, load);
+        else                           block_tail<KeyT, false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, load);
     }
 }
 
@@ -404,10 +438,12 @@ __global__ void k_lookup_count(DbDev db, const u32* features, u64 n, u32* list_l
 }
 
 // one wave per 64 consecutive features: probe again, then copy the lists cooperatively
+template <class KeyT>
 __global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* features, u64 n, const u64* out_off, u64* out_locs) {
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u64 ngroups = (n + 63) / 64, nwaves = (u64)gridDim.x * 4;
+    const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
     for (u64 g = (u64)blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
         const u64 i = g * 64 + lane;
         u64 off = 0; u32 len = 0;
@@ -428,12 +464,22 @@ __global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* feat
             }
             u32 pj = __shfl(pos, (int)lo, 64);
             u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
-            if (t < T) out_locs[obase + t] = db.locs[(((u64)ohi << 32) | olo) + (tt - pj)];
+            if (t < T) out_locs[obase + t] = key_expand<KeyT>(locs[(((u64)ohi << 32) | olo) + (tt - pj)], db.wb);
         }
     }
 }
 
-// rows 8-11 from per-query location segments (home GPU of the sharded path)
+// rows 8-11 from per-query location segments in the public u64 form (home GPU of the sharded path)
+template <int E>
+__device__ __forceinline__ void load_sort_store(u64* buf, const u64* src, u32 T, u32 lane) {
+    u64 r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const u32 t = e * 64 + lane; r[e] = t < T ? src[t] : ~0ull; }
+    wave_regsort<u64, E>(r, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) buf[e * 64 + lane] = r[e];
+}
+
 template <int LCAP>
 __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, u32* ovf_list,
                                                      u64 nq, const u64* loc_off, const u64* locs, const u32* query_len) {
@@ -454,13 +500,14 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         const u32 T = (u32)T64;
         st_loc += T;
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
-        const u32 n2p = pow2ceil(T);
-        for (u32 t = lane; t < n2p; t += 64) buf[t] = (t < T) ? locs[b0 + t] : ~0ull;
+        if (T <= 64)       load_sort_store<1>(buf, locs + b0, T, lane);
+        else if (T <= 128) load_sort_store<2>(buf, locs + b0, T, lane);
+        else if (T <= 256) load_sort_store<4>(buf, locs + b0, T, lane);
+        else               load_sort_store<8>(buf, locs + b0, T, lane);
         wave_sync();
-        bitonic_sort(buf, n2p, lane, 64u, [] { wave_sync(); });
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        sweep_targets<u32, 9>(buf, hits, T, numWindows, lane, 64u, [] { wave_sync(); });
-        st_cand += topk_fold_write<u32, 9>(db, opt, out, buf, hits, T, numWindows, q, lane);
+        sweep_targets<u64, u32, 9>(buf, hits, T, numWindows, 32u, lane, 64u, [] { wave_sync(); });
+        st_cand += topk_fold_write<u64, u32, 9>(db, opt, out, buf, hits, T, numWindows, 32u, q, lane);
         wave_sync();
     }
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
@@ -487,8 +534,8 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
         if (tid == 0) atomicAdd(&ctr->n_locations, (unsigned long long)T);
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         auto load = [&](u32 t) -> u64 { return locs[b0 + t]; };
-        if (pow2ceil(T) <= (u32)LCAPB) block_tail<true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, q, tid, dbg, load);
-        else                           block_tail<false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, q, tid, dbg, load);
+        if (pow2ceil(T) <= (u32)LCAPB) block_tail<u64, true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, 32u, q, tid, dbg, load);
+        else                           block_tail<u64, false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, 32u, q, tid, dbg, load);
     }
 }
 
@@ -588,8 +635,24 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     db->n_keys_local = nk_local; db->n_locs_local = nl_local;
     db->nslots = std::max<u64>(1024, pow2ceil64(nk_local * 2));      // load factor <= 0.5
     if (db->nslots > (1ull << 32)) { return fail(MCQ_E_UNSUPPORTED, "table too large"); }
+    // compact locations: (tgt << wb) | win in 32 bits when target and window ids fit
+    u32 wb = 32, compact = 0;
+    if (!(desc->flags & MCQ_DB_LOCS_64)) {
+        u32* d_mw = nullptr; u32 maxwin = 0;
+        HIPCHK(hipMalloc(&d_mw, 4));
+        HIPCHK(hipMemset(d_mw, 0, 4));
+        if (nl) hipLaunchKernelGGL(k_max_win, dim3(1024), dim3(256), 0, 0, d_locs, nl, d_mw);
+        HIPCHK(hipMemcpy(&maxwin, d_mw, 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d_mw);
+        u32 winbits = 1; while (winbits < 32 && (maxwin >> winbits)) ++winbits;
+        u32 maxtgt = desc->n_targets ? desc->n_targets - 1 : 0;
+        u32 tgtbits = 1; while (tgtbits < 32 && (maxtgt >> tgtbits)) ++tgtbits;
+        if (winbits + tgtbits <= 32 && winbits <= 31 &&
+            ((((u64)maxtgt << winbits) | maxwin) < 0xFFFFFFFFull)) { compact = 1; wb = winbits; }
+    }
+    const u64 locsz = compact ? 4 : 8;
     HIPCHK(hipMalloc(&db->slots, db->nslots * sizeof(uint4)));
-    HIPCHK(hipMalloc(&db->locs, std::max<u64>(1, nl_local) * 8));
+    HIPCHK(hipMalloc(&db->locs, std::max<u64>(1, nl_local) * locsz));
     HIPCHK(hipMalloc(&db->tgt2tax, std::max<u32>(1, desc->n_targets) * 4));
     if (desc->n_targets)
         HIPCHK(hipMemcpy(db->tgt2tax, desc->tgt2tax, (u64)desc->n_targets * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -598,7 +661,9 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
         hipLaunchKernelGGL(k_insert_keys, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, db->slots, (u32)(db->nslots - 1),
                            d_keys, d_new, nk, n_shards, desc->shard_id);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(k_copy_lists, dim3((u32)std::min<u64>((nk * 64 + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, d_off, d_new, d_locs, db->locs, nk);
+        const dim3 cg((u32)std::min<u64>((nk * 64 + TB - 1) / TB, 1u << 20));
+        if (compact) hipLaunchKernelGGL(k_copy_lists<u32>, cg, dim3(TB), 0, 0, d_off, d_new, d_locs, (u32*)db->locs, nk, wb);
+        else         hipLaunchKernelGGL(k_copy_lists<u64>, cg, dim3(TB), 0, 0, d_off, d_new, d_locs, (u64*)db->locs, nk, 32u);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipDeviceSynchronize());
@@ -608,12 +673,13 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     if (t_locs) (void)hipFree(t_locs);
 
     db->d.slots = db->slots; db->d.slot_mask = (u32)(db->nslots - 1); db->d.locs = db->locs;
+    db->d.wb = wb; db->d.compact = compact;
     db->d.tgt2tax = db->tgt2tax; db->d.n_targets = desc->n_targets;
     db->d.k = desc->k; db->d.s = desc->sketch_size; db->d.winlen = desc->winlen; db->d.winstride = desc->winstride;
     db->d.tgt_winstride = desc->tgt_winstride ? desc->tgt_winstride : desc->winstride;
     db->d.magic_stride = (u32)std::min<u64>((1ull << 32) / db->d.winstride, 0xFFFFFFFFull);
     db->d.magic_tgt_stride = (u32)std::min<u64>((1ull << 32) / db->d.tgt_winstride, 0xFFFFFFFFull);
-    db->bytes = db->nslots * sizeof(uint4) + std::max<u64>(1, nl_local) * 8 + (u64)desc->n_targets * 4;
+    db->bytes = db->nslots * sizeof(uint4) + std::max<u64>(1, nl_local) * locsz + (u64)desc->n_targets * 4;
     *out = db;
     return MCQ_OK;
 }
@@ -698,10 +764,13 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
         else { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); }
         HIPCHK(hipEventRecord(e0, st));
     }
-    hipLaunchKernelGGL((k_query_wave<kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
+    if (db->d.compact) hipLaunchKernelGGL((k_query_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
+    else               hipLaunchKernelGGL((k_query_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
     if (ws->timing) { HIPCHK(hipEventRecord(e1, st)); ws->ev_used->emplace_back(e0, e1); }
-    hipLaunchKernelGGL((k_query_block<kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
-                       (const u32*)ws->ovf_list, ws->sc, dbg);
+    if (db->d.compact) hipLaunchKernelGGL((k_query_block<u32, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
+                                          (const u32*)ws->ovf_list, ws->sc, dbg);
+    else               hipLaunchKernelGGL((k_query_block<u64, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
+                                          (const u32*)ws->ovf_list, ws->sc, dbg);
     HIPCHK(hipGetLastError());
     ws->last_nq = b.nq;
     return MCQ_OK;
@@ -848,7 +917,8 @@ extern "C" int mcq_lookup_gather(const mcq_db* db, const uint32_t* features, uin
     if (n_features == 0) return MCQ_OK;
     u64 groups = (n_features + 63) / 64;
     u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
-    hipLaunchKernelGGL(k_lookup_gather, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, out_off, out_locs);
+    if (db->d.compact) hipLaunchKernelGGL(k_lookup_gather<u32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, out_off, out_locs);
+    else               hipLaunchKernelGGL(k_lookup_gather<u64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, out_off, out_locs);
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }

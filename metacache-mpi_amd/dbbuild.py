@@ -85,7 +85,7 @@ def build_table(bases, seq_off, emulate_ranks=1, k=16, s=16, winlen=128, winstri
 
 
 def make_database(keys, list_off, locs, tgt2tax, n_shards=1, shard_id=0, k=16, s=16, winlen=128, winstride=113,
-                  tgt_winstride=0):
+                  tgt_winstride=0, flags=0):
     """cuda tensors -> engine.Database (device-pointer create, no host round trip)."""
     dev = keys.device
 
@@ -97,7 +97,7 @@ def make_database(keys, list_off, locs, tgt2tax, n_shards=1, shard_id=0, k=16, s
     list_off = list_off.contiguous(); locs = locs.contiguous()
     torch.cuda.synchronize(dev)
     db = engine.Database(None, None, None, None, k=k, sketch_size=s, winlen=winlen, winstride=winstride,
-                         tgt_winstride=tgt_winstride, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0,
+                         tgt_winstride=tgt_winstride, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0, flags=flags,
                          device_ptrs=dict(keys=k32.data_ptr(), list_off=list_off.data_ptr(), locs=locs.data_ptr(),
                                           tgt2tax=t2t.data_ptr(), n_keys=k32.numel(), n_locs=locs.numel(),
                                           n_targets=t2t.numel()))

@@ -13,6 +13,7 @@ from .build import lib_path
 MCQ_DEVICE_PTRS = 1
 MCQ_QUIRK_SEQ_DROP = 2
 MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-query path
+MCQ_DB_LOCS_64 = 0x200           # Database(flags=...): keep 64-bit locations
 
 MCQ_OK, MCQ_E_ARG, MCQ_E_HIP, MCQ_E_CAPACITY, MCQ_E_UNSUPPORTED = 0, -1, -2, -3, -4
 
@@ -100,7 +101,7 @@ class Database:
     of the reference's sketch_database: built from the union of its shard tables."""
 
     def __init__(self, keys, list_off, locs, tgt2tax, k=16, sketch_size=16, winlen=128, winstride=113,
-                 tgt_winstride=0, n_shards=1, shard_id=0, device=0, device_ptrs=None):
+                 tgt_winstride=0, n_shards=1, shard_id=0, device=0, device_ptrs=None, flags=0):
         """keys/list_off/locs/tgt2tax: numpy arrays (host) -- or, with device_ptrs=dict(
         keys=ptr, list_off=ptr, locs=ptr, tgt2tax=ptr, n_keys=, n_locs=, n_targets=), raw device pointers."""
         d = DbDesc()
@@ -113,12 +114,12 @@ class Database:
             assert len(oo) == len(kk) + 1
             d.n_keys, d.n_locs, d.n_targets = len(kk), len(ll), len(tt)
             d.keys, d.list_off, d.locs, d.tgt2tax = _np_ptr(kk), _np_ptr(oo), _np_ptr(ll), _np_ptr(tt)
-            d.flags = 0
+            d.flags = flags
         else:
             p = device_ptrs
             d.n_keys, d.n_locs, d.n_targets = p["n_keys"], p["n_locs"], p["n_targets"]
             d.keys, d.list_off, d.locs, d.tgt2tax = p["keys"], p["list_off"], p["locs"], p["tgt2tax"]
-            d.flags = MCQ_DEVICE_PTRS
+            d.flags = MCQ_DEVICE_PTRS | flags
         self.k, self.sketch_size, self.winlen, self.winstride = k, sketch_size, winlen, winstride
         self.device = device
         h = C.c_void_p()

@@ -19,12 +19,12 @@ def eng():
     return importlib.import_module("metacache-mpi_amd.engine")
 
 
-def _dbs(eng, fx, shards=None):
+def _dbs(eng, fx, shards=None, flags=0):
     keys, off, locs = dbfile.union_shards(fx.shards if shards is None else shards)
     p = fx.params
     kw = dict(k=p["qk"], winlen=p["qwinlen"], winstride=p["qwinstride"], tgt_winstride=p["winstride"])
     t2t = fx.tgt2tax()
-    return (eng.Database(keys, off, locs, t2t, sketch_size=p["qs"], **kw),
+    return (eng.Database(keys, off, locs, t2t, sketch_size=p["qs"], flags=flags, **kw),
             orc.OracleDb(keys, off, locs, t2t, s=p["qs"], **kw))
 
 
@@ -36,9 +36,10 @@ def _same(cands, ncand, oc, on):
 
 @pytest.mark.parametrize("tag,P", CASES)
 @pytest.mark.parametrize("block", [False, True], ids=["wave", "block"])
-def test_final_vs_reference_cli(eng, tag, P, block):
+@pytest.mark.parametrize("locs64", [False, True], ids=["loc32", "loc64"])
+def test_final_vs_reference_cli(eng, tag, P, block, locs64):
     fx = Fixture(tag, P)
-    db, odb = _dbs(eng, fx)
+    db, odb = _dbs(eng, fx, flags=eng.MCQ_DB_LOCS_64 if locs64 else 0)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     ws = eng.Workspace(db, len(fx.names), len(bases))
     flags = eng.MCQ_QUIRK_SEQ_DROP | (eng.MCQ_FORCE_BLOCK_PATH if block else 0)
@@ -59,7 +60,7 @@ def test_per_rank_candidates_with_positions(eng, tag, P):
     fx = Fixture(tag, P)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     for r in range(P):
-        db, odb = _dbs(eng, fx, [fx.shards[r]])
+        db, odb = _dbs(eng, fx, [fx.shards[r]], flags=eng.MCQ_DB_LOCS_64 if r % 2 else 0)
         ws = eng.Workspace(db, len(fx.names), len(bases))
         for flags in (0, eng.MCQ_FORCE_BLOCK_PATH):
             cands, ncand = ws.query_host(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=1, flags=flags)
@@ -74,7 +75,7 @@ def test_sorted_match_lists(eng, tag, P):
     fx = Fixture(tag, P)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     for r in range(P):
-        db, odb = _dbs(eng, fx, [fx.shards[r]])
+        db, odb = _dbs(eng, fx, [fx.shards[r]], flags=eng.MCQ_DB_LOCS_64 if r % 2 else 0)
         ws = eng.Workspace(db, len(fx.names), len(bases))
         moff, m = ws.debug_matches(bases, seq_off, True)
         for q in range(len(fx.names)):

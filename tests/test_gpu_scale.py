@@ -21,7 +21,7 @@ def world():
     out = {}
     for P in (1, 2, 4):
         keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=P)
-        db = dbbuild.make_database(keys, off, locs, species)
+        db = dbbuild.make_database(keys, off, locs, species, flags=eng.MCQ_DB_LOCS_64 if P == 4 else 0)
         odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), off.cpu().numpy().astype(np.uint64),
                            locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
         out[P] = (db, odb)
@@ -37,7 +37,7 @@ def _compare(cands, ncand, oc, on, what):
     assert len(bad) == 0, (what, "cands differ at", bad[:5], cands[bad[0]], oc[bad[0]])
 
 
-@pytest.mark.parametrize("P,M", [(1, 4), (2, 2), (2, 8), (4, 4)])
+@pytest.mark.parametrize("P,M", [(1, 4), (2, 2), (2, 8), (4, 4), (4, 16)])
 def test_short_reads(world, P, M):
     eng, synth, gb, goff, dbs = world
     db, odb = dbs[P]
