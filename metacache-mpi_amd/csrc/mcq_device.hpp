@@ -425,6 +425,33 @@ __device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32
     sync();
 }
 
+// Wave version (T <= 512, packed into u32 with JB = 9): the head of an entry's run comes
+// from a ballot of run starts in its 64-chunk (carried across chunks), and the single
+// binary search is confined to [head, j].
+template <class KeyT>
+__device__ __forceinline__ void sweep_targets_wave(const KeyT* buf, u32* H, u32 T, u32 numWindows, u32 wb, u32 lane) {
+    const KeyT winmask = (((KeyT)1) << wb) - 1;
+    for (u32 j = lane; j < T; j += 64) H[j] = 0;
+    wave_sync();
+    u32 carry_head = 0;
+    for (u32 base = 0; base < T; base += 64) {
+        const u32 j = base + lane;
+        const bool valid = j < T;
+        const KeyT key = buf[valid ? j : T - 1];
+        const KeyT prev = buf[(valid && j > 0) ? j - 1 : 0];
+        const bool head = valid && (j == 0 || (prev >> wb) != (key >> wb));
+        const u64 le = __ballot(head) & ((2ull << lane) - 1);
+        const u32 myhead = le ? base + (63u - (u32)__builtin_clzll(le)) : carry_head;
+        const u32 win = (u32)(key & winmask);
+        const KeyT lowkey = (key & ~winmask) | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+        u32 lo = myhead, hi = valid ? j : myhead;
+        while (lo < hi) { u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
+        if (valid) atomicMax(&H[myhead], ((j - lo + 1) << 9) | (511u - j));
+        carry_head = bcast(myhead, 63);
+    }
+    wave_sync();
+}
+
 // window range [beg,end] of the best candidate whose packed word is hv (run head j0 irrelevant)
 template <class KeyT, class HT, int JB>
 __device__ __forceinline__ void best_range(const KeyT* buf, HT hv, u32 numWindows, u32 wb, u32& beg, u32& end) {
@@ -440,108 +467,117 @@ __device__ __forceinline__ void best_range(const KeyT* buf, HT hv, u32 numWindow
 }
 
 // ------------------------------------------------------------------ rows 10-11: top lists in lanes
+// The reference builds each bounded top list by inserting candidates one at a time
+// (src/candidates.h:236-285); the result is order-dependent (max per taxon, evictions,
+// stable ties).  It has a closed form (tests/test_toplist_theorem.py checks it against
+// the restated insert()):
+//     list = first M of { (taxon, max hits, first candidate reaching that max) }
+//            ordered by (hits descending, that candidate's position ascending)
+// because the minimum of a full list never decreases and equal-hit entries keep the order
+// in which they reached their value.  So a list is built by M rounds of "wave-wide max of
+// the packed (hits, -position) word, record it, retire every candidate of that taxon" --
+// no serial insert loop.  A tree-fold step (src/querying.h:910-971) is the same closed form
+// on the concatenation receiver-list ++ sender-list.
+//
 // The P virtual-rank lists live side by side in one wave: list r occupies lanes
-// [r*seg, r*seg + M).  An entry is (tax, hits, j0); hits == 0 marks an unused lane, and
-// used lanes of a list are always a prefix sorted by hits descending.
-struct TopLists {
-    u32 tax, hits, j0;
-};
-
-// insert candidate (ctax, chits, cj0) -- all wave-uniform -- into list `r`
-__device__ __forceinline__ void top_insert(TopLists& L, u32 lane, u32 r, u32 seg, u32 M,
-                                           u32 ctax, u32 chits, u32 cj0) {
-    const u32 base = r * seg;
-    const bool in_list = (lane >= base) && (lane < base + M);
-    const u32 li = lane - base;                                  // index inside the list
-    const u64 segmask = (M >= 64 ? ~0ull : ((1ull << M) - 1)) << base;
-    u64 same = __ballot(in_list && L.hits > 0 && L.tax == ctax) & segmask;
-    // neighbours one lane to the left (for shifting entries right by one)
-    u32 ptax = __shfl_up(L.tax, 1, 64), phits = __shfl_up(L.hits, 1, 64), pj0 = __shfl_up(L.j0, 1, 64);
-    if (same) {
-        u32 i = (u32)__builtin_ctzll(same) - base;               // position of the taxon
-        u32 ihits = __builtin_amdgcn_readlane(L.hits, (int)(base + i));
-        if (chits > ihits) {
-            // new position: after every earlier entry with hits >= chits
-            u64 ge = __ballot(in_list && li < i && L.hits >= chits) & segmask;
-            u32 jn = (u32)__builtin_popcountll(ge);
-            if (in_list && li > jn && li <= i) { L.tax = ptax; L.hits = phits; L.j0 = pj0; }
-            if (in_list && li == jn) { L.tax = ctax; L.hits = chits; L.j0 = cj0; }
-        }
-        return;
-    }
-    // position = number of entries with hits >= chits (first strictly smaller one)
-    u64 ge = __ballot(in_list && L.hits >= chits) & segmask;
-    u32 jn = (u32)__builtin_popcountll(ge);
-    if (jn >= M) return;                                          // full and not better than the last
-    if (in_list && li > jn) { L.tax = ptax; L.hits = phits; L.j0 = pj0; }   // shift right, last one falls off
-    if (in_list && li == jn) { L.tax = ctax; L.hits = chits; L.j0 = cj0; }
+// [r*seg, r*seg + M).  An entry is (tax, hv) with hv the packed sweep word
+// (hits << JB | JMASK - jbest); hv == 0 marks an unused lane.
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+    u32 t;
+    t = dpp_mov<0xB1>(v);  v = t > v ? t : v;
+    t = dpp_mov<0x4E>(v);  v = t > v ? t : v;
+    t = dpp_mov<0x141>(v); v = t > v ? t : v;
+    t = dpp_mov<0x140>(v); v = t > v ? t : v;
+    u32 a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    u32 c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    a = a > b ? a : b; c = c > d ? c : d;
+    return a > c ? a : c;
+}
+__device__ __forceinline__ u32 wave_max(u32 v) { return wave_max_u32(v); }
+__device__ __forceinline__ u64 wave_max(u64 v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { u64 o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
 }
 
-// Builds the P lists from the swept buffer, folds them in the reference's tree order
-// and writes the result for query q.  Executed by ONE full wave.  Returns the number
-// of candidates written (wave-uniform).
-//
-// Parallel pre-filter (exact): a candidate changes nothing if (a) its list is full and
-// its hits do not exceed the list minimum -- minima of a full list never decrease -- or
-// (b) its taxon was already inserted into the same list with at least as many hits (if
-// that entry has been evicted since, (a) covers it).  Only survivors reach top_insert.
 template <class KeyT, class HT, int JB>
 __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& opt, const OutDev& out,
-                                               const KeyT* buf, const HT* H, u32 T, u32 numWindows, u32 wb,
+                                               const KeyT* buf, HT* H, u32 T, u32 numWindows, u32 wb,
                                                u64 q, u32 lane) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
-    TopLists L; L.tax = MCQ_EMPTY; L.hits = 0; L.j0 = 0;
+    const HT JMASK = ((HT)1 << JB) - 1;
+    const u64 below = (1ull << lane) - 1;
 
+    // 1. compact the run heads' packed words to H[0..nheads) (in place: writes trail reads)
+    u32 nheads = 0;
     for (u32 base = 0; base < T; base += 64) {
-        u32 j = base + lane;
-        HT hv = (j < T) ? H[j] : 0;
-        u32 h = (u32)(hv >> JB);
-        u32 tgt = (j < T) ? (u32)(buf[j] >> wb) : 0;
-        u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
-        // taxon key of every run head of this chunk, fetched together
-        u32 tax = MCQ_EMPTY;
-        if (h > 0) tax = (tgt < db.n_targets) ? db.tgt2tax[tgt] : MCQ_EMPTY;
-        // best hits already in my list for my taxon (lists persist across chunks)
-        u32 dom = 0;
-        if (base > 0) {
+        const u32 j = base + lane;
+        const HT hv = (j < T) ? H[j] : 0;
+        const u64 hm = __ballot(hv != 0);
+        if (hv != 0) H[nheads + (u32)__builtin_popcountll(hm & below)] = hv;
+        nheads += (u32)__builtin_popcountll(hm);
+    }
+    wave_sync();
+
+    // 2. stream the candidates through the lists, 64 at a time
+    const u32 rl = lane / seg, li = lane - rl * seg;
+    const bool lslot = (li < M) && (rl < P);
+    u32 Ltax = MCQ_EMPTY; HT Lhv = 0;
+    for (u32 base = 0; base < nheads; base += 64) {
+        const u32 k = base + lane;
+        HT cv = (k < nheads) ? H[k] : 0;
+        const u32 jb = (u32)(JMASK - (cv & JMASK));
+        const u32 tgt = (u32)(buf[cv ? jb : 0] >> wb);
+        u32 ctax = MCQ_EMPTY;
+        if (cv != 0 && tgt < db.n_targets) ctax = db.tgt2tax[tgt];
+        if (ctax == MCQ_EMPTY) cv = 0;
+        const u32 cr = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+        u32 Ntax = MCQ_EMPTY; HT Nhv = 0;
+        bool lalive = Lhv != 0;
+        for (u32 r = 0; r < P; ++r) {
             for (u32 i = 0; i < M; ++i) {
-                u32 et = __shfl(L.tax, (int)(r * seg + i), 64), eh = __shfl(L.hits, (int)(r * seg + i), 64);
-                if (eh > 0 && et == tax) dom = eh;
+                const HT a = (cr == r) ? cv : 0;
+                const HT b2 = (lalive && lslot && rl == r) ? Lhv : 0;
+                const HT v = a > b2 ? a : b2;
+                const HT m = wave_max(v);
+                if (m == 0) break;
+                const u32 src = (u32)__builtin_ctzll(__ballot(v == m));
+                const u32 wtax = bcast((a == m) ? ctax : Ltax, src);
+                if (lane == r * seg + i) { Ntax = wtax; Nhv = m; }
+                if (cr == r && ctax == wtax) cv = 0;
+                if (lslot && rl == r && Ltax == wtax) lalive = false;
             }
         }
-        u64 pending = __ballot(h > 0 && tax != MCQ_EMPTY);
-        while (pending) {
-            u32 thr = __shfl(L.hits, (int)(r * seg + M - 1), 64);
-            pending &= __ballot(h > thr && h > dom);
-            if (!pending) break;
-            u32 c = (u32)__builtin_ctzll(pending);
-            pending &= pending - 1;
-            u32 ctax = bcast(tax, c), chits = bcast(h, c), cr = bcast(r, c);
-            top_insert(L, lane, cr, seg, M, ctax, chits, base + c);
-            if (r == cr && tax == ctax && chits > dom) dom = chits;
-        }
+        Ltax = Ntax; Lhv = Nhv;
     }
 
+    // 3. tree fold: receiver-list ++ sender-list, positions decide ties
     if (P > 1) {
         for (u32 f = 0; f < opt.n_fold; ++f) {
-            u32 snd = opt.fold_snd[f], rcv = opt.fold_rcv[f];
+            const u32 snd = opt.fold_snd[f], rcv = opt.fold_rcv[f];
+            const bool mine = lslot && (rl == rcv || rl == snd) && Lhv != 0 &&
+                              !(opt.quirk_seq_drop && rl == snd && (Ltax & 0x80000000u));
+            u32 fk = mine ? (((u32)(Lhv >> JB)) << 8) | (255u - (rl == snd ? M + li : li)) : 0u;
+            u32 Ntax = MCQ_EMPTY; HT Nhv = 0;
             for (u32 i = 0; i < M; ++i) {
-                u32 sl = snd * seg + i;
-                u32 ctax = bcast(L.tax, sl), chits = bcast(L.hits, sl);
-                if (chits == 0) break;
-                if (opt.quirk_seq_drop && (ctax & 0x80000000u)) continue;
-                top_insert(L, lane, rcv, seg, M, ctax, chits, 0);
+                const u32 m = wave_max_u32(fk);
+                if (m == 0) break;
+                const u32 src = (u32)__builtin_ctzll(__ballot(fk == m));
+                const u32 wtax = bcast(Ltax, src);
+                if (lane == rcv * seg + i) { Ntax = wtax; Nhv = (HT)(m >> 8) << JB; }
+                if (Ltax == wtax) fk = 0;
             }
+            if (lslot && (rl == rcv || rl == snd)) { Ltax = Ntax; Lhv = Nhv; }
         }
     }
 
     // list 0 is the result
-    u32 n = (u32)__builtin_popcountll(__ballot(lane < M && L.hits > 0));
+    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lhv != 0));
     if (lane < n) {
         u32 beg = 0, end = 0;
-        if (P == 1) best_range<KeyT, HT, JB>(buf, H[L.j0], numWindows, wb, beg, end);
-        uint4 v; v.x = L.tax; v.y = L.hits; v.z = beg; v.w = end;
+        if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, wb, beg, end);
+        uint4 v; v.x = Ltax; v.y = (u32)(Lhv >> JB); v.z = beg; v.w = end;
         reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
     }
     if (lane == 0) out.ncand[q] = n;

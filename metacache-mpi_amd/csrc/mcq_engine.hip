@@ -205,7 +205,7 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 }
 
 template <class KeyT, int LCAP>
-__global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
+__global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? 8 : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                     CountersDev* ctr, u32* ovf_list, int force_block) {
     static_assert(LCAP == 512, "wave path: 8 keys per lane at most, entry index packed into 9 bits");
     __shared__ KeyT s_buf[4][LCAP];
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_query_wave(DbDev db, BatchDev b, OptDev
         wave_sync();
         if (stop == 3 || stop == 4) { if (buf[lane] == (KeyT)0x1234) out.ncand[q] = 1; continue; }
         const u32 numWindows = range_width(l1 + l2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        sweep_targets<KeyT, u32, 9>(buf, hits, T, numWindows, db.wb, lane, 64u, [] { wave_sync(); });
+        sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
         if (stop == 5) { if (hits[lane] == 0x12345u) out.ncand[q] = 1; continue; }
         st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         else               load_sort_store<8>(buf, locs + b0, T, lane);
         wave_sync();
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        sweep_targets<u64, u32, 9>(buf, hits, T, numWindows, 32u, lane, 64u, [] { wave_sync(); });
+        sweep_targets_wave<u64>(buf, hits, T, numWindows, 32u, lane);
         st_cand += topk_fold_write<u64, u32, 9>(db, opt, out, buf, hits, T, numWindows, 32u, q, lane);
         wave_sync();
     }

@@ -421,6 +421,16 @@ u32 orc_tree_fold(u32 P, u32 max_cand, const u32* lists, const u32* n, u32 quirk
     return (u32)L[0].size();
 }
 
+// Row 10 in isolation: insert a sequence of (tax,hits) candidates into an empty bounded
+// list with the reference's insert(); returns the list as (tax, hits, index of the inserted
+// candidate) triples.  Used to check the engine's order-free formulation of the same list.
+u32 orc_insert_sequence(u32 n, const u32* tax, const u32* hits, u32 max_cand, u32* out) {
+    std::vector<Cand> top;
+    for (u32 i = 0; i < n; ++i) top_insert(top, Cand{tax[i], hits[i], i, 0}, max_cand);
+    for (size_t i = 0; i < top.size(); ++i) { out[3 * i] = top[i].tax; out[3 * i + 1] = top[i].hits; out[3 * i + 2] = top[i].beg; }
+    return (u32)top.size();
+}
+
 // ---- row 12: src/classification.cpp:235-265 (classify) + ranked_lca ----------
 // cands: n x (tax_key,hits); lineage: n_taxa x 21 taxon indices (0xFFFFFFFF = null)
 // indexed by (key & 0x7FFFFFFF), rank index as in src/taxonomy.h:62-85; rank_of[idx].

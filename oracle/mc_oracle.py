@@ -50,6 +50,8 @@ def lib():
                                              C.c_uint64, u32p, C.c_uint64]
         L.orc_tree_fold.restype = C.c_uint32
         L.orc_tree_fold.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, C.c_uint32, u32p]
+        L.orc_insert_sequence.restype = C.c_uint32
+        L.orc_insert_sequence.argtypes = [C.c_uint32, u32p, u32p, C.c_uint32, u32p]
         L.orc_classify.restype = C.c_uint32
         L.orc_classify.argtypes = [u32p, C.c_uint32, u32p, C.POINTER(C.c_uint8), C.c_uint32, C.c_float, C.c_uint32]
         _lib = L
@@ -154,6 +156,14 @@ def tree_fold(lists, max_cand, quirk_seq_drop=0):
     out = np.zeros((max_cand, 2), np.uint32)
     m = lib().orc_tree_fold(P, max_cand, _p(arr, u32p), _p(n, u32p), quirk_seq_drop, _p(out, u32p))
     return [tuple(int(x) for x in out[i]) for i in range(m)]
+
+
+def insert_sequence(tax, hits, max_cand):
+    """reference insert() applied to a candidate sequence; returns [(tax, hits, source index)]."""
+    tax = np.ascontiguousarray(tax, np.uint32); hits = np.ascontiguousarray(hits, np.uint32)
+    out = np.zeros((max_cand, 3), np.uint32)
+    n = lib().orc_insert_sequence(len(tax), _p(tax, u32p), _p(hits, u32p), max_cand, _p(out, u32p))
+    return [tuple(int(x) for x in out[i]) for i in range(n)]
 
 
 def classify(cands, lineage, rank_of, hits_min, hits_diff_fraction, highest_rank):
