@@ -174,24 +174,51 @@ __device__ __forceinline__ u32 bcast(u32 v, u32 src_lane) {       // src_lane wa
 }
 
 // ------------------------------------------------------------------ rows 2-5: one window, one wave
-// value of lane (l ^ J), J a power of two < 64, without touching LDS memory
+// value of lane (l ^ J), J a power of two < 64: VALU only (DPP / permlane swaps), no LDS pipe
 template <int J>
-__device__ __forceinline__ u32 xor_lane(u32 v) {
+__device__ __forceinline__ u32 xor_lane(u32 v, u32 lane) {
     if constexpr (J == 1) return dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
     else if constexpr (J == 2) return dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
-    else if constexpr (J == 4) return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);   // bitmode xor 4
+    else if constexpr (J == 4) {                                          // banks 0,2 <- lane+4, banks 1,3 <- lane-4
+        u32 t = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);   // row_shl:4
+        return (u32)__builtin_amdgcn_update_dpp((int)t, (int)v, 0x114, 0xF, 0xA, false);    // row_shr:4
+    }
     else if constexpr (J == 8) return dpp_mov<0x128>(v);                 // row_ror:8
-    else if constexpr (J == 16) return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);  // bitmode xor 16
-    else return (u32)__shfl_xor((int)v, 32, 64);
+    else if constexpr (J == 16) { auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? a[0] : a[1]; }
+    else { auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? a[0] : a[1]; }
+}
+
+// lanes that keep the minimum in a compare-exchange at distance J of a bitonic level K
+// (K >= 64: every lane sorts ascending unless `up` says otherwise)
+constexpr u64 keepmin_mask(int K, int J, bool up_const) {
+    u64 m = 0;
+    for (int l = 0; l < 64; ++l) {
+        bool up = (K >= 64) ? up_const : ((l & K) == 0);
+        bool lower = (l & J) == 0;
+        if (lower == up) m |= 1ull << l;
+    }
+    return m;
+}
+// compare-exchange result for this lane: keepmin lanes take min(v,o), the others max(v,o).
+// One v_cmp, one s_xor with a constant lane mask, one v_cndmask.  All lanes must be active.
+__device__ __forceinline__ u32 cmpex(u32 v, u32 o, u64 keepmin) {
+    u64 take = __ballot(v < o) ^ keepmin;              // take the partner's value
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(o), "s"(take));
+    return r;
+}
+__device__ __forceinline__ u64 cmpex(u64 v, u64 o, u64 keepmin) {
+    u64 take = __ballot(v < o) ^ keepmin;
+    u32 lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((u32)v), "v"((u32)o), "s"(take));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((u32)(v >> 32)), "v"((u32)(o >> 32)), "s"(take));
+    return ((u64)hi << 32) | lo;
 }
 
 template <int K, int J>
 __device__ __forceinline__ u32 bitonic_step(u32 v, u32 lane) {
-    u32 o = xor_lane<J>(v);
-    bool up = (K >= 64) || ((lane & K) == 0);
-    bool lower = (lane & J) == 0;
-    u32 mn = v < o ? v : o, mx = v < o ? o : v;
-    return (lower == up) ? mn : mx;
+    constexpr u64 KM = keepmin_mask(K, J, true);
+    return cmpex(v, xor_lane<J>(v, lane), KM);
 }
 
 // ascending sort of one u32 per lane across the wave (21 compare-exchange stages)
@@ -236,9 +263,9 @@ __device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, 
     u32 a1 = !(u1 == 'A' || u1 == 'C' || u1 == 'G' || u1 == 'T');
 
     u32 w = ((x0 << 2) | x1) << (28 - 4 * (lane & 7));
-    w |= xor_lane<1>(w); w |= xor_lane<2>(w); w |= xor_lane<4>(w);
+    w |= xor_lane<1>(w, lane); w |= xor_lane<2>(w, lane); w |= xor_lane<4>(w, lane);
     u32 am = ((a0 << 1) | a1) << (30 - 2 * (lane & 15));
-    am |= xor_lane<1>(am); am |= xor_lane<2>(am); am |= xor_lane<4>(am); am |= xor_lane<8>(am);
+    am |= xor_lane<1>(am, lane); am |= xor_lane<2>(am, lane); am |= xor_lane<4>(am, lane); am |= xor_lane<8>(am, lane);
 
     u32 h[2];
 #pragma unroll
@@ -336,22 +363,11 @@ __device__ __forceinline__ void bitonic_sort(KeyT* buf, u32 n, u32 tid, u32 G, S
 // Bitonic network over n = 64*E keys held as r[e] = element e*64 + lane.  Exchanges at
 // distance j < 64 cross lanes (DPP / swizzle / permlane32_swap, no LDS memory); distance
 // j >= 64 pairs two registers of the same lane.  Fully unrolled: every index is static.
-__device__ __forceinline__ u64 xor_lane64_32(u64 v, u32 lane) {      // value of lane ^ 32
-    u32 lo = (u32)v, hi = (u32)(v >> 32);
-    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    u32 olo = (lane & 32) ? a[0] : a[1], ohi = (lane & 32) ? b[0] : b[1];
-    return ((u64)ohi << 32) | olo;
-}
 template <int J>
-__device__ __forceinline__ u32 xlane(u32 v, u32 lane) {
-    if constexpr (J == 32) { auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? a[0] : a[1]; }
-    else return xor_lane<J>(v);
-}
+__device__ __forceinline__ u32 xlane(u32 v, u32 lane) { return xor_lane<J>(v, lane); }
 template <int J>
 __device__ __forceinline__ u64 xlane(u64 v, u32 lane) {
-    if constexpr (J == 32) return xor_lane64_32(v, lane);
-    else return ((u64)xor_lane<J>((u32)(v >> 32)) << 32) | xor_lane<J>((u32)v);
+    return ((u64)xor_lane<J>((u32)(v >> 32), lane) << 32) | xor_lane<J>((u32)v, lane);
 }
 
 template <class KeyT, int E, int K, int J>
@@ -370,11 +386,10 @@ __device__ __forceinline__ void regsort_stage(KeyT (&r)[E], u32 lane) {
     } else {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            KeyT o = xlane<J>(r[e], lane);
-            const bool up = (K >= 64) ? (((e * 64) & K) == 0) : ((lane & K) == 0);   // bit 6+ of the index lives in e
-            const bool lower = (lane & J) == 0;
-            KeyT mn = r[e] < o ? r[e] : o, mx = r[e] < o ? o : r[e];
-            r[e] = (lower == up) ? mn : mx;
+            // bit 6+ of the element index lives in e, so for K >= 64 the direction is static
+            const u64 km = (K >= 64) ? ((((e * 64) & K) == 0) ? keepmin_mask(64, J, true) : keepmin_mask(64, J, false))
+                                     : keepmin_mask(K, J, true);
+            r[e] = cmpex(r[e], xlane<J>(r[e], lane), km);
         }
     }
 }
