@@ -169,6 +169,19 @@ int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, const uint64_t*
                uint64_t* locs /* sorted in place per query */, const uint32_t* query_len /* [n_queries] sum of mate lengths */,
                const mcq_query_opts* opt, mcq_result* out, void* stream);
 
+/* Routing helpers of the sharded path (device pointers).
+ * mcq_bucket_features: groups the non-empty features by owning shard.  counts is a device
+ *   array of 2*n_shards u64 (the first n_shards receive the per-shard counts, the rest is
+ *   scratch); bucketed/src_index receive, shard after shard, the features and the slot
+ *   (index into `features`) each came from.
+ * mcq_scatter_lists: list i (src_locs[src_off[i] .. src_off[i+1])) is copied to
+ *   dst_locs[dst_off[dst_slot[i]] ...): puts the lists that came back from the owners
+ *   into per-query order for mcq_reduce.                                              */
+int mcq_bucket_features(const uint32_t* features, uint64_t n, uint32_t n_shards,
+                        uint64_t* counts, uint32_t* bucketed, uint32_t* src_index, void* stream);
+int mcq_scatter_lists(uint64_t n_lists, const uint64_t* src_off, const uint32_t* dst_slot, const uint64_t* dst_off,
+                      const uint64_t* src_locs, uint64_t* dst_locs, void* stream);
+
 /* shard that owns a feature: a range of h2(f) = thomas_mueller_hash(f)
  * (src/hash_int.h:39-45), never of f itself                          */
 uint32_t mcq_owner(uint32_t feature, uint32_t n_shards);

@@ -539,6 +539,79 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
     }
 }
 
+// ------------------------------------------------------------------ sharded-path routing kernels
+// Bucket features by owning shard (mcq_owner).  EMPTY features are dropped.  Pass 1 counts
+// per shard (one atomic per shard per wave), pass 2 places each feature at
+// base[owner] + (wave-aggregated cursor) and records its source slot.
+__global__ __launch_bounds__(256) void k_bucket_count(const u32* features, u64 n, u32 n_shards, unsigned long long* counts) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const u64 i = i0 + lane;
+        const u32 f = i < n ? features[i] : MCQ_EMPTY;
+        const u32 own = f == MCQ_EMPTY ? 0xFFFFFFFFu : (u32)(((u64)tmh(f) * n_shards) >> 32);
+        for (u32 o = 0; o < n_shards; ++o) {
+            u32 c = (u32)__builtin_popcountll(__ballot(own == o));
+            if (lane == 0 && c) atomicAdd(&counts[o], (unsigned long long)c);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_bucket_fill(const u32* features, u64 n, u32 n_shards, const unsigned long long* counts,
+                                                     unsigned long long* cursor, u32* bucketed, u32* src_index) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 below = (1ull << lane) - 1;
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const u64 i = i0 + lane;
+        const u32 f = i < n ? features[i] : MCQ_EMPTY;
+        const u32 own = f == MCQ_EMPTY ? 0xFFFFFFFFu : (u32)(((u64)tmh(f) * n_shards) >> 32);
+        u64 base = 0;
+        for (u32 o = 0; o < n_shards; ++o) {
+            const u64 m = __ballot(own == o);
+            const u32 c = (u32)__builtin_popcountll(m);
+            unsigned long long start = 0;
+            if (lane == 0 && c) start = atomicAdd(&cursor[o], (unsigned long long)c);
+            start = ((unsigned long long)__builtin_amdgcn_readfirstlane((u32)(start >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)start);
+            if (own == o) {
+                const u64 d = base + start + (u32)__builtin_popcountll(m & below);
+                bucketed[d] = f; src_index[d] = (u32)i;
+            }
+            base += counts[o];
+        }
+    }
+}
+
+// list i = src_locs[src_off[i] .. src_off[i+1]) goes to dst_locs[dst_off[dst_slot[i]] ..); one wave per 64 lists
+__global__ __launch_bounds__(256) void k_scatter_lists(u64 n_lists, const u64* src_off, const u32* dst_slot, const u64* dst_off,
+                                                       const u64* src_locs, u64* dst_locs) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 ngroups = (n_lists + 63) / 64, nwaves = (u64)gridDim.x * 4;
+    for (u64 g = (u64)blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
+        const u64 i = g * 64 + lane;
+        u64 so = 0, d = 0; u32 len = 0;
+        if (i < n_lists) { so = src_off[i]; len = (u32)(src_off[i + 1] - so); d = dst_off[dst_slot[i]]; }
+        const u64 sbase = src_off[g * 64];
+        u32 incl = wave_incl_scan(len, lane);
+        u32 pos = incl - len;
+        const u32 T = bcast(incl, 63);
+        for (u32 base = 0; base < T; base += 64) {
+            const u32 t = base + lane;
+            const u32 tt = t < T ? t : T - 1;
+            u32 lo = 0;
+#pragma unroll
+            for (u32 step = 32; step > 0; step >>= 1) {
+                u32 c = lo + step;
+                u32 pc = __shfl(pos, (int)(c & 63), 64);
+                if (c < 64 && pc <= tt) lo = c;
+            }
+            u32 pj = __shfl(pos, (int)lo, 64);
+            u32 dlo = __shfl((u32)d, (int)lo, 64), dhi = __shfl((u32)(d >> 32), (int)lo, 64);
+            if (t < T) dst_locs[(((u64)dhi << 32) | dlo) + (tt - pj)] = src_locs[sbase + t];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ host helpers
 static u64 pow2ceil64(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 
@@ -974,5 +1047,33 @@ extern "C" int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_laun
     int rc = drain_events(ws); if (rc) return rc;
     if (total_ms) *total_ms = ws->timed_ms;
     if (n_launches) *n_launches = ws->timed_launches;
+    return MCQ_OK;
+}
+
+// ------------------------------------------------------------------ sharded-path routing entry points
+extern "C" int mcq_bucket_features(const uint32_t* features, uint64_t n, uint32_t n_shards,
+                                   uint64_t* counts, uint32_t* bucketed, uint32_t* src_index, void* stream) {
+    if (!counts || (n && (!features || !bucketed || !src_index))) return fail(MCQ_E_ARG, "null argument");
+    if (n_shards < 1 || n_shards > 64) return fail(MCQ_E_ARG, "n_shards must be 1..64");
+    if (n >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "more than 2^32 feature slots in one batch");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(counts, 0, 2ull * n_shards * 8, st));          // [counts | cursors]
+    if (n == 0) return MCQ_OK;
+    u32 grid = (u32)std::min<u64>((n + 255) / 256, 256ull * 16);
+    hipLaunchKernelGGL(k_bucket_count, dim3(grid), dim3(256), 0, st, features, n, n_shards, (unsigned long long*)counts);
+    hipLaunchKernelGGL(k_bucket_fill, dim3(grid), dim3(256), 0, st, features, n, n_shards, (const unsigned long long*)counts,
+                       (unsigned long long*)counts + n_shards, bucketed, src_index);
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+extern "C" int mcq_scatter_lists(uint64_t n_lists, const uint64_t* src_off, const uint32_t* dst_slot, const uint64_t* dst_off,
+                                 const uint64_t* src_locs, uint64_t* dst_locs, void* stream) {
+    if (n_lists == 0) return MCQ_OK;
+    if (!src_off || !dst_slot || !dst_off) return fail(MCQ_E_ARG, "null argument");
+    u64 groups = (n_lists + 63) / 64;
+    u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
+    hipLaunchKernelGGL(k_scatter_lists, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_lists, src_off, dst_slot, dst_off, src_locs, dst_locs);
+    HIPCHK(hipGetLastError());
     return MCQ_OK;
 }

@@ -81,6 +81,8 @@ def lib():
         L.mcq_sketch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_lookup_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.mcq_lookup_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_bucket_features.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_scatter_lists.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         _lib = L
@@ -226,6 +228,14 @@ class Workspace:
         m = np.zeros(max(1, int(moff[nq])), np.uint64)
         _chk(lib().mcq_debug_matches(self.db.h, self.h, C.byref(b), _np_ptr(moff), _np_ptr(m), len(m)))
         return moff, m[:int(moff[nq])]
+
+
+def bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream=None):
+    _chk(lib().mcq_bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream))
+
+
+def scatter_lists(n_lists, src_off_ptr, dst_slot_ptr, dst_off_ptr, src_locs_ptr, dst_locs_ptr, stream=None):
+    _chk(lib().mcq_scatter_lists(n_lists, src_off_ptr, dst_slot_ptr, dst_off_ptr, src_locs_ptr, dst_locs_ptr, stream))
 
 
 def owner(feature, n_shards):

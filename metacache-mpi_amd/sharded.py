@@ -1,0 +1,162 @@
+"""Feature-sharded multi-GPU query path over torch.distributed.
+
+One process per GPU.  The feature -> locations table is partitioned by hash range of
+h2(feature) (engine.owner); reads are split across ranks.  Per batch, every rank
+
+  1. sketches its own reads                      (mcq_count_windows + mcq_sketch)
+  2. buckets the features by owning shard        (mcq_bucket_features)
+  3. all-to-all: counts, then features           -> owners
+  4. owner looks the features up in its shard    (mcq_lookup_count + mcq_lookup_gather)
+  5. all-to-all: list lengths, then locations    -> home ranks
+  6. puts the lists into per-query order         (mcq_scatter_lists)
+  7. sorts / sweeps / folds per query            (mcq_reduce)
+
+All locations of a read reach its home rank, so per-target hit counts equal the
+reference's (which computes them on the single MPI rank owning the target,
+src/sketch_database.h:540); the only cross-shard semantic left, the reference's tree-merge
+order (src/querying.h:867-1073), is emulated inside mcq_reduce with virtual rank = tgt % P.
+
+The collective layer is torch.distributed (backend "nccl" = RCCL over xGMI on the GPU
+node).  The stage functions come from a backend object: HipBackend below is the product;
+the CPU gloo test of the routing logic injects its own (tests/test_sharded_gloo.py).
+"""
+import torch
+import torch.distributed as dist
+
+from . import engine
+
+EMPTY = -1          # 0xFFFFFFFF as int32
+
+
+class HipBackend:
+    """Stage functions on CUDA tensors through the C ABI (no CPU fallback)."""
+
+    def __init__(self, db, dev, max_queries, max_locs_per_query=0):
+        self.db, self.dev = db, dev
+        self.s = db.sketch_size
+        self.ws = engine.Workspace(db, max_queries, 1, max_locs_per_query)
+
+    def _st(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def sketch(self, bases, seq_off, n_seqs, n_win_hint=None):
+        win_off = torch.empty(n_seqs + 1, dtype=torch.int64, device=self.dev)
+        self.db.count_windows(bases.data_ptr(), seq_off.data_ptr(), n_seqs, win_off.data_ptr(), self._st())
+        n_win = int(win_off[-1].item()) if n_win_hint is None else n_win_hint
+        feats = torch.empty((max(n_win, 1), self.s), dtype=torch.int32, device=self.dev)
+        nfeat = torch.empty(max(n_win, 1), dtype=torch.int32, device=self.dev)
+        self.db.sketch(bases.data_ptr(), seq_off.data_ptr(), n_seqs, win_off.data_ptr(), feats.data_ptr(),
+                       nfeat.data_ptr(), self._st())
+        return win_off, feats[:n_win]
+
+    def bucket(self, feats_flat, n_shards):
+        n = feats_flat.numel()
+        counts = torch.empty(2 * n_shards, dtype=torch.int64, device=self.dev)
+        bucketed = torch.empty(max(n, 1), dtype=torch.int32, device=self.dev)
+        src = torch.empty(max(n, 1), dtype=torch.int32, device=self.dev)
+        engine.bucket_features(feats_flat.data_ptr(), n, n_shards, counts.data_ptr(), bucketed.data_ptr(), src.data_ptr(), self._st())
+        c = counts[:n_shards].cpu().tolist()
+        m = sum(c)
+        return c, bucketed[:m], src[:m]
+
+    def lookup(self, feats):
+        n = feats.numel()
+        lens = torch.zeros(max(n, 1), dtype=torch.int32, device=self.dev)
+        self.db.lookup_count(feats.data_ptr(), n, lens.data_ptr(), self._st())
+        off = torch.zeros(n + 1, dtype=torch.int64, device=self.dev)
+        torch.cumsum(lens[:n].to(torch.int64), 0, out=off[1:])
+        return lens[:n], off
+
+    def gather(self, feats, off, total):
+        locs = torch.empty(max(total, 1), dtype=torch.int64, device=self.dev)
+        self.db.lookup_gather(feats.data_ptr(), feats.numel(), off.data_ptr(), locs.data_ptr(), self._st())
+        return locs[:total]
+
+    def scatter(self, n_lists, src_off, dst_slot, dst_off, src_locs, total):
+        dst = torch.empty(max(total, 1), dtype=torch.int64, device=self.dev)
+        engine.scatter_lists(n_lists, src_off.data_ptr(), dst_slot.data_ptr(), dst_off.data_ptr(), src_locs.data_ptr(),
+                             dst.data_ptr(), self._st())
+        return dst
+
+    def reduce(self, nq, loc_off, locs, query_len, cands, ncand, max_cand, emulate_ranks, insert_size_max, flags):
+        self.ws.reduce_device(nq, loc_off.data_ptr(), locs.data_ptr(), query_len.data_ptr(), cands.data_ptr(),
+                              ncand.data_ptr(), max_cand=max_cand, emulate_ranks=emulate_ranks,
+                              insert_size_max=insert_size_max, flags=flags, stream=self._st())
+
+    def stats(self):
+        return self.ws.sync(self._st())
+
+
+def _a2a(out_numel, inp, send_counts, recv_counts, group):
+    """all_to_all_single with explicit split sizes.  On the GPU node the backend is nccl (RCCL)
+    and the tensors stay in HBM; under gloo (tests on a box without a second GPU) device
+    tensors are staged through the host."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        out = torch.empty(out_numel, dtype=inp.dtype)
+        dist.all_to_all_single(out, inp.contiguous().cpu(), list(recv_counts), list(send_counts), group=group)
+        return out.to(inp.device)
+    out = torch.empty(out_numel, dtype=inp.dtype, device=inp.device)
+    dist.all_to_all_single(out, inp.contiguous(), list(recv_counts), list(send_counts), group=group)
+    return out
+
+
+class ShardedQuery:
+    def __init__(self, db, world, rank, dev, max_queries, max_bases=0, read_len_hint=None, backend=None, group=None):
+        self.world, self.rank, self.dev, self.group = world, rank, dev, group
+        self.be = backend if backend is not None else HipBackend(db, dev, max_queries)
+        self.s = self.be.s
+        self._last = {}
+
+    def query(self, bases, seq_off, n_seqs, paired, cands, ncand, max_cand=2, emulate_ranks=1, insert_size_max=0,
+              flags=0, n_win_hint=None):
+        N, be, s = self.world, self.be, self.s
+        nq = n_seqs // 2 if paired else n_seqs
+        # 1-2. sketch, bucket by owner
+        win_off, feats = be.sketch(bases, seq_off, n_seqs, n_win_hint)
+        F = feats.numel()
+        send_counts, bucketed, src_idx = be.bucket(feats.reshape(-1), N)
+        m = bucketed.numel()
+        # 3. counts, then features to their owners
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=bucketed.device)
+        rc = _a2a(N, sc, [1] * N, [1] * N, self.group)
+        recv_counts = rc.cpu().tolist()
+        R = sum(recv_counts)
+        recv_feats = _a2a(R, bucketed, send_counts, recv_counts, self.group)
+        # 4. owner lookup
+        lens_r, off_r = be.lookup(recv_feats)
+        # 5. lengths back, then locations back (split sizes = per-peer sums of lengths)
+        lens_back = _a2a(m, lens_r, recv_counts, send_counts, self.group)
+        src_off = torch.zeros(m + 1, dtype=torch.int64, device=bucketed.device)
+        torch.cumsum(lens_back.to(torch.int64), 0, out=src_off[1:])
+        rb = torch.tensor([0] + recv_counts, dtype=torch.int64).cumsum(0).to(off_r.device)
+        sb = torch.tensor([0] + send_counts, dtype=torch.int64).cumsum(0).to(off_r.device)
+        sizes = torch.cat([off_r[rb], src_off[sb]]).cpu()
+        send_loc = (sizes[1:N + 1] - sizes[:N]).tolist()
+        recv_loc = (sizes[N + 2:] - sizes[N + 1:-1]).tolist()
+        total_r, total_b = int(sizes[N]), int(sizes[-1])
+        locs_r = be.gather(recv_feats, off_r, total_r)
+        locs_back = _a2a(total_b, locs_r, send_loc, recv_loc, self.group)
+        # 6. per-query order: list of feature slot f goes to the exclusive prefix sum of slot lengths
+        lens_slot = torch.zeros(F + 1, dtype=torch.int64, device=bucketed.device)
+        lens_slot[src_idx.long()] = lens_back.to(torch.int64)
+        dst_off = torch.zeros(F + 1, dtype=torch.int64, device=bucketed.device)
+        torch.cumsum(lens_slot[:F], 0, out=dst_off[1:])
+        locs_q = be.scatter(m, src_off, src_idx, dst_off, locs_back, total_b)
+        qstep = 2 if paired else 1
+        first_slot = win_off[0:n_seqs + 1:qstep][:nq + 1] * s
+        loc_off = dst_off[first_slot].contiguous()
+        so = seq_off[0:n_seqs + 1:qstep][:nq + 1]
+        query_len = (so[1:] - so[:-1]).to(torch.int32).contiguous()
+        # 7. sort / sweep / top lists / fold on the home rank
+        be.reduce(nq, loc_off, locs_q, query_len, cands, ncand, max_cand, emulate_ranks, insert_size_max, flags)
+        self._last = {"n_features": m, "n_locations": total_b, "n_queries": nq,
+                      "n_features_served": R, "n_locations_served": total_r}
+
+    def last_stats(self):
+        st = dict(self._last)
+        if hasattr(self.be, "stats"):
+            st.update({k: v for k, v in self.be.stats().items() if k in ("n_cands", "n_overflow")})
+        st.setdefault("n_hit_features", 0)
+        st.setdefault("n_cands", 0)
+        st.setdefault("n_overflow", 0)
+        return st

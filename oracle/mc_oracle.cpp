@@ -409,6 +409,26 @@ u64 orc_query_target_cands(const void* dbp, const char* s1, u64 n1, const char* 
     return tc.size();
 }
 
+// Rows 8-11 from an (unsorted) location segment of one query: what the home GPU of the
+// sharded path computes after the lists came back from their owners.
+u32 orc_reduce_query(const void* dbp, const u64* locs, u64 n, u64 query_len, u32 max_cand, u32 emulate_ranks,
+                     u64 insert_size_max, u32 quirk_seq_drop, u32* out /* max_cand x 4 */) {
+    const Db& db = *(const Db*)dbp;
+    std::vector<u64> m(locs, locs + n);
+    std::sort(m.begin(), m.end());
+    std::vector<TgtCand> tc;
+    target_candidates(m, (u32)(2 + std::max<u64>(query_len, insert_size_max) / db.tgt_winstride), tc);
+    u32 P = emulate_ranks < 1 ? 1 : emulate_ranks;
+    std::vector<std::vector<Cand>> L(P);
+    for (const auto& c : tc) {
+        u32 tax = c.tgt < db.n_targets ? db.tgt2tax[c.tgt] : (0x80000000u | c.tgt);
+        top_insert(L[c.tgt % P], Cand{tax, c.hits, c.beg, c.end}, max_cand);
+    }
+    if (P > 1) tree_fold(L, max_cand, quirk_seq_drop != 0);
+    for (size_t i = 0; i < L[0].size(); ++i) { out[4*i] = L[0][i].tax; out[4*i+1] = L[0][i].hits; out[4*i+2] = L[0][i].beg; out[4*i+3] = L[0][i].end; }
+    return (u32)L[0].size();
+}
+
 // Fold P explicit per-rank candidate lists (row 11 in isolation).
 // lists: P x max_cand x (tax,hits); n[r] entries valid.  Result in out.
 u32 orc_tree_fold(u32 P, u32 max_cand, const u32* lists, const u32* n, u32 quirk_seq_drop, u32* out) {

@@ -48,6 +48,8 @@ def lib():
         L.orc_query_target_cands.restype = C.c_uint64
         L.orc_query_target_cands.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
                                              C.c_uint64, u32p, C.c_uint64]
+        L.orc_reduce_query.restype = C.c_uint32
+        L.orc_reduce_query.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, u32p]
         L.orc_tree_fold.restype = C.c_uint32
         L.orc_tree_fold.argtypes = [C.c_uint32, C.c_uint32, u32p, u32p, C.c_uint32, u32p]
         L.orc_insert_sequence.restype = C.c_uint32
@@ -120,6 +122,13 @@ class OracleDb:
         lib().orc_query(self.h, n_seq, bases, _p(off, u64p), 1 if paired else 0, max_cand, emulate_ranks,
                         insert_size_max, quirk_seq_drop, _p(cand, u32p), _p(ncand, u32p), _p(stats, u64p), threads)
         return (cand, ncand, stats) if want_stats else (cand, ncand)
+
+    def reduce_query(self, locs, query_len, max_cand=2, emulate_ranks=1, insert_size_max=0, quirk_seq_drop=0):
+        locs = np.ascontiguousarray(locs, np.uint64)
+        out = np.zeros((max_cand, 4), np.uint32)
+        n = lib().orc_reduce_query(self.h, _p(locs, u64p), len(locs), query_len, max_cand, emulate_ranks, insert_size_max,
+                                   quirk_seq_drop, _p(out, u32p))
+        return out, n
 
     def matches(self, s1, s2=b""):
         s1 = s1.encode() if isinstance(s1, str) else s1
