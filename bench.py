@@ -62,9 +62,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or a.mode == "sharded":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU")
@@ -80,7 +81,7 @@ def main():
     mode = a.mode
     if mode == "auto":
         mode = "single" if world == 1 else "sharded"
-    if world == 1:
+    if world == 1 and mode == "replicas":
         mode = "single"
 
     # ---- database: same seeded genomes on every rank; each rank keeps its hash-range shard
@@ -104,6 +105,7 @@ def main():
         batches.append(r)
     read_off = off
     sharded = None
+    n_win_per_batch = B * (1 if L <= 128 else ((L - 128) // 113 + 1 + (1 if ((L - 128) // 113 + 1) * 113 < L else 0)))
     if mode == "sharded":
         sh = importlib.import_module("metacache-mpi_amd.sharded")
         sharded = sh.ShardedQuery(db, world, rank, dev, max_queries=B, max_bases=B * L, read_len_hint=L)
@@ -117,7 +119,8 @@ def main():
     def step(i):
         r = batches[i % nb]
         if sharded is not None:
-            sharded.query(r, read_off, B, False, cands, ncand, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks)
+            sharded.query(r, read_off, B, False, cands, ncand, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks,
+                          n_win_hint=n_win_per_batch)
         else:
             ws.query_device(r.data_ptr(), read_off.data_ptr(), B, False, cands.data_ptr(), ncand.data_ptr(),
                             max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=(a.stop_stage & 15) << 12, stream=stream)
@@ -181,7 +184,7 @@ def main():
                                            cands, ncand, B, L)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.mode == "sharded":
         import torch.distributed as dist
         dist.destroy_process_group()
 

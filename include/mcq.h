@@ -171,9 +171,8 @@ int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, const uint64_t*
 
 /* Routing helpers of the sharded path (device pointers).
  * mcq_bucket_features: groups the non-empty features by owning shard.  counts is a device
- *   array of 2*n_shards u64 (the first n_shards receive the per-shard counts, the rest is
- *   scratch); bucketed/src_index receive, shard after shard, the features and the slot
- *   (index into `features`) each came from.
+ *   array of n_shards u64 receiving the per-shard counts; bucketed/src_index receive,
+ *   shard after shard, the features and the slot (index into `features`) each came from.
  * mcq_scatter_lists: list i (src_locs[src_off[i] .. src_off[i+1])) is copied to
  *   dst_locs[dst_off[dst_slot[i]] ...): puts the lists that came back from the owners
  *   into per-query order for mcq_reduce.                                              */

@@ -166,6 +166,38 @@ __global__ __launch_bounds__(1024) void k_scan_u64(const u64* in, u64* out, u64 
     if (tid == 0) out[n] = s_carry;
 }
 
+// exclusive scan of n u64 values in three launches: per-tile scan + tile sums, scan of the
+// tile sums (one workgroup), add.  out has n + 1 entries (out[n] = total).
+#define MCQ_SCAN_TILE 8192
+__global__ __launch_bounds__(1024) void k_scan_tiles(const u64* in, u64* out, u64 n, u64* tile_sums) {
+    __shared__ u64 s_w[16];
+    __shared__ u64 s_carry;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    const u64 t0 = (u64)blockIdx.x * MCQ_SCAN_TILE;
+    for (u64 base = t0; base < t0 + MCQ_SCAN_TILE; base += 1024) {
+        const u64 i = base + tid;
+        u64 v = (i < n) ? in[i] : 0, x = v;
+        for (int d = 1; d < 64; d <<= 1) { u64 t = __shfl_up(x, d, 64); if (lane >= (u32)d) x += t; }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        u64 woff = 0;
+        for (u32 w = 0; w < wave; ++w) woff += s_w[w];
+        const u64 carry = s_carry;
+        if (i < n) out[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) tile_sums[blockIdx.x] = s_carry;
+}
+__global__ void k_scan_add(u64* out, u64 n, const u64* tile_off) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += tile_off[i / MCQ_SCAN_TILE];
+    if (i == 0) out[n] = tile_off[(n + MCQ_SCAN_TILE - 1) / MCQ_SCAN_TILE];
+}
+
 // ------------------------------------------------------------------ kernel: wave per query
 __device__ __forceinline__ u32 pow2ceil(u32 x) { return x <= 1 ? 1u : 1u << (32 - __builtin_clz(x - 1)); }
 
@@ -429,6 +461,30 @@ __global__ __launch_bounds__(256) void k_sketch_windows(DbDev db, const char* ba
     }
 }
 
+// one wave per sequence, looping over its (few) windows: no search, window math in 32 bits
+__global__ __launch_bounds__(256) void k_sketch_seqs(DbDev db, const char* bases, const u64* seq_off, u64 n_seqs,
+                                                     const u64* win_off, u32* features, u32* n_feat) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u64 nwaves = (u64)gridDim.x * 4;
+    __shared__ u32 s_sk[4][128];
+    u32* sk = s_sk[wave];
+    for (u64 i = (u64)blockIdx.x * 4 + wave; i < n_seqs; i += nwaves) {
+        const u64 o0 = seq_off[i];
+        const u32 n = (u32)(seq_off[i + 1] - o0);
+        const u64 w0 = win_off[i];
+        const u32 nw = (u32)(win_off[i + 1] - w0);
+        for (u32 j = 0; j < nw; ++j) {
+            u32 beg, wl;
+            window_of32(n, db.winlen, db.winstride, db.magic_stride, j, beg, wl);
+            u32 m = wave_sketch(bases + o0 + beg, wl, db.k, db.s, lane, sk, sk + 64);
+            if (lane < db.s) features[(w0 + j) * db.s + lane] = (lane < m) ? sk[64 + lane] : MCQ_EMPTY;
+            if (lane == 0) n_feat[w0 + j] = m;
+            wave_sync();
+        }
+    }
+}
+
 __global__ void k_lookup_count(DbDev db, const u32* features, u64 n, u32* list_len) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -540,43 +596,83 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
 }
 
 // ------------------------------------------------------------------ sharded-path routing kernels
-// Bucket features by owning shard (mcq_owner).  EMPTY features are dropped.  Pass 1 counts
-// per shard (one atomic per shard per wave), pass 2 places each feature at
-// base[owner] + (wave-aggregated cursor) and records its source slot.
-__global__ __launch_bounds__(256) void k_bucket_count(const u32* features, u64 n, u32 n_shards, unsigned long long* counts) {
+// Bucket features by owning shard (mcq_owner); EMPTY features are dropped.  Counting sort
+// over workgroup tiles: (1) every workgroup counts its tile per shard, (2) one workgroup
+// turns the [shard][workgroup] counts into start offsets (shard-major), (3) every workgroup
+// places its features; waves of a workgroup claim their slice with an LDS atomic.
+#define MCQ_BUCKET_MAX_SHARDS 64
+__device__ __forceinline__ u32 owner_of(u32 f, u32 n_shards) {
+    return f == MCQ_EMPTY ? 0xFFFFFFFFu : (u32)(((u64)tmh(f) * n_shards) >> 32);
+}
+__global__ __launch_bounds__(256) void k_bucket_count(const u32* features, u64 n, u32 n_shards, u64 tile,
+                                                      unsigned long long* blk_counts /* [n_shards][gridDim.x] */) {
+    __shared__ u32 s_c[MCQ_BUCKET_MAX_SHARDS];
     const u32 lane = threadIdx.x & 63;
-    const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+    if (threadIdx.x < MCQ_BUCKET_MAX_SHARDS) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 t0 = (u64)blockIdx.x * tile, t1 = t0 + tile < n ? t0 + tile : n;
+    for (u64 i0 = t0 + (threadIdx.x & ~63u); i0 < t1; i0 += 256) {
         const u64 i = i0 + lane;
-        const u32 f = i < n ? features[i] : MCQ_EMPTY;
-        const u32 own = f == MCQ_EMPTY ? 0xFFFFFFFFu : (u32)(((u64)tmh(f) * n_shards) >> 32);
+        const u32 own = owner_of(i < t1 ? features[i] : MCQ_EMPTY, n_shards);
         for (u32 o = 0; o < n_shards; ++o) {
             u32 c = (u32)__builtin_popcountll(__ballot(own == o));
-            if (lane == 0 && c) atomicAdd(&counts[o], (unsigned long long)c);
+            if (lane == 0 && c) atomicAdd(&s_c[o], c);
         }
     }
+    __syncthreads();
+    if (threadIdx.x < n_shards) blk_counts[(u64)threadIdx.x * gridDim.x + blockIdx.x] = s_c[threadIdx.x];
 }
-__global__ __launch_bounds__(256) void k_bucket_fill(const u32* features, u64 n, u32 n_shards, const unsigned long long* counts,
-                                                     unsigned long long* cursor, u32* bucketed, u32* src_index) {
+// exclusive scan over the [shard][workgroup] matrix in shard-major order; totals per shard to counts[]
+__global__ __launch_bounds__(1024) void k_bucket_scan(unsigned long long* blk_counts, u32 n_shards, u32 n_blocks, unsigned long long* counts) {
+    __shared__ unsigned long long s_w[16];
+    __shared__ unsigned long long s_carry;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 n = (u64)n_shards * n_blocks;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < n; base += 1024) {
+        const u64 i = base + tid;
+        unsigned long long v = i < n ? blk_counts[i] : 0, x = v;
+        for (int d = 1; d < 64; d <<= 1) { unsigned long long t = __shfl_up(x, d, 64); if (lane >= (u32)d) x += t; }
+        if (lane == 63) s_w[wave] = x;
+        __syncthreads();
+        unsigned long long woff = 0;
+        for (u32 w = 0; w < wave; ++w) woff += s_w[w];
+        const unsigned long long carry = s_carry;
+        if (i < n) blk_counts[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+    // per-shard totals = difference of the shard's first offsets
+    if (tid < n_shards) {
+        unsigned long long b0 = blk_counts[(u64)tid * n_blocks];
+        unsigned long long b1 = (tid + 1 < n_shards) ? blk_counts[(u64)(tid + 1) * n_blocks] : s_carry;
+        counts[tid] = b1 - b0;
+    }
+}
+__global__ __launch_bounds__(256) void k_bucket_fill(const u32* features, u64 n, u32 n_shards, u64 tile,
+                                                     const unsigned long long* blk_off, u32* bucketed, u32* src_index) {
+    __shared__ unsigned long long s_cur[MCQ_BUCKET_MAX_SHARDS];
     const u32 lane = threadIdx.x & 63;
-    const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 below = (1ull << lane) - 1;
-    for (u64 i0 = (u64)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+    if (threadIdx.x < n_shards) s_cur[threadIdx.x] = blk_off[(u64)threadIdx.x * gridDim.x + blockIdx.x];
+    __syncthreads();
+    const u64 t0 = (u64)blockIdx.x * tile, t1 = t0 + tile < n ? t0 + tile : n;
+    for (u64 i0 = t0 + (threadIdx.x & ~63u); i0 < t1; i0 += 256) {
         const u64 i = i0 + lane;
-        const u32 f = i < n ? features[i] : MCQ_EMPTY;
-        const u32 own = f == MCQ_EMPTY ? 0xFFFFFFFFu : (u32)(((u64)tmh(f) * n_shards) >> 32);
-        u64 base = 0;
+        const u32 f = i < t1 ? features[i] : MCQ_EMPTY;
+        const u32 own = owner_of(f, n_shards);
         for (u32 o = 0; o < n_shards; ++o) {
             const u64 m = __ballot(own == o);
             const u32 c = (u32)__builtin_popcountll(m);
             unsigned long long start = 0;
-            if (lane == 0 && c) start = atomicAdd(&cursor[o], (unsigned long long)c);
+            if (lane == 0 && c) start = atomicAdd(&s_cur[o], (unsigned long long)c);
             start = ((unsigned long long)__builtin_amdgcn_readfirstlane((u32)(start >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)start);
             if (own == o) {
-                const u64 d = base + start + (u32)__builtin_popcountll(m & below);
+                const u64 d = start + (u32)__builtin_popcountll(m & below);
                 bucketed[d] = f; src_index[d] = (u32)i;
             }
-            base += counts[o];
         }
     }
 }
@@ -614,6 +710,20 @@ __global__ __launch_bounds__(256) void k_scatter_lists(u64 n_lists, const u64* s
 
 // ------------------------------------------------------------------ host helpers
 static u64 pow2ceil64(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
+
+static int device_exclusive_scan(const u64* in, u64* out, u64 n, hipStream_t st) {
+    const u64 ntiles = (n + MCQ_SCAN_TILE - 1) / MCQ_SCAN_TILE;
+    if (ntiles <= 1) { hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, in, out, n); return MCQ_OK; }
+    u64 *sums = nullptr, *offs = nullptr;
+    HIPCHK(hipMallocAsync((void**)&sums, ntiles * 8, st));
+    HIPCHK(hipMallocAsync((void**)&offs, (ntiles + 1) * 8, st));
+    hipLaunchKernelGGL(k_scan_tiles, dim3((u32)ntiles), dim3(1024), 0, st, in, out, n, sums);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, (const u64*)sums, offs, ntiles);
+    hipLaunchKernelGGL(k_scan_add, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, out, n, (const u64*)offs);
+    HIPCHK(hipFreeAsync(sums, st));
+    HIPCHK(hipFreeAsync(offs, st));
+    return MCQ_OK;
+}
 
 // Fold schedule of the reference's merge loop (src/querying.h:867-1073): senders = odd
 // ranks, receivers = even ranks, i-th sender -> i-th receiver; used senders retire, every
@@ -695,7 +805,7 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     HIPCHK(hipMalloc(&d_new, (nk + 1) * 8));
     const u32 TB = 256;
     if (nk) hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id, d_len);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, 0, d_len, d_new, nk);
+    { int rcs = device_exclusive_scan(d_len, d_new, nk, 0); if (rcs) return rcs; }
     u64 nl_local = 0;
     HIPCHK(hipMemcpy(&nl_local, d_new + nk, 8, hipMemcpyDeviceToHost));
     // number of owned non-empty keys (for the table size) -- count on host from lengths
@@ -955,7 +1065,7 @@ extern "C" int mcq_count_windows(const mcq_db* db, const mcq_batch* in, uint64_t
     u64* cnt = nullptr;
     HIPCHK(hipMallocAsync((void**)&cnt, std::max<u64>(1, n) * 8, st));
     if (n) hipLaunchKernelGGL(k_count_windows, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, in->seq_off, n, db->d.winlen, db->d.winstride, cnt);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, (const u64*)cnt, win_off, n);
+    { int rcs = device_exclusive_scan(cnt, win_off, n, st); if (rcs) return rcs; }
     HIPCHK(hipFreeAsync(cnt, st));
     HIPCHK(hipGetLastError());
     return MCQ_OK;
@@ -967,8 +1077,15 @@ extern "C" int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t*
     if (!(in->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "staged entry points take device pointers");
     HIPCHK(hipSetDevice(db->device));
     if (in->n_seqs == 0) return MCQ_OK;
-    hipLaunchKernelGGL(k_sketch_windows, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, db->d, in->bases, in->seq_off,
-                       in->n_seqs, win_off, features, n_feat);
+    // many short sequences (reads): one wave per sequence; few long ones (genomes): one wave per window
+    if (in->n_seqs >= 4096) {
+        u32 grid = (u32)std::min<u64>((in->n_seqs + 3) / 4, 256ull * 32);
+        hipLaunchKernelGGL(k_sketch_seqs, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, in->bases, in->seq_off,
+                           in->n_seqs, win_off, features, n_feat);
+    } else {
+        hipLaunchKernelGGL(k_sketch_windows, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, db->d, in->bases, in->seq_off,
+                           in->n_seqs, win_off, features, n_feat);
+    }
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }
@@ -1054,15 +1171,18 @@ extern "C" int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_laun
 extern "C" int mcq_bucket_features(const uint32_t* features, uint64_t n, uint32_t n_shards,
                                    uint64_t* counts, uint32_t* bucketed, uint32_t* src_index, void* stream) {
     if (!counts || (n && (!features || !bucketed || !src_index))) return fail(MCQ_E_ARG, "null argument");
-    if (n_shards < 1 || n_shards > 64) return fail(MCQ_E_ARG, "n_shards must be 1..64");
+    if (n_shards < 1 || n_shards > MCQ_BUCKET_MAX_SHARDS) return fail(MCQ_E_ARG, "n_shards must be 1..64");
     if (n >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "more than 2^32 feature slots in one batch");
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemsetAsync(counts, 0, 2ull * n_shards * 8, st));          // [counts | cursors]
-    if (n == 0) return MCQ_OK;
-    u32 grid = (u32)std::min<u64>((n + 255) / 256, 256ull * 16);
-    hipLaunchKernelGGL(k_bucket_count, dim3(grid), dim3(256), 0, st, features, n, n_shards, (unsigned long long*)counts);
-    hipLaunchKernelGGL(k_bucket_fill, dim3(grid), dim3(256), 0, st, features, n, n_shards, (const unsigned long long*)counts,
-                       (unsigned long long*)counts + n_shards, bucketed, src_index);
+    if (n == 0) { HIPCHK(hipMemsetAsync(counts, 0, (u64)n_shards * 8, st)); return MCQ_OK; }
+    const u32 grid = (u32)std::min<u64>((n + 4095) / 4096, 2048);
+    const u64 tile = ((n + grid - 1) / grid + 255) / 256 * 256;
+    unsigned long long* blk = nullptr;
+    HIPCHK(hipMallocAsync((void**)&blk, (u64)n_shards * grid * 8, st));
+    hipLaunchKernelGGL(k_bucket_count, dim3(grid), dim3(256), 0, st, features, n, n_shards, tile, blk);
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, blk, n_shards, grid, (unsigned long long*)counts);
+    hipLaunchKernelGGL(k_bucket_fill, dim3(grid), dim3(256), 0, st, features, n, n_shards, tile, (const unsigned long long*)blk, bucketed, src_index);
+    HIPCHK(hipFreeAsync(blk, st));
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }
