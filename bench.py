@@ -42,7 +42,13 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"])
     ap.add_argument("--small", action="store_true", help="tiny DB / few reads (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (a 1-GPU box has a 16-core share)")
+    ap.add_argument("--long-batch", type=int, default=1 << 14, help="reads per step for --workload long")
+    ap.add_argument("--long-mean", type=int, default=8000)
+    ap.add_argument("--workload", default="c2", choices=["c2", "paired", "long"],
+                    help="c2 = BASELINE configs[1] (150 bp single-end); paired = 2x150 bp pairs (configs[3] shape); "
+                         "long = ONT-like reads, mean 8 kb (configs[4] shape) -- the last two on the 1-GPU database")
     ap.add_argument("--stop-stage", type=int, default=0, help="profiling: stop the fused kernel after stage 1..5 (results invalid)")
     ap.add_argument("--distinct-batches", type=int, default=0, help="0 = one per step (capped by memory)")
     return ap.parse_args()
@@ -96,33 +102,47 @@ def main():
 
     # ---- reads (distinct batches, resident in HBM before the clock starts)
     L, B = a.read_len, a.batch
+    paired = a.workload == "paired"
+    if a.workload == "long":
+        B = min(B, a.long_batch)
     nb = a.distinct_batches or a.steps
     free = torch.cuda.mem_get_info(dev)[0]
-    nb = max(1, min(nb, int(free * 0.5) // (B * L * 3)))
-    batches = []
+    per_batch = (B * a.long_mean * 12) if a.workload == "long" else (B * L * 3)
+    nb = max(1, min(nb, int(free * 0.5) // per_batch))
+    batches, offsets = [], []
     for i in range(nb):
-        r, off, _ = synth.sample_reads(gen_bases, gen_off, B, L, 0.005, 0.001, seed=1000 + 7919 * rank + i)
-        batches.append(r)
-    read_off = off
+        sd = 1000 + 7919 * rank + i
+        if a.workload == "c2":
+            r, off, _ = synth.sample_reads(gen_bases, gen_off, B, L, 0.005, 0.001, seed=sd)
+        elif paired:
+            r, off, _ = synth.sample_pairs(gen_bases, gen_off, B // 2, L, 300, 500, 0.005, 0.001, seed=sd)
+        else:
+            r, off, _ = synth.sample_long_reads(gen_bases, gen_off, B, a.long_mean, 0.08, seed=sd)
+        batches.append(r); offsets.append(off)
+    read_off = offsets[0]
+    max_bases = max(int(o[-1].item()) for o in offsets)
+    nq = B // 2 if paired else B
     sharded = None
-    n_win_per_batch = B * (1 if L <= 128 else ((L - 128) // 113 + 1 + (1 if ((L - 128) // 113 + 1) * 113 < L else 0)))
+    n_win_per_batch = None
+    if a.workload != "long":
+        n_win_per_batch = B * (1 if L <= 128 else ((L - 128) // 113 + 1 + (1 if ((L - 128) // 113 + 1) * 113 < L else 0)))
     if mode == "sharded":
         sh = importlib.import_module("metacache-mpi_amd.sharded")
-        sharded = sh.ShardedQuery(db, world, rank, dev, max_queries=B, max_bases=B * L, read_len_hint=L)
-    ws = eng.Workspace(db, B, B * L)
-    cands = torch.zeros((B, a.max_cand, 4), dtype=torch.int32, device=dev)
-    ncand = torch.zeros(B, dtype=torch.int32, device=dev)
+        sharded = sh.ShardedQuery(db, world, rank, dev, max_queries=nq, max_bases=max_bases, read_len_hint=L)
+    ws = eng.Workspace(db, nq, max_bases)
+    cands = torch.zeros((nq, a.max_cand, 4), dtype=torch.int32, device=dev)
+    ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     torch.cuda.synchronize(dev)
     t_setup = time.time() - t_setup
 
     def step(i):
-        r = batches[i % nb]
+        r, ro = batches[i % nb], offsets[i % nb]
         if sharded is not None:
-            sharded.query(r, read_off, B, False, cands, ncand, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks,
+            sharded.query(r, ro, B, paired, cands, ncand, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks,
                           n_win_hint=n_win_per_batch)
         else:
-            ws.query_device(r.data_ptr(), read_off.data_ptr(), B, False, cands.data_ptr(), ncand.data_ptr(),
+            ws.query_device(r.data_ptr(), ro.data_ptr(), B, paired, cands.data_ptr(), ncand.data_ptr(),
                             max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=(a.stop_stage & 15) << 12, stream=stream)
 
     def barrier():
@@ -150,16 +170,20 @@ def main():
     kms, kn = ws.kernel_time()
     ws.timing(False)
 
-    total_reads = a.steps * B * world
+    total_reads = a.steps * B * world          # paired-end: each mate counts (src/printing.cpp:626-627)
     value = total_reads / elapsed
     out = {
         "metric": "query reads/sec (whole node)", "value": value, "unit": "reads/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {
-            "workload": "BASELINE configs[1]: %d synthetic genomes (%d species x %d strains, %.1f%% divergence, %.2f Gbp) in HBM, "
-                        "%d x %d bp single-end reads per step per GPU, k=16 s=16 w=128/113" %
-                        (n_targets, a.species, a.strains, 100 * a.divergence, db_bp / 1e9, B, L),
+            "workload": "%s: %d synthetic genomes (%d species x %d strains, %.1f%% divergence, %.2f Gbp) in HBM, %s per step per GPU, "
+                        "k=16 s=16 w=128/113" %
+                        ({"c2": "BASELINE configs[1]", "paired": "BASELINE configs[3] shape on the 1-GPU DB",
+                          "long": "BASELINE configs[4] shape on the 1-GPU DB"}[a.workload],
+                         n_targets, a.species, a.strains, 100 * a.divergence, db_bp / 1e9,
+                         {"c2": "%d x %d bp single-end reads" % (B, L), "paired": "%d reads = %d pairs of 2x%d bp" % (B, B // 2, L),
+                          "long": "%d ONT-like reads, mean %d bp, 8%% substitutions" % (B, a.long_mean)}[a.workload]),
             "reads_total": total_reads, "db_keys": n_keys, "db_locations": n_locs, "db_hbm_bytes": db.bytes(),
             "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "distinct_batches": nb,
             "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
@@ -168,20 +192,21 @@ def main():
         },
     }
     if sharded is None and kn > 0:
-        algo = algorithmic_bytes(B * L, st)
+        algo = algorithmic_bytes(max_bases, st)
         avg_ms = kms / kn
         ach = algo / (avg_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_query_wave", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel_note": "k_query_wave timed by HIP events on its stream (mcq_ws_timing); for --workload long the work is in k_query_block, timed by ms_per_step",
                            "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": avg_ms, "launches_timed": kn,
                            "bytes_per_read": algo / B,
                            "per_launch": {k: st[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow")}}
 
     if a.stop_stage:
         out["INVALID_profiling_stop_stage"] = a.stop_stage
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stop_stage:
-        out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches[(a.warmup + a.steps - 1) % nb], read_off,
-                                           cands, ncand, B, L)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stop_stage and mode == "single":
+        out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches, offsets, (a.warmup + a.steps - 1) % nb,
+                                           cands, ncand, B, paired)
     if rank == 0:
         print(json.dumps(out))
     if world > 1 or a.mode == "sharded":
@@ -189,33 +214,35 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(a, keys, list_off, locs, species, reads, read_off, cands, ncand, B, L):
+def cpu_baseline(a, keys, list_off, locs, species, batches, offsets, first, cands, ncand, B, paired):
     """The oracle (bit-exact CPU restatement of the reference path) timed on this box's
-    host cores, on a bounded sample of the same batch, checked against the GPU result."""
+    host cores on a bounded sample of the same workload (whole batches, starting with the
+    last timed one, until ~cpu_seconds), and checked against the GPU result of that batch."""
     from oracle import mc_oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(aff, a.cpu_threads))
     odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), list_off.cpu().numpy().astype(np.uint64),
                        locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
-    n0 = min(B, 20000)
-    rb = reads[: n0 * L].cpu().numpy().tobytes()
-    ro = read_off[: n0 + 1].cpu().numpy().astype(np.uint64)
-    t0 = time.perf_counter()
-    odb.query(rb, ro, False, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, threads=cores)
-    rate0 = n0 / (time.perf_counter() - t0)
-    n1 = int(max(n0, min(B, rate0 * a.cpu_seconds)))
-    rb = reads[: n1 * L].cpu().numpy().tobytes()
-    ro = read_off[: n1 + 1].cpu().numpy().astype(np.uint64)
-    t0 = time.perf_counter()
-    oc, on = odb.query(rb, ro, False, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, threads=cores)
-    dt = time.perf_counter() - t0
-    gc = cands[:n1].cpu().numpy().view(np.uint32); gn = ncand[:n1].cpu().numpy().view(np.uint32)
-    ok = bool(np.array_equal(gn, on))
-    if ok:
-        mask = np.arange(a.max_cand)[None, :] < on[:, None]
-        ok = bool(np.array_equal(gc[mask], oc[mask]))
-    return {"value": n1 / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the last timed batch, %d threads, DB build excluded" % (n1, cores),
-            "seconds": dt, "gpu_matches_cpu_on_sample": ok}
+    nq = B // 2 if paired else B
+    total_t, total_n, ok, nb = 0.0, 0, None, len(batches)
+    i = first
+    while total_t < a.cpu_seconds and total_n < 16 * B:
+        rb = batches[i % nb].cpu().numpy().tobytes()
+        ro = offsets[i % nb].cpu().numpy().astype(np.uint64)
+        t0 = time.perf_counter()
+        oc, on = odb.query(rb, ro, paired, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, threads=cores)
+        total_t += time.perf_counter() - t0
+        total_n += B
+        if ok is None:          # the GPU buffers still hold this batch's result
+            gc = cands[:nq].cpu().numpy().view(np.uint32); gn = ncand[:nq].cpu().numpy().view(np.uint32)
+            ok = bool(np.array_equal(gn, on))
+            if ok:
+                mask = np.arange(a.max_cand)[None, :] < on[:, None]
+                ok = bool(np.array_equal(gc[mask], oc[mask]))
+        i += 1
+    return {"value": total_n / total_t, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "%d reads (%d whole batches of the timed workload), %d threads, DB build excluded" % (total_n, total_n // B, cores),
+            "seconds": total_t, "gpu_matches_cpu_on_first_batch": ok}
 
 
 if __name__ == "__main__":

@@ -65,3 +65,60 @@ def sample_reads(bases, seq_off, n_reads, read_len, sub_rate, n_rate, seed, revc
         reads = torch.where(flip[:, None], rc, reads)
     off = torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * read_len
     return reads.reshape(-1).contiguous(), off, tgt
+
+
+def sample_pairs(bases, seq_off, n_pairs, read_len, ins_lo, ins_hi, sub_rate, n_rate, seed):
+    """Paired-end reads: fragment of length U[ins_lo, ins_hi]; mate 1 = its first read_len
+    bases, mate 2 = the first read_len bases of its reverse complement.  Sequences 2q, 2q+1
+    are the mates of pair q.  Returns (reads uint8, read_off int64 [2n+1], origin target)."""
+    dev = bases.device
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    lens = (seq_off[1:] - seq_off[:-1]).to(torch.float64)
+    w = torch.clamp(lens - ins_hi, min=0)
+    tgt = torch.multinomial(w / w.sum(), n_pairs, replacement=True, generator=g)
+    r = torch.rand(n_pairs, generator=g, device=dev, dtype=torch.float64)
+    pos = seq_off[tgt] + (r * w[tgt]).to(torch.int64)
+    ins = torch.randint(ins_lo, ins_hi + 1, (n_pairs,), generator=g, device=dev, dtype=torch.int64)
+    ar = torch.arange(read_len, device=dev, dtype=torch.int64)[None, :]
+    m1 = bases[pos[:, None] + ar]
+    m2 = _comp_table(dev)[bases[(pos + ins - 1)[:, None] - ar].long()]
+    reads = torch.stack([m1, m2], dim=1).reshape(2 * n_pairs, read_len)
+    if sub_rate > 0:
+        m = torch.rand(reads.shape, generator=g, device=dev) < sub_rate
+        code = ((reads >> 1) & 3); code = code ^ (code >> 1)
+        sh = torch.randint(1, 4, reads.shape, generator=g, device=dev, dtype=torch.uint8)
+        reads = torch.where(m, _ACGT.to(dev)[((code + sh) & 3).long()], reads)
+    if n_rate > 0:
+        m = torch.rand(reads.shape, generator=g, device=dev) < n_rate
+        reads = torch.where(m, torch.full_like(reads, 78), reads)
+    off = torch.arange(2 * n_pairs + 1, device=dev, dtype=torch.int64) * read_len
+    return reads.reshape(-1).contiguous(), off, tgt
+
+
+def sample_long_reads(bases, seq_off, n_reads, mean_len, sub_rate, seed, min_len=500, max_len=60000, sigma=0.6):
+    """ONT-like reads: lengths log-normal with the given mean (substitution errors only).
+    Returns (reads uint8, read_off int64 [n+1], origin target)."""
+    import math
+    dev = bases.device
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    mu = math.log(mean_len) - 0.5 * sigma * sigma
+    ln = torch.exp(mu + sigma * torch.randn(n_reads, generator=g, device=dev, dtype=torch.float64))
+    ln = torch.clamp(ln, min_len, max_len).to(torch.int64)
+    lens = (seq_off[1:] - seq_off[:-1])
+    w = torch.clamp(lens - max_len, min=0).to(torch.float64)
+    tgt = torch.multinomial(w / w.sum(), n_reads, replacement=True, generator=g)
+    r = torch.rand(n_reads, generator=g, device=dev, dtype=torch.float64)
+    pos = seq_off[tgt] + (r * (lens[tgt] - ln).to(torch.float64)).to(torch.int64)
+    off = torch.zeros(n_reads + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(ln, 0, out=off[1:])
+    total = int(off[-1].item())
+    rid = torch.repeat_interleave(torch.arange(n_reads, device=dev), ln)
+    idx = pos[rid] + (torch.arange(total, device=dev, dtype=torch.int64) - off[rid])
+    reads = bases[idx]
+    del idx, rid
+    if sub_rate > 0:
+        m = torch.rand(total, generator=g, device=dev) < sub_rate
+        code = ((reads >> 1) & 3); code = code ^ (code >> 1)
+        sh = torch.randint(1, 4, (total,), generator=g, device=dev, dtype=torch.uint8)
+        reads = torch.where(m, _ACGT.to(dev)[((code + sh) & 3).long()], reads)
+    return reads.contiguous(), off, tgt
