@@ -1,0 +1,79 @@
+/* mcq_host.h -- host-side companions of the query engine (C ABI, no GPU needed).
+ *
+ * Rows f1 and f3 of SURVEY.md section 8: reading the reference's database shard files
+ * and the final per-read classification.  Each entry point names the reference code it
+ * stands in for (paths relative to the reference root).
+ *
+ *   mcq_refdb_open      sketch_database::read            src/sketch_database.h:858-952
+ *                       hash_multimap::deserialize        src/hash_multimap.h:923-964
+ *                       taxon / taxonomy read_binary       src/taxonomy.h:312-335, :660-676
+ *   mcq_refdb_tgt2tax   db.ancestor(taxon_of_target, r)   src/sketch_database.h:146, :717-720
+ *                       as used by candidates insert()    src/candidates.h:242-245
+ *   mcq_refdb_classify  classify()                        src/classification.cpp:235-265
+ *                       ranked_lca()                      src/taxonomy.h:531-537
+ *   mcq_rank_from_name  taxonomy::rank_from_name          src/taxonomy.h:173-213
+ *
+ * A taxon *key* is the index of the taxon in the database's taxon list; bit 31 marks a
+ * sequence-level taxon (rank Sequence), 0xFFFFFFFF is "no taxon".  These are the keys
+ * mcq_db_desc.tgt2tax carries and mcq_cand.tax returns.
+ */
+#ifndef MCQ_HOST_H
+#define MCQ_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mcq_refdb mcq_refdb;
+
+typedef struct {
+    uint32_t k, sketch_size, winlen, winstride;        /* target sketching parameters      */
+    uint32_t q_sketch_size, q_winlen, q_winstride;      /* query sketching parameters       */
+    uint32_t max_locs_per_feature;
+    uint32_t n_ranks;                                    /* shard files read                 */
+    uint32_t n_targets, n_taxa;
+    uint64_t n_keys, n_locs;                             /* of the union table               */
+} mcq_refdb_info;
+
+#define MCQ_NO_TAXON 0xFFFFFFFFu
+#define MCQ_RANK_SEQUENCE 0u
+#define MCQ_RANK_SPECIES 4u
+#define MCQ_RANK_DOMAIN 19u
+#define MCQ_RANK_ROOT 20u
+#define MCQ_RANK_NONE 21u
+
+/* reads <prefix>.db_0 .. <prefix>.db_<n_ranks-1> and unions their tables */
+int mcq_refdb_open(const char* prefix, uint32_t n_ranks, mcq_refdb** out);
+int mcq_refdb_close(mcq_refdb* db);
+int mcq_refdb_get_info(const mcq_refdb* db, mcq_refdb_info* out);
+
+/* union table in the layout mcq_db_desc wants; valid until mcq_refdb_close */
+const uint32_t* mcq_refdb_keys(const mcq_refdb* db);
+const uint64_t* mcq_refdb_list_off(const mcq_refdb* db);
+const uint64_t* mcq_refdb_locs(const mcq_refdb* db);
+
+/* taxon key per target for candidate merging below `merge_below_rank` */
+int mcq_refdb_tgt2tax(const mcq_refdb* db, uint32_t merge_below_rank, uint32_t* out /* [n_targets] */);
+
+int64_t mcq_refdb_taxon_id(const mcq_refdb* db, uint32_t key);       /* 0 for MCQ_NO_TAXON        */
+uint32_t mcq_refdb_taxon_rank(const mcq_refdb* db, uint32_t key);
+const char* mcq_refdb_taxon_name(const mcq_refdb* db, uint32_t key);
+/* taxon index at `rank` in the ranked lineage of `key`, MCQ_NO_TAXON if none */
+uint32_t mcq_refdb_ancestor(const mcq_refdb* db, uint32_t key, uint32_t rank);
+
+/* cands: n x {tax key, hits, (2 ignored words)} as mcq_query returns them.
+ * hits_diff_fraction as the reference stores it (-hitdiff 80 -> 0.8f).
+ * Returns the taxon index of the classification or MCQ_NO_TAXON.                      */
+uint32_t mcq_refdb_classify(const mcq_refdb* db, const uint32_t* cands, uint32_t n,
+                            uint32_t hits_min, float hits_diff_fraction, uint32_t highest_rank);
+
+/* default of -hitmin when unset: src/mode_query.cpp:247-259 */
+uint32_t mcq_default_hits_min(uint32_t sketch_size);
+uint32_t mcq_rank_from_name(const char* name);
+const char* mcq_rank_name(uint32_t rank);
+const char* mcq_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

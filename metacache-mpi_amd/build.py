@@ -12,6 +12,37 @@ def lib_path():
     return os.path.join(_HERE, "libmcq_hip.so")
 
 
+def host_lib_path():
+    return os.path.join(_HERE, "libmcq_host.so")
+
+
+def cli_path():
+    return os.path.join(_HERE, "mcq_query_cli")
+
+
+def build_host(force=False, verbose=False):
+    """libmcq_host.so (shard reader, taxonomy keys, classify; g++, no GPU) and the
+    mcq_query_cli binary (links both libraries)."""
+    src = os.path.join(_HERE, "csrc", "host", "mcq_host.cpp")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "mcq_host.h")
+    out = host_lib_path()
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        cmd = ["g++", "-std=c++14", "-O2", "-Wall", "-shared", "-fPIC", src, "-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    cli_src = os.path.join(_HERE, "csrc", "host", "mcq_query_cli.cpp")
+    cli = cli_path()
+    if force or not os.path.exists(cli) or os.path.getmtime(cli) < max(os.path.getmtime(cli_src), os.path.getmtime(out),
+                                                                         os.path.getmtime(lib_path())):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc, "-std=c++14", "-O2", cli_src, "-o", cli, "-L" + _HERE, "-lmcq_hip", "-lmcq_host", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
 def build_hip(force=False, verbose=False):
     out = lib_path()
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _DEPS):

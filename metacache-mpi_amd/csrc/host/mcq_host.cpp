@@ -1,0 +1,205 @@
+// mcq_host.cpp -- host companions of the engine: reference shard reader, taxonomy keys,
+// classification (include/mcq_host.h).  Plain C++14, no GPU, no MPI.
+#include "../../../include/mcq_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(const std::string& m) { g_err = m; return -1; }
+
+const uint64_t kDbVersion = 20181001;      // MC_DB_VERSION
+const int kNumRanks = 21;                  // taxonomy::num_ranks; rank::root == 20, rank::none == 21
+
+struct Taxon { int64_t id, parent; uint8_t rank; std::string name; uint64_t windows; };
+
+struct Reader {
+    std::vector<unsigned char> buf; size_t pos = 0; bool ok = true;
+    template <class T> T get() {
+        T v{};
+        if (pos + sizeof(T) > buf.size()) { ok = false; return v; }
+        std::memcpy(&v, buf.data() + pos, sizeof(T)); pos += sizeof(T);
+        return v;
+    }
+    std::string str() {                     // u64 length + bytes (src/io_serialize.h:48-55)
+        uint64_t n = get<uint64_t>();
+        if (!ok || pos + n > buf.size()) { ok = false; return ""; }
+        std::string s((const char*)buf.data() + pos, n); pos += n;
+        return s;
+    }
+};
+
+}  // namespace
+
+struct mcq_refdb {
+    mcq_refdb_info info{};
+    std::vector<Taxon> taxa;
+    std::unordered_map<int64_t, uint32_t> by_id;
+    std::vector<uint32_t> lineage;          // n_taxa x 21, taxon indices or MCQ_NO_TAXON
+    std::vector<uint32_t> keys; std::vector<uint64_t> off, locs;
+};
+
+static bool read_file(const std::string& path, std::vector<unsigned char>& out) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::fseek(f, 0, SEEK_END); long n = std::ftell(f); std::fseek(f, 0, SEEK_SET);
+    out.resize((size_t)n);
+    bool ok = n == 0 || std::fread(out.data(), 1, (size_t)n, f) == (size_t)n;
+    std::fclose(f);
+    return ok;
+}
+
+extern "C" const char* mcq_host_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mcq_refdb_open(const char* prefix, uint32_t n_ranks, mcq_refdb** out) {
+    if (!prefix || !out || n_ranks < 1) return fail("bad argument");
+    mcq_refdb* db = new mcq_refdb();
+    // (key, location) pairs of all shards; the union list of a key is the multiset union of
+    // the per-rank lists, each target living on exactly one rank (src/sketch_database.h:540)
+    std::vector<std::pair<uint32_t, uint64_t>> all;
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        Reader rd;
+        const std::string path = std::string(prefix) + ".db_" + std::to_string(r);
+        if (!read_file(path, rd.buf)) { delete db; return fail("can't open file " + path); }
+        if (rd.get<uint64_t>() != kDbVersion) { delete db; return fail("Database " + path + " is incompatible (version)"); }
+        uint8_t w[6]; for (auto& x : w) x = rd.get<uint8_t>();
+        if (w[0] != 4 || w[1] != 4 || w[2] != 4 || w[3] != 1 || w[4] != 8 || w[5] != kNumRanks) {
+            delete db; return fail("Database " + path + " is incompatible due to different data type sizes");
+        }
+        uint64_t p[9]; for (auto& x : p) x = rd.get<uint64_t>();
+        const uint64_t ntaxa = rd.get<uint64_t>();
+        std::vector<Taxon> taxa; taxa.reserve(ntaxa);
+        for (uint64_t i = 0; i < ntaxa && rd.ok; ++i) {
+            Taxon t; t.id = rd.get<int64_t>(); t.parent = rd.get<int64_t>(); t.rank = rd.get<uint8_t>();
+            t.name = rd.str(); rd.str(); rd.get<uint64_t>(); t.windows = rd.get<uint64_t>();
+            taxa.push_back(std::move(t));
+        }
+        const uint32_t ntargets = rd.get<uint32_t>();
+        if (r == 0) {
+            db->info.k = (uint32_t)p[0]; db->info.sketch_size = (uint32_t)p[1]; db->info.winlen = (uint32_t)p[2];
+            db->info.winstride = (uint32_t)p[3]; db->info.q_sketch_size = (uint32_t)p[5]; db->info.q_winlen = (uint32_t)p[6];
+            db->info.q_winstride = (uint32_t)p[7]; db->info.max_locs_per_feature = (uint32_t)p[8];
+            db->info.n_targets = ntargets; db->info.n_taxa = (uint32_t)ntaxa; db->info.n_ranks = n_ranks;
+            db->taxa = std::move(taxa);
+        } else if (ntargets != db->info.n_targets || ntaxa != db->info.n_taxa) {
+            delete db; return fail("shard " + path + " does not belong to the same database");
+        }
+        if (ntargets >= 1) {
+            const uint64_t nkeys = rd.get<uint64_t>(); rd.get<uint64_t>();
+            for (uint64_t i = 0; i < nkeys && rd.ok; ++i) {
+                const uint32_t key = rd.get<uint32_t>(); const uint8_t n = rd.get<uint8_t>();
+                if (n == 0) continue;
+                const uint64_t n1 = rd.get<uint64_t>(); const size_t tpos = rd.pos; rd.pos += 4 * n1;
+                const uint64_t n2 = rd.get<uint64_t>(); const size_t wpos = rd.pos; rd.pos += 4 * n2;
+                if (n1 != n || n2 != n || rd.pos > rd.buf.size()) { rd.ok = false; break; }
+                for (uint32_t j = 0; j < n; ++j) {
+                    uint32_t t, wi; std::memcpy(&t, rd.buf.data() + tpos + 4 * j, 4); std::memcpy(&wi, rd.buf.data() + wpos + 4 * j, 4);
+                    all.emplace_back(key, ((uint64_t)t << 32) | wi);
+                }
+            }
+        }
+        if (!rd.ok) { delete db; return fail("Database " + path + " is truncated or corrupt"); }
+    }
+    std::sort(all.begin(), all.end());
+    db->off.push_back(0);
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (i == 0 || all[i].first != all[i - 1].first) { if (i) db->off.push_back(i); db->keys.push_back(all[i].first); }
+        db->locs.push_back(all[i].second);
+    }
+    if (!all.empty()) db->off.push_back(all.size());
+    db->info.n_keys = db->keys.size(); db->info.n_locs = db->locs.size();
+    // ranked lineages: walk the parents, record every ranked ancestor (incl. the taxon itself)
+    // at lineage[rank] (taxonomy::ranks, src/taxonomy.h:576-597)
+    for (uint32_t i = 0; i < db->taxa.size(); ++i) db->by_id[db->taxa[i].id] = i;
+    db->lineage.assign((size_t)db->taxa.size() * kNumRanks, MCQ_NO_TAXON);
+    for (uint32_t i = 0; i < db->taxa.size(); ++i) {
+        int64_t cur = db->taxa[i].id;
+        while (cur != 0) {
+            auto it = db->by_id.find(cur);
+            if (it == db->by_id.end()) break;
+            const Taxon& t = db->taxa[it->second];
+            if (t.rank < kNumRanks) db->lineage[(size_t)i * kNumRanks + t.rank] = it->second;
+            cur = (t.parent != cur) ? t.parent : 0;
+        }
+    }
+    *out = db;
+    return 0;
+}
+
+extern "C" int mcq_refdb_close(mcq_refdb* db) { delete db; return 0; }
+extern "C" int mcq_refdb_get_info(const mcq_refdb* db, mcq_refdb_info* out) { if (!db || !out) return fail("bad argument"); *out = db->info; return 0; }
+extern "C" const uint32_t* mcq_refdb_keys(const mcq_refdb* db) { return db->keys.data(); }
+extern "C" const uint64_t* mcq_refdb_list_off(const mcq_refdb* db) { return db->off.empty() ? nullptr : db->off.data(); }
+extern "C" const uint64_t* mcq_refdb_locs(const mcq_refdb* db) { return db->locs.data(); }
+
+extern "C" int mcq_refdb_tgt2tax(const mcq_refdb* db, uint32_t merge_below_rank, uint32_t* out) {
+    if (!db || !out) return fail("bad argument");
+    for (uint32_t t = 0; t < db->info.n_targets; ++t) {
+        auto it = db->by_id.find(-(int64_t)t - 1);              // taxon_id_of_target (src/sketch_database.h:149-150)
+        if (it == db->by_id.end()) return fail("target " + std::to_string(t) + " has no sequence-level taxon");
+        uint32_t a = (merge_below_rank > 0 && merge_below_rank < (uint32_t)kNumRanks)
+                         ? db->lineage[(size_t)it->second * kNumRanks + merge_below_rank] : MCQ_NO_TAXON;
+        out[t] = (a != MCQ_NO_TAXON) ? a : (0x80000000u | it->second);
+    }
+    return 0;
+}
+
+static inline bool valid_key(const mcq_refdb* db, uint32_t key) { return key != MCQ_NO_TAXON && (key & 0x7FFFFFFFu) < db->taxa.size(); }
+extern "C" int64_t mcq_refdb_taxon_id(const mcq_refdb* db, uint32_t key) { return valid_key(db, key) ? db->taxa[key & 0x7FFFFFFFu].id : 0; }
+extern "C" uint32_t mcq_refdb_taxon_rank(const mcq_refdb* db, uint32_t key) { return valid_key(db, key) ? db->taxa[key & 0x7FFFFFFFu].rank : MCQ_RANK_NONE; }
+extern "C" const char* mcq_refdb_taxon_name(const mcq_refdb* db, uint32_t key) { return valid_key(db, key) ? db->taxa[key & 0x7FFFFFFFu].name.c_str() : "--"; }
+extern "C" uint32_t mcq_refdb_ancestor(const mcq_refdb* db, uint32_t key, uint32_t rank) {
+    if (!valid_key(db, key) || rank >= (uint32_t)kNumRanks) return MCQ_NO_TAXON;
+    return db->lineage[(size_t)(key & 0x7FFFFFFFu) * kNumRanks + rank];
+}
+
+extern "C" uint32_t mcq_refdb_classify(const mcq_refdb* db, const uint32_t* c, uint32_t n,
+                                       uint32_t hits_min, float hits_diff_fraction, uint32_t highest_rank) {
+    if (n == 0 || !valid_key(db, c[0])) return MCQ_NO_TAXON;
+    const uint64_t h0 = c[1];
+    if (h0 < hits_min) return MCQ_NO_TAXON;                     // below threshold: not classifiable
+    uint32_t lca = c[0] & 0x7FFFFFFFu;
+    const float thr = h0 > hits_min ? (float)(h0 - hits_min) * hits_diff_fraction : 0.0f;
+    for (uint32_t i = 1; i < n; ++i) {
+        if (!((float)(uint64_t)c[4 * i + 1] > thr)) break;
+        uint32_t r = MCQ_NO_TAXON;
+        if (valid_key(db, c[4 * i])) {
+            const uint32_t b = c[4 * i] & 0x7FFFFFFFu;
+            for (int j = 0; j <= 20; ++j) {                      // ranked_lca: first shared non-null rank up to root
+                uint32_t x = db->lineage[(size_t)lca * kNumRanks + j];
+                if (x != MCQ_NO_TAXON && x == db->lineage[(size_t)b * kNumRanks + j]) { r = x; break; }
+            }
+        }
+        lca = r;
+        if (lca == MCQ_NO_TAXON || db->taxa[lca].rank > highest_rank) return MCQ_NO_TAXON;
+    }
+    return db->taxa[lca].rank <= highest_rank ? lca : MCQ_NO_TAXON;
+}
+
+extern "C" uint32_t mcq_default_hits_min(uint32_t s) { return s >= 6 ? (uint32_t)(s / 3.0) : (s >= 4 ? 2u : 1u); }
+
+static const char* kRankNames[] = {"sequence", "form", "variety", "subspecies", "species", "subgenus", "genus", "subtribe",
+                                   "tribe", "subfamily", "family", "suborder", "order", "subclass", "class", "subphylum",
+                                   "phylum", "subkingdom", "kingdom", "domain", "root", "none"};
+extern "C" const char* mcq_rank_name(uint32_t r) { return kRankNames[r < 21 ? r : 21]; }
+extern "C" uint32_t mcq_rank_from_name(const char* name) {
+    if (!name) return MCQ_RANK_NONE;
+    std::string s(name);
+    std::transform(s.begin(), s.end(), s.begin(), ::tolower);
+    static const std::map<std::string, uint32_t> m = {
+        {"sequence", 0}, {"genome", 0}, {"form", 1}, {"forma", 1}, {"variety", 2}, {"varietas", 2}, {"subspecies", 3},
+        {"species", 4}, {"species group", 5}, {"species subgroup", 5}, {"subgenus", 5}, {"genus", 6}, {"subtribe", 7},
+        {"tribe", 8}, {"subfamily", 9}, {"family", 10}, {"superfamily", 11}, {"parvorder", 11}, {"infraorder", 11},
+        {"suborder", 11}, {"order", 12}, {"superorder", 13}, {"infraclass", 13}, {"subclass", 13}, {"class", 14},
+        {"superclass", 15}, {"subphylum", 15}, {"phylum", 16}, {"division", 16}, {"superphylum", 17}, {"subkingdom", 17},
+        {"kingdom", 18}, {"subdomain", 18}, {"superkingdom", 19}, {"domain", 19}, {"root", 20}};
+    auto it = m.find(s);
+    return it == m.end() ? MCQ_RANK_NONE : it->second;
+}

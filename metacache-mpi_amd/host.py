@@ -1,0 +1,95 @@
+"""ctypes mirror of include/mcq_host.h (reference shard reader, taxonomy keys, classify)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import host_lib_path
+
+NO_TAXON = 0xFFFFFFFF
+
+
+class Info(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("sketch_size", C.c_uint32), ("winlen", C.c_uint32), ("winstride", C.c_uint32),
+                ("q_sketch_size", C.c_uint32), ("q_winlen", C.c_uint32), ("q_winstride", C.c_uint32),
+                ("max_locs_per_feature", C.c_uint32), ("n_ranks", C.c_uint32), ("n_targets", C.c_uint32),
+                ("n_taxa", C.c_uint32), ("n_keys", C.c_uint64), ("n_locs", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        p = host_lib_path()
+        if not os.path.exists(p):
+            raise ImportError("host library %s missing: run __graft_entry__.build()" % p)
+        L = C.CDLL(p)
+        L.mcq_refdb_open.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.mcq_refdb_close.argtypes = [C.c_void_p]
+        L.mcq_refdb_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
+        for f, t in (("mcq_refdb_keys", C.POINTER(C.c_uint32)), ("mcq_refdb_list_off", C.POINTER(C.c_uint64)),
+                     ("mcq_refdb_locs", C.POINTER(C.c_uint64))):
+            getattr(L, f).restype = t; getattr(L, f).argtypes = [C.c_void_p]
+        L.mcq_refdb_tgt2tax.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+        L.mcq_refdb_taxon_id.restype = C.c_int64; L.mcq_refdb_taxon_id.argtypes = [C.c_void_p, C.c_uint32]
+        L.mcq_refdb_taxon_rank.restype = C.c_uint32; L.mcq_refdb_taxon_rank.argtypes = [C.c_void_p, C.c_uint32]
+        L.mcq_refdb_taxon_name.restype = C.c_char_p; L.mcq_refdb_taxon_name.argtypes = [C.c_void_p, C.c_uint32]
+        L.mcq_refdb_ancestor.restype = C.c_uint32; L.mcq_refdb_ancestor.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.mcq_refdb_classify.restype = C.c_uint32
+        L.mcq_refdb_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_uint32]
+        L.mcq_default_hits_min.restype = C.c_uint32; L.mcq_default_hits_min.argtypes = [C.c_uint32]
+        L.mcq_rank_from_name.restype = C.c_uint32; L.mcq_rank_from_name.argtypes = [C.c_char_p]
+        L.mcq_rank_name.restype = C.c_char_p; L.mcq_rank_name.argtypes = [C.c_uint32]
+        L.mcq_host_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+class RefDb:
+    """The reference's <prefix>.db_<r> shard files, parsed and unioned on the host."""
+
+    def __init__(self, prefix, n_ranks):
+        h = C.c_void_p()
+        if lib().mcq_refdb_open(prefix.encode(), n_ranks, C.byref(h)) != 0:
+            raise RuntimeError(lib().mcq_host_last_error().decode())
+        self.h = h
+        self.info = Info()
+        lib().mcq_refdb_get_info(self.h, C.byref(self.info))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcq_refdb_close(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def table(self):
+        n, m = self.info.n_keys, self.info.n_locs
+        keys = np.ctypeslib.as_array(lib().mcq_refdb_keys(self.h), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        off = np.ctypeslib.as_array(lib().mcq_refdb_list_off(self.h), shape=(n + 1,)).copy() if n else np.zeros(1, np.uint64)
+        locs = np.ctypeslib.as_array(lib().mcq_refdb_locs(self.h), shape=(m,)).copy() if m else np.zeros(0, np.uint64)
+        return keys, off, locs
+
+    def tgt2tax(self, merge_below_rank):
+        out = np.zeros(self.info.n_targets, np.uint32)
+        if lib().mcq_refdb_tgt2tax(self.h, merge_below_rank, out.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError(lib().mcq_host_last_error().decode())
+        return out
+
+    def taxon_id(self, key):
+        return int(lib().mcq_refdb_taxon_id(self.h, int(key)))
+
+    def classify(self, cands, hits_min, hits_diff_fraction, highest_rank):
+        """cands: array [n, 4] of (tax key, hits, beg, end) -> taxon index or NO_TAXON"""
+        c = np.ascontiguousarray(cands, np.uint32).reshape(-1, 4)
+        return int(lib().mcq_refdb_classify(self.h, c.ctypes.data_as(C.c_void_p), len(c), hits_min,
+                                            C.c_float(hits_diff_fraction), highest_rank))
+
+
+def rank_from_name(name):
+    return int(lib().mcq_rank_from_name(name.encode()))
