@@ -192,11 +192,20 @@ def main():
         },
     }
     if sharded is None and kn > 0:
+        traffic = None      # HBM bytes per launch from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if a.workload == "c2" and not a.small:
+                traffic = tj["hbm_bytes_per_launch"] * B / tj["reads_per_launch"]
+        except Exception:
+            traffic = None
         algo = algorithmic_bytes(max_bases, st)
         avg_ms = kms / kn
         ach = algo / (avg_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_query_wave", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": "profiles/pmc_traffic.json (FETCH_SIZE+WRITE_SIZE of the committed rocprofv3 --pmc passes, uncorrected, see profiles/r01_fetch_calibration.txt)" if traffic else None,
+                           "binding_resource": "integer VALU issue (~1 wave64 instr / 4 cycles / SIMD, scripts/valu_rate.hip); HBM random-sector traffic is ~17% of peak",
                            "kernel_note": "k_query_wave timed by HIP events on its stream (mcq_ws_timing); for --workload long the work is in k_query_block, timed by ms_per_step",
                            "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": avg_ms, "launches_timed": kn,
                            "bytes_per_read": algo / B,
