@@ -76,8 +76,11 @@ typedef struct {
     const uint32_t* tgt2tax;    /* [n_targets]                                        */
     uint32_t n_shards;          /* >= 1                                               */
     uint32_t shard_id;
-    uint32_t flags;             /* MCQ_DEVICE_PTRS                                    */
+    uint32_t flags;             /* MCQ_DEVICE_PTRS, MCQ_DB_LOCS_64                    */
     int32_t  device;            /* HIP device ordinal                                 */
+    uint32_t loc_win_bits;      /* 0 = derive from the data.  Shards built from different
+                                   data must agree on the location format: pass the bit width
+                                   of the largest window id of the WHOLE database          */
 } mcq_db_desc;
 
 /* One batch of sequences: bases[seq_off[i] .. seq_off[i+1]) is sequence i (ASCII,
@@ -155,31 +158,40 @@ int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats);
  * mcq_sketch  : rows 1-5.  features[w * sketch_size + i], n_feat[w] for window w of
  *               the batch; win_query[w] = query index of window w; returns the number
  *               of windows in *n_windows (device scalar when MCQ_DEVICE_PTRS).
- * mcq_lookup  : rows 6-7 on the owning shard: for each feature, list length and the
- *               concatenated lists (two calls: counts, then gather).
- * mcq_reduce  : rows 8-11 on the home GPU from per-query location segments.          */
+ * mcq_lookup_*: rows 6-7 on the owning shard (counts, then gather).
+ * mcq_assemble / mcq_reduce: rows 8-11 on the home GPU.                              */
 int mcq_count_windows(const mcq_db* db, const mcq_batch* in, uint64_t* win_off /* [n_seqs+1] */, void* stream);
 int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t* win_off,
                uint32_t* features, uint32_t* n_feat, void* stream);
+/* mcq_lookup_count: list length per feature (0 for absent / foreign / 0xFFFFFFFF); if
+ *   list_src is not NULL it also receives where each list starts in the shard, so that
+ *   mcq_lookup_gather need not probe again.
+ * mcq_lookup_gather: concatenates the lists at out_off[i] in the handle's NATIVE location
+ *   width: mcq_db_loc_bytes() = 4 ((tgt << mcq_db_win_bits()) | win) or 8 ((tgt << 32) | win).
+ *   The native width is what travels between GPUs.                                     */
 int mcq_lookup_count(const mcq_db* db, const uint32_t* features, uint64_t n_features,
-                     uint32_t* list_len, void* stream);
+                     uint32_t* list_len, uint64_t* list_src, void* stream);
 int mcq_lookup_gather(const mcq_db* db, const uint32_t* features, uint64_t n_features,
-                      const uint64_t* out_off /* [n_features+1] */, uint64_t* out_locs, void* stream);
+                      const uint32_t* list_len, const uint64_t* list_src,
+                      const uint64_t* out_off /* [n_features+1] */, void* out_locs, void* stream);
+uint32_t mcq_db_loc_bytes(const mcq_db* db);
+uint32_t mcq_db_win_bits(const mcq_db* db);
+/* mcq_assemble: home side, after the lists came back.  List i (list_len[i] native-width
+ *   locations, consecutive in src_locs) belongs to feature slot src_slot[i] of the batch's
+ *   [window][sketch_size] feature array.  Produces the per-query segments mcq_reduce takes:
+ *   loc_off[n_queries+1], query_len[n_queries] (sum of the mates' lengths) and dst_locs.   */
+int mcq_assemble(const mcq_db* db, uint64_t n_lists, const uint32_t* list_len, const uint32_t* src_slot,
+                 uint64_t n_slots, const void* src_locs, const mcq_batch* in, const uint64_t* win_off,
+                 uint64_t* loc_off, uint32_t* query_len, void* dst_locs, void* stream);
+/* mcq_reduce: rows 8-11 per query from native-width location segments (any order inside). */
 int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, const uint64_t* loc_off /* [n_queries+1] */,
-               uint64_t* locs /* sorted in place per query */, const uint32_t* query_len /* [n_queries] sum of mate lengths */,
-               const mcq_query_opts* opt, mcq_result* out, void* stream);
+               const void* locs, const uint32_t* query_len, const mcq_query_opts* opt, mcq_result* out, void* stream);
 
-/* Routing helpers of the sharded path (device pointers).
- * mcq_bucket_features: groups the non-empty features by owning shard.  counts is a device
+/* mcq_bucket_features: groups the non-empty features by owning shard.  counts is a device
  *   array of n_shards u64 receiving the per-shard counts; bucketed/src_index receive,
- *   shard after shard, the features and the slot (index into `features`) each came from.
- * mcq_scatter_lists: list i (src_locs[src_off[i] .. src_off[i+1])) is copied to
- *   dst_locs[dst_off[dst_slot[i]] ...): puts the lists that came back from the owners
- *   into per-query order for mcq_reduce.                                              */
+ *   shard after shard, the features and the slot (index into `features`) each came from. */
 int mcq_bucket_features(const uint32_t* features, uint64_t n, uint32_t n_shards,
                         uint64_t* counts, uint32_t* bucketed, uint32_t* src_index, void* stream);
-int mcq_scatter_lists(uint64_t n_lists, const uint64_t* src_off, const uint32_t* dst_slot, const uint64_t* dst_off,
-                      const uint64_t* src_locs, uint64_t* dst_locs, void* stream);
 
 /* shard that owns a feature: a range of h2(f) = thomas_mueller_hash(f)
  * (src/hash_int.h:39-45), never of f itself                          */

@@ -140,7 +140,8 @@ __global__ void k_max_win(const u64* locs, u64 n, u32* out) {
 }
 
 // exclusive scan of u64 array (single workgroup, used only at DB build)
-__global__ __launch_bounds__(1024) void k_scan_u64(const u64* in, u64* out, u64 n) {
+template <class InT>
+__global__ __launch_bounds__(1024) void k_scan_u64(const InT* in, u64* out, u64 n) {
     __shared__ u64 s_w[16];
     __shared__ u64 s_carry;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(1024) void k_scan_u64(const u64* in, u64* out, u64 
 // exclusive scan of n u64 values in three launches: per-tile scan + tile sums, scan of the
 // tile sums (one workgroup), add.  out has n + 1 entries (out[n] = total).
 #define MCQ_SCAN_TILE 8192
-__global__ __launch_bounds__(1024) void k_scan_tiles(const u64* in, u64* out, u64 n, u64* tile_sums) {
+template <class InT>
+__global__ __launch_bounds__(1024) void k_scan_tiles(const InT* in, u64* out, u64 n, u64* tile_sums) {
     __shared__ u64 s_w[16];
     __shared__ u64 s_carry;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -485,17 +487,20 @@ __global__ __launch_bounds__(256) void k_sketch_seqs(DbDev db, const char* bases
     }
 }
 
-__global__ void k_lookup_count(DbDev db, const u32* features, u64 n, u32* list_len) {
+__global__ void k_lookup_count(DbDev db, const u32* features, u64 n, u32* list_len, u64* list_src) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 off; u32 len;
     probe(db, features[i], off, len);
     list_len[i] = len;
+    if (list_src) list_src[i] = off;
 }
 
-// one wave per 64 consecutive features: probe again, then copy the lists cooperatively
+// one wave per 64 consecutive features: (probe again unless the list starts were kept), then
+// copy the lists cooperatively, in the handle's native location width
 template <class KeyT>
-__global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* features, u64 n, const u64* out_off, u64* out_locs) {
+__global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* features, u64 n, const u32* list_len,
+                                                       const u64* list_src, const u64* out_off, KeyT* out_locs) {
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u64 ngroups = (n + 63) / 64, nwaves = (u64)gridDim.x * 4;
@@ -503,7 +508,10 @@ __global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* feat
     for (u64 g = (u64)blockIdx.x * 4 + wave; g < ngroups; g += nwaves) {
         const u64 i = g * 64 + lane;
         u64 off = 0; u32 len = 0;
-        if (i < n) probe(db, features[i], off, len);
+        if (i < n) {
+            if (list_src) { off = list_src[i]; len = list_len[i]; }
+            else probe(db, features[i], off, len);
+        }
         const u64 obase = out_off[g * 64];
         u32 incl = wave_incl_scan(len, lane);
         u32 pos = incl - len;
@@ -520,30 +528,30 @@ __global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* feat
             }
             u32 pj = __shfl(pos, (int)lo, 64);
             u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
-            if (t < T) out_locs[obase + t] = key_expand<KeyT>(locs[(((u64)ohi << 32) | olo) + (tt - pj)], db.wb);
+            if (t < T) out_locs[obase + t] = locs[(((u64)ohi << 32) | olo) + (tt - pj)];
         }
     }
 }
 
-// rows 8-11 from per-query location segments in the public u64 form (home GPU of the sharded path)
-template <int E>
-__device__ __forceinline__ void load_sort_store(u64* buf, const u64* src, u32 T, u32 lane) {
-    u64 r[E];
+// rows 8-11 from per-query location segments in the handle's native width (home GPU of the sharded path)
+template <class KeyT, int E>
+__device__ __forceinline__ void load_sort_store(KeyT* buf, const KeyT* src, u32 T, u32 lane) {
+    KeyT r[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) { const u32 t = e * 64 + lane; r[e] = t < T ? src[t] : ~0ull; }
-    wave_regsort<u64, E>(r, lane);
+    for (int e = 0; e < E; ++e) { const u32 t = e * 64 + lane; r[e] = t < T ? src[t] : key_pad<KeyT>(); }
+    wave_regsort<KeyT, E>(r, lane);
 #pragma unroll
     for (int e = 0; e < E; ++e) buf[e * 64 + lane] = r[e];
 }
 
-template <int LCAP>
+template <class KeyT, int LCAP>
 __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, u32* ovf_list,
-                                                     u64 nq, const u64* loc_off, const u64* locs, const u32* query_len) {
-    __shared__ u64 s_buf[4][LCAP];
+                                                     u64 nq, const u64* loc_off, const KeyT* locs, const u32* query_len) {
+    __shared__ KeyT s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    u64* buf = s_buf[wave];
+    KeyT* buf = s_buf[wave];
     u32* hits = s_hits[wave];
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_loc = 0, st_cand = 0;
@@ -556,26 +564,26 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         const u32 T = (u32)T64;
         st_loc += T;
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
-        if (T <= 64)       load_sort_store<1>(buf, locs + b0, T, lane);
-        else if (T <= 128) load_sort_store<2>(buf, locs + b0, T, lane);
-        else if (T <= 256) load_sort_store<4>(buf, locs + b0, T, lane);
-        else               load_sort_store<8>(buf, locs + b0, T, lane);
+        if (T <= 64)       load_sort_store<KeyT, 1>(buf, locs + b0, T, lane);
+        else if (T <= 128) load_sort_store<KeyT, 2>(buf, locs + b0, T, lane);
+        else if (T <= 256) load_sort_store<KeyT, 4>(buf, locs + b0, T, lane);
+        else               load_sort_store<KeyT, 8>(buf, locs + b0, T, lane);
         wave_sync();
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        sweep_targets_wave<u64>(buf, hits, T, numWindows, 32u, lane);
-        st_cand += topk_fold_write<u64, u32, 9>(db, opt, out, buf, hits, T, numWindows, 32u, q, lane);
+        sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
+        st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
     }
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
 }
 
-template <int LCAPB>
+template <class KeyT, int LCAPB>
 __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
-                                                       ScratchDev sc, const u64* loc_off, const u64* locs, const u32* query_len) {
-    __shared__ u64 s_buf[LCAPB];
+                                                       ScratchDev sc, const u64* loc_off, const KeyT* locs, const u32* query_len) {
+    __shared__ KeyT s_buf[LCAPB];
     __shared__ u64 s_hits[LCAPB];
     const u32 tid = threadIdx.x;
-    u64* gbuf = sc.gbuf + (u64)blockIdx.x * sc.lmax;
+    KeyT* gbuf = reinterpret_cast<KeyT*>(sc.gbuf + (u64)blockIdx.x * sc.lmax);
     u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
     const u32 n_ovf = ctr->ovf_count;
     DebugDev dbg; dbg.mode = 0; dbg.match_cnt = nullptr; dbg.match_off = nullptr; dbg.matches = nullptr;
@@ -589,9 +597,9 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
         const u32 T = (u32)T64;
         if (tid == 0) atomicAdd(&ctr->n_locations, (unsigned long long)T);
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        auto load = [&](u32 t) -> u64 { return locs[b0 + t]; };
-        if (pow2ceil(T) <= (u32)LCAPB) block_tail<u64, true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, 32u, q, tid, dbg, load);
-        else                           block_tail<u64, false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, 32u, q, tid, dbg, load);
+        auto load = [&](u32 t) -> KeyT { return locs[b0 + t]; };
+        if (pow2ceil(T) <= (u32)LCAPB) block_tail<KeyT, true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, load);
+        else                           block_tail<KeyT, false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, load);
     }
 }
 
@@ -678,8 +686,9 @@ __global__ __launch_bounds__(256) void k_bucket_fill(const u32* features, u64 n,
 }
 
 // list i = src_locs[src_off[i] .. src_off[i+1]) goes to dst_locs[dst_off[dst_slot[i]] ..); one wave per 64 lists
+template <class KeyT>
 __global__ __launch_bounds__(256) void k_scatter_lists(u64 n_lists, const u64* src_off, const u32* dst_slot, const u64* dst_off,
-                                                       const u64* src_locs, u64* dst_locs) {
+                                                       const KeyT* src_locs, KeyT* dst_locs) {
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const u64 ngroups = (n_lists + 63) / 64, nwaves = (u64)gridDim.x * 4;
@@ -707,18 +716,33 @@ __global__ __launch_bounds__(256) void k_scatter_lists(u64 n_lists, const u64* s
         }
     }
 }
+__global__ void k_scatter_len(const u32* list_len, const u32* slot, u64 n, u32* slot_len) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slot_len[slot[i]] = list_len[i];
+}
+// per query: location segment start = offset of its first feature slot; length = sum of its mates
+__global__ void k_query_offsets(u64 nq, u32 qstep, u32 s, const u64* win_off, const u64* seq_off, const u64* dst_off, u64 n_slots,
+                                u64* loc_off, u32* query_len) {
+    const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) {
+        loc_off[q] = dst_off[win_off[q * qstep] * s];
+        query_len[q] = (u32)(seq_off[(q + 1) * qstep] - seq_off[q * qstep]);
+    }
+    if (q == 0) loc_off[nq] = dst_off[n_slots];
+}
 
 // ------------------------------------------------------------------ host helpers
 static u64 pow2ceil64(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 
-static int device_exclusive_scan(const u64* in, u64* out, u64 n, hipStream_t st) {
+template <class InT>
+static int device_exclusive_scan(const InT* in, u64* out, u64 n, hipStream_t st) {
     const u64 ntiles = (n + MCQ_SCAN_TILE - 1) / MCQ_SCAN_TILE;
-    if (ntiles <= 1) { hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, in, out, n); return MCQ_OK; }
+    if (ntiles <= 1) { hipLaunchKernelGGL(k_scan_u64<InT>, dim3(1), dim3(1024), 0, st, in, out, n); return MCQ_OK; }
     u64 *sums = nullptr, *offs = nullptr;
     HIPCHK(hipMallocAsync((void**)&sums, ntiles * 8, st));
     HIPCHK(hipMallocAsync((void**)&offs, (ntiles + 1) * 8, st));
-    hipLaunchKernelGGL(k_scan_tiles, dim3((u32)ntiles), dim3(1024), 0, st, in, out, n, sums);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, (const u64*)sums, offs, ntiles);
+    hipLaunchKernelGGL(k_scan_tiles<InT>, dim3((u32)ntiles), dim3(1024), 0, st, in, out, n, sums);
+    hipLaunchKernelGGL(k_scan_u64<u64>, dim3(1), dim3(1024), 0, st, (const u64*)sums, offs, ntiles);
     hipLaunchKernelGGL(k_scan_add, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, out, n, (const u64*)offs);
     HIPCHK(hipFreeAsync(sums, st));
     HIPCHK(hipFreeAsync(offs, st));
@@ -805,7 +829,7 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     HIPCHK(hipMalloc(&d_new, (nk + 1) * 8));
     const u32 TB = 256;
     if (nk) hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id, d_len);
-    { int rcs = device_exclusive_scan(d_len, d_new, nk, 0); if (rcs) return rcs; }
+    { int rcs = device_exclusive_scan<u64>(d_len, d_new, nk, 0); if (rcs) return rcs; }
     u64 nl_local = 0;
     HIPCHK(hipMemcpy(&nl_local, d_new + nk, 8, hipMemcpyDeviceToHost));
     // number of owned non-empty keys (for the table size) -- count on host from lengths
@@ -830,6 +854,7 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
         u32 winbits = 1; while (winbits < 32 && (maxwin >> winbits)) ++winbits;
         u32 maxtgt = desc->n_targets ? desc->n_targets - 1 : 0;
         u32 tgtbits = 1; while (tgtbits < 32 && (maxtgt >> tgtbits)) ++tgtbits;
+        if (desc->loc_win_bits > winbits) winbits = desc->loc_win_bits;
         if (winbits + tgtbits <= 32 && winbits <= 31 &&
             ((((u64)maxtgt << winbits) | maxwin) < 0xFFFFFFFFull)) { compact = 1; wb = winbits; }
     }
@@ -1065,7 +1090,7 @@ extern "C" int mcq_count_windows(const mcq_db* db, const mcq_batch* in, uint64_t
     u64* cnt = nullptr;
     HIPCHK(hipMallocAsync((void**)&cnt, std::max<u64>(1, n) * 8, st));
     if (n) hipLaunchKernelGGL(k_count_windows, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, in->seq_off, n, db->d.winlen, db->d.winstride, cnt);
-    { int rcs = device_exclusive_scan(cnt, win_off, n, st); if (rcs) return rcs; }
+    { int rcs = device_exclusive_scan<u64>((const u64*)cnt, win_off, n, st); if (rcs) return rcs; }
     HIPCHK(hipFreeAsync(cnt, st));
     HIPCHK(hipGetLastError());
     return MCQ_OK;
@@ -1090,31 +1115,67 @@ extern "C" int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t*
     return MCQ_OK;
 }
 
+extern "C" uint32_t mcq_db_loc_bytes(const mcq_db* db) { return db && db->d.compact ? 4u : 8u; }
+extern "C" uint32_t mcq_db_win_bits(const mcq_db* db) { return db ? db->d.wb : 32u; }
+
 extern "C" int mcq_lookup_count(const mcq_db* db, const uint32_t* features, uint64_t n_features,
-                                uint32_t* list_len, void* stream) {
+                                uint32_t* list_len, uint64_t* list_src, void* stream) {
     if (!db || (n_features && (!features || !list_len))) return fail(MCQ_E_ARG, "null argument");
     HIPCHK(hipSetDevice(db->device));
     if (n_features == 0) return MCQ_OK;
-    hipLaunchKernelGGL(k_lookup_count, dim3((u32)((n_features + 255) / 256)), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, list_len);
+    hipLaunchKernelGGL(k_lookup_count, dim3((u32)((n_features + 255) / 256)), dim3(256), 0, (hipStream_t)stream, db->d, features,
+                       n_features, list_len, list_src);
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }
 
 extern "C" int mcq_lookup_gather(const mcq_db* db, const uint32_t* features, uint64_t n_features,
-                                 const uint64_t* out_off, uint64_t* out_locs, void* stream) {
+                                 const uint32_t* list_len, const uint64_t* list_src,
+                                 const uint64_t* out_off, void* out_locs, void* stream) {
     if (!db || (n_features && (!features || !out_off))) return fail(MCQ_E_ARG, "null argument");
+    if (list_src && !list_len) return fail(MCQ_E_ARG, "list_src needs list_len");
     HIPCHK(hipSetDevice(db->device));
     if (n_features == 0) return MCQ_OK;
     u64 groups = (n_features + 63) / 64;
     u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
-    if (db->d.compact) hipLaunchKernelGGL(k_lookup_gather<u32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, out_off, out_locs);
-    else               hipLaunchKernelGGL(k_lookup_gather<u64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, out_off, out_locs);
+    if (db->d.compact) hipLaunchKernelGGL(k_lookup_gather<u32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, list_len, list_src, out_off, (u32*)out_locs);
+    else               hipLaunchKernelGGL(k_lookup_gather<u64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, list_len, list_src, out_off, (u64*)out_locs);
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+extern "C" int mcq_assemble(const mcq_db* db, uint64_t n_lists, const uint32_t* list_len, const uint32_t* src_slot,
+                            uint64_t n_slots, const void* src_locs, const mcq_batch* in, const uint64_t* win_off,
+                            uint64_t* loc_off, uint32_t* query_len, void* dst_locs, void* stream) {
+    if (!db || !in || !win_off || !loc_off || !query_len) return fail(MCQ_E_ARG, "null argument");
+    if (!(in->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "staged entry points take device pointers");
+    if (n_lists && (!list_len || !src_slot)) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(db->device));
+    hipStream_t st = (hipStream_t)stream;
+    const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
+    u32* slot_len = nullptr; u64 *dst_off = nullptr, *src_off = nullptr;
+    HIPCHK(hipMallocAsync((void**)&slot_len, std::max<u64>(1, n_slots) * 4, st));
+    HIPCHK(hipMallocAsync((void**)&dst_off, (n_slots + 1) * 8, st));
+    HIPCHK(hipMallocAsync((void**)&src_off, (n_lists + 1) * 8, st));
+    HIPCHK(hipMemsetAsync(slot_len, 0, std::max<u64>(1, n_slots) * 4, st));
+    if (n_lists) hipLaunchKernelGGL(k_scatter_len, dim3((u32)((n_lists + 255) / 256)), dim3(256), 0, st, list_len, src_slot, n_lists, slot_len);
+    int rc = device_exclusive_scan<u32>(slot_len, dst_off, n_slots, st); if (rc) return rc;
+    rc = device_exclusive_scan<u32>(list_len, src_off, n_lists, st); if (rc) return rc;
+    if (n_lists) {
+        u64 groups = (n_lists + 63) / 64;
+        u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
+        if (db->d.compact) hipLaunchKernelGGL(k_scatter_lists<u32>, dim3(grid), dim3(256), 0, st, n_lists, (const u64*)src_off, src_slot, (const u64*)dst_off, (const u32*)src_locs, (u32*)dst_locs);
+        else               hipLaunchKernelGGL(k_scatter_lists<u64>, dim3(grid), dim3(256), 0, st, n_lists, (const u64*)src_off, src_slot, (const u64*)dst_off, (const u64*)src_locs, (u64*)dst_locs);
+    }
+    hipLaunchKernelGGL(k_query_offsets, dim3((u32)((nq + 256) / 256)), dim3(256), 0, st, nq, in->paired ? 2u : 1u, db->d.s, win_off,
+                       in->seq_off, (const u64*)dst_off, n_slots, loc_off, query_len);
+    HIPCHK(hipFreeAsync(slot_len, st)); HIPCHK(hipFreeAsync(dst_off, st)); HIPCHK(hipFreeAsync(src_off, st));
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }
 
 extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, const uint64_t* loc_off,
-                          uint64_t* locs, const uint32_t* query_len, const mcq_query_opts* opt, mcq_result* out, void* stream) {
+                          const void* locs, const uint32_t* query_len, const mcq_query_opts* opt, mcq_result* out, void* stream) {
     if (!db || !ws || !opt || !out || (n_queries && (!loc_off || !query_len))) return fail(MCQ_E_ARG, "null argument");
     if (!(out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "staged entry points take device pointers");
     if (n_queries > ws->max_queries) return fail(MCQ_E_ARG, "more queries than the workspace allows");
@@ -1128,10 +1189,17 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     if (n_queries == 0) return MCQ_OK;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
     u32 grid = (u32)std::min<u64>((n_queries + 3) / 4, 256ull * 24);
-    hipLaunchKernelGGL((k_reduce_wave<kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
-                       n_queries, loc_off, (const u64*)locs, query_len);
-    hipLaunchKernelGGL((k_reduce_block<kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
-                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
+    if (db->d.compact) {
+        hipLaunchKernelGGL((k_reduce_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
+                           n_queries, loc_off, (const u32*)locs, query_len);
+        hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+                           (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len);
+    } else {
+        hipLaunchKernelGGL((k_reduce_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
+                           n_queries, loc_off, (const u64*)locs, query_len);
+        hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+                           (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
+    }
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }
@@ -1183,17 +1251,6 @@ extern "C" int mcq_bucket_features(const uint32_t* features, uint64_t n, uint32_
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, blk, n_shards, grid, (unsigned long long*)counts);
     hipLaunchKernelGGL(k_bucket_fill, dim3(grid), dim3(256), 0, st, features, n, n_shards, tile, (const unsigned long long*)blk, bucketed, src_index);
     HIPCHK(hipFreeAsync(blk, st));
-    HIPCHK(hipGetLastError());
-    return MCQ_OK;
-}
-
-extern "C" int mcq_scatter_lists(uint64_t n_lists, const uint64_t* src_off, const uint32_t* dst_slot, const uint64_t* dst_off,
-                                 const uint64_t* src_locs, uint64_t* dst_locs, void* stream) {
-    if (n_lists == 0) return MCQ_OK;
-    if (!src_off || !dst_slot || !dst_off) return fail(MCQ_E_ARG, "null argument");
-    u64 groups = (n_lists + 63) / 64;
-    u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
-    hipLaunchKernelGGL(k_scatter_lists, dim3(grid), dim3(256), 0, (hipStream_t)stream, n_lists, src_off, dst_slot, dst_off, src_locs, dst_locs);
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }

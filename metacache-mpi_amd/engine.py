@@ -28,7 +28,8 @@ class DbDesc(C.Structure):
     _fields_ = [("k", C.c_uint32), ("sketch_size", C.c_uint32), ("winlen", C.c_uint32), ("winstride", C.c_uint32),
                 ("tgt_winstride", C.c_uint32), ("n_targets", C.c_uint32), ("n_keys", C.c_uint64), ("n_locs", C.c_uint64),
                 ("keys", C.c_void_p), ("list_off", C.c_void_p), ("locs", C.c_void_p), ("tgt2tax", C.c_void_p),
-                ("n_shards", C.c_uint32), ("shard_id", C.c_uint32), ("flags", C.c_uint32), ("device", C.c_int32)]
+                ("n_shards", C.c_uint32), ("shard_id", C.c_uint32), ("flags", C.c_uint32), ("device", C.c_int32),
+                ("loc_win_bits", C.c_uint32)]
 
 
 class Batch(C.Structure):
@@ -79,10 +80,13 @@ def lib():
         L.mcq_ws_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.mcq_count_windows.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
         L.mcq_sketch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.mcq_lookup_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
-        L.mcq_lookup_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_lookup_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_lookup_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_db_loc_bytes.restype = C.c_uint32; L.mcq_db_loc_bytes.argtypes = [C.c_void_p]
+        L.mcq_db_win_bits.restype = C.c_uint32; L.mcq_db_win_bits.argtypes = [C.c_void_p]
         L.mcq_bucket_features.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.mcq_scatter_lists.argtypes = [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Batch),
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         _lib = L
@@ -103,12 +107,13 @@ class Database:
     of the reference's sketch_database: built from the union of its shard tables."""
 
     def __init__(self, keys, list_off, locs, tgt2tax, k=16, sketch_size=16, winlen=128, winstride=113,
-                 tgt_winstride=0, n_shards=1, shard_id=0, device=0, device_ptrs=None, flags=0):
+                 tgt_winstride=0, n_shards=1, shard_id=0, device=0, device_ptrs=None, flags=0, loc_win_bits=0):
         """keys/list_off/locs/tgt2tax: numpy arrays (host) -- or, with device_ptrs=dict(
         keys=ptr, list_off=ptr, locs=ptr, tgt2tax=ptr, n_keys=, n_locs=, n_targets=), raw device pointers."""
         d = DbDesc()
         d.k, d.sketch_size, d.winlen, d.winstride, d.tgt_winstride = k, sketch_size, winlen, winstride, tgt_winstride
         d.n_shards, d.shard_id, d.device = n_shards, shard_id, device
+        d.loc_win_bits = loc_win_bits
         if device_ptrs is None:
             self._keep = (np.ascontiguousarray(keys, np.uint32), np.ascontiguousarray(list_off, np.uint64),
                           np.ascontiguousarray(locs, np.uint64), np.ascontiguousarray(tgt2tax, np.uint32))
@@ -140,11 +145,24 @@ class Database:
         b = Batch(n_seqs, bases_ptr, seq_off_ptr, 0, MCQ_DEVICE_PTRS)
         _chk(lib().mcq_sketch(self.h, C.byref(b), win_off_ptr, features_ptr, n_feat_ptr, stream))
 
-    def lookup_count(self, features_ptr, n, list_len_ptr, stream=None):
-        _chk(lib().mcq_lookup_count(self.h, features_ptr, n, list_len_ptr, stream))
+    def lookup_count(self, features_ptr, n, list_len_ptr, list_src_ptr=None, stream=None):
+        _chk(lib().mcq_lookup_count(self.h, features_ptr, n, list_len_ptr, list_src_ptr, stream))
 
-    def lookup_gather(self, features_ptr, n, out_off_ptr, out_locs_ptr, stream=None):
-        _chk(lib().mcq_lookup_gather(self.h, features_ptr, n, out_off_ptr, out_locs_ptr, stream))
+    def lookup_gather(self, features_ptr, n, out_off_ptr, out_locs_ptr, list_len_ptr=None, list_src_ptr=None, stream=None):
+        """out_locs in the handle's native width (loc_bytes())"""
+        _chk(lib().mcq_lookup_gather(self.h, features_ptr, n, list_len_ptr, list_src_ptr, out_off_ptr, out_locs_ptr, stream))
+
+    def loc_bytes(self):
+        return int(lib().mcq_db_loc_bytes(self.h))
+
+    def win_bits(self):
+        return int(lib().mcq_db_win_bits(self.h))
+
+    def assemble(self, n_lists, list_len_ptr, src_slot_ptr, n_slots, src_locs_ptr, bases_ptr, seq_off_ptr, n_seqs, paired,
+                 win_off_ptr, loc_off_ptr, query_len_ptr, dst_locs_ptr, stream=None):
+        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 1 if paired else 0, MCQ_DEVICE_PTRS)
+        _chk(lib().mcq_assemble(self.h, n_lists, list_len_ptr, src_slot_ptr, n_slots, src_locs_ptr, C.byref(b), win_off_ptr,
+                                loc_off_ptr, query_len_ptr, dst_locs_ptr, stream))
 
     def close(self):
         if getattr(self, "h", None):
@@ -232,10 +250,6 @@ class Workspace:
 
 def bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream=None):
     _chk(lib().mcq_bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream))
-
-
-def scatter_lists(n_lists, src_off_ptr, dst_slot_ptr, dst_off_ptr, src_locs_ptr, dst_locs_ptr, stream=None):
-    _chk(lib().mcq_scatter_lists(n_lists, src_off_ptr, dst_slot_ptr, dst_off_ptr, src_locs_ptr, dst_locs_ptr, stream))
 
 
 def owner(feature, n_shards):

@@ -8,7 +8,7 @@ h2(feature) (engine.owner); reads are split across ranks.  Per batch, every rank
   3. all-to-all: counts, then features           -> owners
   4. owner looks the features up in its shard    (mcq_lookup_count + mcq_lookup_gather)
   5. all-to-all: list lengths, then locations    -> home ranks
-  6. puts the lists into per-query order         (mcq_scatter_lists)
+  6. puts the lists into per-query order         (mcq_assemble)
   7. sorts / sweeps / folds per query            (mcq_reduce)
 
 All locations of a read reach its home rank, so per-target hit counts equal the
@@ -34,6 +34,7 @@ class HipBackend:
     def __init__(self, db, dev, max_queries, max_locs_per_query=0):
         self.db, self.dev = db, dev
         self.s = db.sketch_size
+        self.loc_dtype = torch.int32 if db.loc_bytes() == 4 else torch.int64
         self.ws = engine.Workspace(db, max_queries, 1, max_locs_per_query)
 
     def _st(self):
@@ -60,23 +61,32 @@ class HipBackend:
         return c, bucketed[:m], src[:m]
 
     def lookup(self, feats):
+        """-> (list lengths int32 [n], exclusive offsets int64 [n+1]); keeps the list starts for gather()"""
         n = feats.numel()
         lens = torch.zeros(max(n, 1), dtype=torch.int32, device=self.dev)
-        self.db.lookup_count(feats.data_ptr(), n, lens.data_ptr(), self._st())
+        self._src = torch.empty(max(n, 1), dtype=torch.int64, device=self.dev)
+        self.db.lookup_count(feats.data_ptr(), n, lens.data_ptr(), self._src.data_ptr(), self._st())
         off = torch.zeros(n + 1, dtype=torch.int64, device=self.dev)
-        torch.cumsum(lens[:n].to(torch.int64), 0, out=off[1:])
+        torch.cumsum(lens[:n], 0, dtype=torch.int64, out=off[1:])
+        self._lens = lens
         return lens[:n], off
 
     def gather(self, feats, off, total):
-        locs = torch.empty(max(total, 1), dtype=torch.int64, device=self.dev)
-        self.db.lookup_gather(feats.data_ptr(), feats.numel(), off.data_ptr(), locs.data_ptr(), self._st())
+        """locations in the shard's native width: int32 words when compact, else int64"""
+        locs = torch.empty(max(total, 1), dtype=self.loc_dtype, device=self.dev)
+        self.db.lookup_gather(feats.data_ptr(), feats.numel(), off.data_ptr(), locs.data_ptr(), self._lens.data_ptr(),
+                              self._src.data_ptr(), self._st())
         return locs[:total]
 
-    def scatter(self, n_lists, src_off, dst_slot, dst_off, src_locs, total):
-        dst = torch.empty(max(total, 1), dtype=torch.int64, device=self.dev)
-        engine.scatter_lists(n_lists, src_off.data_ptr(), dst_slot.data_ptr(), dst_off.data_ptr(), src_locs.data_ptr(),
-                             dst.data_ptr(), self._st())
-        return dst
+    def assemble(self, m, lens_back, src_idx, n_slots, locs_back, total, bases, seq_off, n_seqs, paired, win_off):
+        nq = n_seqs // 2 if paired else n_seqs
+        loc_off = torch.empty(nq + 1, dtype=torch.int64, device=self.dev)
+        query_len = torch.empty(max(nq, 1), dtype=torch.int32, device=self.dev)
+        dst = torch.empty(max(total, 1), dtype=self.loc_dtype, device=self.dev)
+        self.db.assemble(m, lens_back.data_ptr(), src_idx.data_ptr(), n_slots, locs_back.data_ptr(), bases.data_ptr(),
+                         seq_off.data_ptr(), n_seqs, paired, win_off.data_ptr(), loc_off.data_ptr(), query_len.data_ptr(),
+                         dst.data_ptr(), self._st())
+        return loc_off, query_len, dst
 
     def reduce(self, nq, loc_off, locs, query_len, cands, ncand, max_cand, emulate_ranks, insert_size_max, flags):
         self.ws.reduce_device(nq, loc_off.data_ptr(), locs.data_ptr(), query_len.data_ptr(), cands.data_ptr(),
@@ -127,7 +137,7 @@ class ShardedQuery:
         # 5. lengths back, then locations back (split sizes = per-peer sums of lengths)
         lens_back = _a2a(m, lens_r, recv_counts, send_counts, self.group)
         src_off = torch.zeros(m + 1, dtype=torch.int64, device=bucketed.device)
-        torch.cumsum(lens_back.to(torch.int64), 0, out=src_off[1:])
+        torch.cumsum(lens_back, 0, dtype=torch.int64, out=src_off[1:])
         rb = torch.tensor([0] + recv_counts, dtype=torch.int64).cumsum(0).to(off_r.device)
         sb = torch.tensor([0] + send_counts, dtype=torch.int64).cumsum(0).to(off_r.device)
         sizes = torch.cat([off_r[rb], src_off[sb]]).cpu()
@@ -136,17 +146,9 @@ class ShardedQuery:
         total_r, total_b = int(sizes[N]), int(sizes[-1])
         locs_r = be.gather(recv_feats, off_r, total_r)
         locs_back = _a2a(total_b, locs_r, send_loc, recv_loc, self.group)
-        # 6. per-query order: list of feature slot f goes to the exclusive prefix sum of slot lengths
-        lens_slot = torch.zeros(F + 1, dtype=torch.int64, device=bucketed.device)
-        lens_slot[src_idx.long()] = lens_back.to(torch.int64)
-        dst_off = torch.zeros(F + 1, dtype=torch.int64, device=bucketed.device)
-        torch.cumsum(lens_slot[:F], 0, out=dst_off[1:])
-        locs_q = be.scatter(m, src_off, src_idx, dst_off, locs_back, total_b)
-        qstep = 2 if paired else 1
-        first_slot = win_off[0:n_seqs + 1:qstep][:nq + 1] * s
-        loc_off = dst_off[first_slot].contiguous()
-        so = seq_off[0:n_seqs + 1:qstep][:nq + 1]
-        query_len = (so[1:] - so[:-1]).to(torch.int32).contiguous()
+        # 6. per-query order (feature slot f's list goes to the exclusive prefix sum of the slot lengths)
+        loc_off, query_len, locs_q = be.assemble(m, lens_back, src_idx, F, locs_back, total_b, bases, seq_off, n_seqs,
+                                                 paired, win_off)
         # 7. sort / sweep / top lists / fold on the home rank
         be.reduce(nq, loc_off, locs_q, query_len, cands, ncand, max_cand, emulate_ranks, insert_size_max, flags)
         self._last = {"n_features": m, "n_locations": total_b, "n_queries": nq,

@@ -61,13 +61,20 @@ class OracleBackend:
         assert len(out) == total
         return torch.from_numpy(out.astype(np.int64))
 
-    def scatter(self, n_lists, src_off, dst_slot, dst_off, src_locs, total):
+    def assemble(self, m, lens_back, src_idx, n_slots, locs_back, total, bases, seq_off, n_seqs, paired, win_off):
+        lens = lens_back.numpy().astype(np.int64); slot = src_idx.numpy().astype(np.int64)
+        slot_len = np.zeros(n_slots + 1, np.int64); slot_len[slot] = lens
+        dst_off = np.zeros(n_slots + 1, np.int64); dst_off[1:] = np.cumsum(slot_len[:n_slots])
+        src_off = np.zeros(m + 1, np.int64); src_off[1:] = np.cumsum(lens)
         dst = torch.zeros(max(total, 1), dtype=torch.int64)
-        so, ds, do = src_off.numpy(), dst_slot.numpy(), dst_off.numpy()
-        for i in range(n_lists):
-            n = so[i + 1] - so[i]
-            dst[do[ds[i]]:do[ds[i]] + n] = src_locs[so[i]:so[i + 1]]
-        return dst
+        for i in range(m):
+            dst[dst_off[slot[i]]:dst_off[slot[i]] + lens[i]] = locs_back[src_off[i]:src_off[i + 1]]
+        qstep = 2 if paired else 1
+        nq = n_seqs // qstep
+        wo = win_off.numpy(); so = seq_off.numpy()
+        loc_off = torch.from_numpy(dst_off[wo[0:n_seqs + 1:qstep][:nq + 1] * self.s].copy())
+        ql = so[0:n_seqs + 1:qstep][:nq + 1]
+        return loc_off, torch.from_numpy((ql[1:] - ql[:-1]).astype(np.int32)), dst
 
     def reduce(self, nq, loc_off, locs, query_len, cands, ncand, max_cand, emulate_ranks, insert_size_max, flags):
         lo = loc_off.numpy(); l = locs.numpy().astype(np.uint64); ql = query_len.numpy()

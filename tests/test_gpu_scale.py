@@ -87,12 +87,17 @@ def test_db_roundtrip_lookup(world):
             n = probe.numel()
             lens = torch.zeros(n, dtype=torch.int32, device=dev)
             st = torch.cuda.current_stream(dev).cuda_stream
-            db.lookup_count(probe.data_ptr(), n, lens.data_ptr(), st)
+            db.lookup_count(probe.data_ptr(), n, lens.data_ptr(), None, st)
             ooff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
             torch.cumsum(lens.to(torch.int64), 0, out=ooff[1:])
-            out = torch.zeros(int(ooff[-1].item()) + 1, dtype=torch.int64, device=dev)
-            db.lookup_gather(probe.data_ptr(), n, ooff.data_ptr(), out.data_ptr(), st)
+            native = torch.zeros(int(ooff[-1].item()) + 1, dtype=torch.int32 if db.loc_bytes() == 4 else torch.int64, device=dev)
+            db.lookup_gather(probe.data_ptr(), n, ooff.data_ptr(), native.data_ptr(), stream=st)
             torch.cuda.synchronize()
+            if db.loc_bytes() == 4:          # (tgt << win_bits) | win  ->  (tgt << 32) | win
+                wb = db.win_bits(); w = native.to(torch.int64) & 0xFFFFFFFF
+                out = ((w >> wb) << 32) | (w & ((1 << wb) - 1))
+            else:
+                out = native
             own = torch.tensor([eng.owner(int(k) & 0xFFFFFFFF, n_shards) == sid for k in keys[:2000].tolist()])
             exp_len = (off[1:] - off[:-1])
             got = lens[:keys.numel()].to(torch.int64)
