@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--emulate-ranks", type=int, default=2, help="reference rank count whose results are reproduced")
     ap.add_argument("--max-cand", type=int, default=2)
     ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"])
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only to rehearse N>1 on a box with one GPU")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N>1: skip the extra sharded (all-to-all) measurement")
     ap.add_argument("--small", action="store_true", help="tiny DB / few reads (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,11 +75,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
-                                timeout=datetime.timedelta(seconds=300))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
+                                    timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
 
     pkg = importlib.import_module("metacache-mpi_amd")
@@ -173,7 +177,7 @@ def main():
         el = time.perf_counter() - t0
         if world > 1:
             import torch.distributed as dist
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
