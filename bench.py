@@ -251,6 +251,23 @@ def main():
 
     if a.stop_stage:
         out["INVALID_profiling_stop_stage"] = a.stop_stage
+    if world == 1 and a.workload == "c2" and not a.stop_stage and not a.small:
+        # the boundary may hand over HOST buffers: same steps with the batch copied in from pinned memory and the
+        # result copied back (PCIe Gen5 x16); reported for DESIGN.md, never as `value`
+        hb = [b.cpu().pin_memory() for b in batches[:4]]
+        hc = torch.zeros_like(cands, device="cpu").pin_memory(); hn = torch.zeros_like(ncand, device="cpu").pin_memory()
+        dbuf = torch.empty_like(batches[0])
+        nsteps = min(a.steps, 16)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            dbuf.copy_(hb[i % len(hb)], non_blocking=True)
+            ws.query_device(dbuf.data_ptr(), offsets[0].data_ptr(), B, paired, cands.data_ptr(), ncand.data_ptr(),
+                            max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, stream=stream)
+            hc.copy_(cands, non_blocking=True); hn.copy_(ncand, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        out["pcie_inclusive"] = {"value": nsteps * B / (time.perf_counter() - t0), "unit": "reads/s",
+                                 "note": "bases in from pinned host memory + candidates out per step, single stream, no overlap"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stop_stage:
         out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches, offsets, (a.warmup + a.steps - 1) % nb,
                                            cands, ncand, B, paired)
