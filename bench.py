@@ -257,14 +257,15 @@ def main():
         hb = [b.cpu().pin_memory() for b in batches[:4]]
         hc = torch.zeros_like(cands, device="cpu").pin_memory(); hn = torch.zeros_like(ncand, device="cpu").pin_memory()
         dbuf = torch.empty_like(batches[0])
+        c2, n2 = torch.empty_like(cands), torch.empty_like(ncand)      # own result buffers: `cands` keeps the timed run's last batch
         nsteps = min(a.steps, 16)
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(nsteps):
             dbuf.copy_(hb[i % len(hb)], non_blocking=True)
-            ws.query_device(dbuf.data_ptr(), offsets[0].data_ptr(), B, paired, cands.data_ptr(), ncand.data_ptr(),
+            ws.query_device(dbuf.data_ptr(), offsets[0].data_ptr(), B, paired, c2.data_ptr(), n2.data_ptr(),
                             max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, stream=stream)
-            hc.copy_(cands, non_blocking=True); hn.copy_(ncand, non_blocking=True)
+            hc.copy_(c2, non_blocking=True); hn.copy_(n2, non_blocking=True)
         torch.cuda.synchronize(dev)
         out["pcie_inclusive"] = {"value": nsteps * B / (time.perf_counter() - t0), "unit": "reads/s",
                                  "note": "bases in from pinned host memory + candidates out per step, single stream, no overlap"}
