@@ -137,7 +137,7 @@ int mcq_db_destroy(mcq_db* db);
 uint64_t mcq_db_bytes(const mcq_db* db);
 
 /* max_queries / max_bases bound one batch; max_locs_per_query bounds the match list
- * of a single query on the block-per-query path (0 = default 1<<20).                 */
+ * of a single query on the block-per-query path (0 = default 1<<18).                 */
 int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t max_bases,
                   uint64_t max_locs_per_query, mcq_ws** out);
 int mcq_ws_destroy(mcq_ws* ws);

@@ -911,7 +911,7 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     mcq_ws* ws = new mcq_ws();
     memset(ws, 0, sizeof(*ws));
     ws->device = db->device; ws->max_queries = max_queries; ws->max_bases = max_bases;
-    u64 lmax = max_locs_per_query ? pow2ceil64(max_locs_per_query) : (1ull << 20);
+    u64 lmax = max_locs_per_query ? pow2ceil64(max_locs_per_query) : (1ull << 18);
     if (lmax > (1ull << 30)) return fail(MCQ_E_UNSUPPORTED, "max_locs_per_query too large");
     ws->sc.lmax = (u32)lmax;
     ws->sc.fmax = 1u << 15;

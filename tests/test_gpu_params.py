@@ -65,3 +65,24 @@ def test_rejected_parameters():
     # an empty database answers every query with no candidates
     c, n = ws.query_host(b"ACGTACGTACGTACGTACGTACGT", np.array([0, 24], np.uint64), False)
     assert n.tolist() == [0]
+
+
+def test_capacity_error_is_reported_not_hidden():
+    """a query whose match list exceeds the workspace's per-query capacity gets no result and
+    mcq_ws_sync returns MCQ_E_CAPACITY (the reference's analogue: a FAIL log line, src/querying.h:833-847)"""
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    synth = importlib.import_module("metacache-mpi_amd.synth")
+    dev = torch.device("cuda", 0)
+    gb, goff, species = synth.make_genomes(2, 12, 60_000, 80_000, 0.01, seed=23, device=dev)
+    keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=1)
+    db = dbbuild.make_database(keys, off, locs, species)
+    reads, roff, _ = synth.sample_long_reads(gb, goff, 4, 20000, 0.0, seed=1, min_len=15000, max_len=25000)
+    rb = reads.cpu().numpy().tobytes(); ro = roff.cpu().numpy().astype(np.uint64)
+    small = eng.Workspace(db, 4, len(rb), max_locs_per_query=1024)
+    with pytest.raises(eng.McqError) as e:
+        small.query_host(rb, ro, False, max_cand=2)
+    assert e.value.code == eng.MCQ_E_CAPACITY
+    big = eng.Workspace(db, 4, len(rb))
+    c, n = big.query_host(rb, ro, False, max_cand=2)
+    assert (n > 0).all() and big.sync()["n_overflow"] == 4
