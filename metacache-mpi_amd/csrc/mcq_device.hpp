@@ -235,6 +235,23 @@ __device__ __forceinline__ u32 wave_sort64(u32 v, u32 lane) {
     return v;
 }
 
+// ascending sort of lanes 0-31 (lanes 32-63 hold padding and sort among themselves): 15 stages
+template <int J>
+__device__ __forceinline__ u32 bitonic_final32(u32 v, u32 lane) {
+    constexpr u64 KM = keepmin_mask(64, J, true);
+    return cmpex(v, xor_lane<J>(v, lane), KM);
+}
+__device__ __forceinline__ u32 wave_sort32_low(u32 v, u32 lane) {
+    v = bitonic_step<2, 1>(v, lane);
+    v = bitonic_step<4, 2>(v, lane);  v = bitonic_step<4, 1>(v, lane);
+    v = bitonic_step<8, 4>(v, lane);  v = bitonic_step<8, 2>(v, lane);  v = bitonic_step<8, 1>(v, lane);
+    v = bitonic_step<16, 8>(v, lane); v = bitonic_step<16, 4>(v, lane); v = bitonic_step<16, 2>(v, lane);
+    v = bitonic_step<16, 1>(v, lane);
+    v = bitonic_final32<16>(v, lane); v = bitonic_final32<8>(v, lane); v = bitonic_final32<4>(v, lane);
+    v = bitonic_final32<2>(v, lane);  v = bitonic_final32<1>(v, lane);
+    return v;
+}
+
 // Sketch of seq[0..n), n <= 128, by one full wave.  Lane l encodes bases 2l and 2l+1;
 // 8 lanes form one 16-base word (2 bits per base, first base in the top bits), 16 lanes
 // one 32-base ambiguity word.  Lane l then owns the k-mers starting at l and l+64.
@@ -267,9 +284,13 @@ __device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, 
     u32 am = ((a0 << 1) | a1) << (30 - 2 * (lane & 15));
     am |= xor_lane<1>(am, lane); am |= xor_lane<2>(am, lane); am |= xor_lane<4>(am, lane); am |= xor_lane<8>(am, lane);
 
+    // a window with at most 64 k-mer start positions (the tail window of a read) needs only slot 0
+    const bool one_slot = cap <= 64;
     u32 h[2];
+    h[1] = MCQ_EMPTY;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        if (i == 1 && one_slot) break;
         u32 pos = lane + 64 * i;
         u32 wi = pos >> 4, sh = (pos & 15) * 2;
         u32 w0 = __shfl(w, (int)((wi * 8) & 63), 64);
@@ -300,7 +321,7 @@ __device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, 
         if (s1) tmp[n0 + (u32)__builtin_popcountll(m1 & below)] = h[1];
         wave_sync();
         u32 v = lane < cnt ? tmp[lane] : MCQ_EMPTY;
-        v = wave_sort64(v, lane);
+        v = (cnt <= 32) ? wave_sort32_low(v, lane) : wave_sort64(v, lane);     // 15 stages when the low half suffices
         u32 prev = __shfl_up(v, 1, 64);
         bool keep = (v != MCQ_EMPTY) && (lane == 0 || v != prev);
         u64 km = __ballot(keep);
