@@ -47,6 +47,10 @@ enum {
     MCQ_QUIRK_SEQ_DROP = 2u,    /* emulate the reference's u32 wire format: a sequence-
                                    level taxon (key bit 31 set) sent by a non-root rank
                                    is dropped (src/querying.h:958, :983-985)            */
+    MCQ_BATCH_RANGES = 8u,      /* mcq_batch.flags (device pointers only): seq_off holds 2*n_seqs
+                                   (begin,end) byte ranges into `bases` instead of n_seqs+1 offsets:
+                                   the sequences may sit anywhere in the buffer, e.g. inside raw
+                                   FASTQ text indexed by mcq_fastq_index                          */
     MCQ_FORCE_BLOCK_PATH = 0x100u, /* test hook: every query takes the workgroup path    */
     MCQ_DB_LOCS_64 = 0x200u     /* mcq_db_desc.flags: keep 64-bit locations in HBM even when
                                    (tgt,win) would fit the compact 32-bit form           */
@@ -202,6 +206,15 @@ uint32_t mcq_owner(uint32_t feature, uint32_t n_shards);
  * summed duration and launch count since enabling (synchronises the recorded events).   */
 int mcq_ws_timing(mcq_ws* ws, int enable);
 int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_launches);
+
+/* ---- row f4: FASTQ ingest on the GPU ------------------------------------------------
+ * text: raw FASTQ bytes in DEVICE memory (4 lines per record, as fastq_reader::read_next reads
+ * them: src/sequence_io.cpp:251-285).  Writes the (begin,end) byte range of every record's
+ * sequence line to seq_ranges[2*r], [2*r+1] (device, capacity 2*max_seqs) and the record count
+ * to *n_seqs_out (device).  Feed mcq_query with bases = text, seq_off = seq_ranges,
+ * flags = MCQ_DEVICE_PTRS | MCQ_BATCH_RANGES: the bases are read in place, never copied.  */
+int mcq_fastq_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs,
+                    uint64_t* n_seqs_out, void* stream);
 
 /* ---- debug / parity taps (rows 5 and 8 in isolation) ----------------------------- */
 /* sorted match list of every query: match_off[q..q+1) into matches (capacity cap)   */

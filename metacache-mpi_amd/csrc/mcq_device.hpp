@@ -43,11 +43,17 @@ struct DbDev {
 
 struct BatchDev {
     const char* bases;
-    const u64* seq_off;
+    const u64* seq_off;      // [n_seq+1] back-to-back, or [2*n_seq] (begin,end) pairs when `ranges`
     u64 n_seq;
     u64 nq;
     u32 paired;
+    u32 ranges;
 };
+// byte range [beg,end) of sequence a of the batch
+__device__ __forceinline__ void seq_bounds(const u64* seq_off, u32 ranges, u64 a, u64& beg, u64& end) {
+    if (ranges) { beg = seq_off[2 * a]; end = seq_off[2 * a + 1]; }
+    else { beg = seq_off[a]; end = seq_off[a + 1]; }
+}
 
 struct OptDev {
     u32 max_cand;            // M

@@ -257,9 +257,10 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? 8 : 5) void k_query_wave(D
     for (u64 q = (u64)blockIdx.x * 4 + wave; q < b.nq; q += nwaves) {
         const int stop = force_block >> 4;          // profiling hook: 0 = run everything
         const u64 a = b.paired ? 2 * q : q;
-        const u64 o0 = b.seq_off[a], o1 = b.seq_off[a + 1];
-        const u64 o2 = b.paired ? b.seq_off[a + 2] : o1;
-        const u64 l1 = o1 - o0, l2 = o2 - o1;
+        u64 o0, e0, o1, e1;
+        seq_bounds(b.seq_off, b.ranges, a, o0, e0);
+        if (b.paired) seq_bounds(b.seq_off, b.ranges, a + 1, o1, e1); else { o1 = e0; e1 = e0; }
+        const u64 l1 = e0 - o0, l2 = e1 - o1;
         bool ovf = (force_block & 1) || ((l1 | l2) >> 20) != 0;
         const u32 n1 = (u32)l1, n2 = (u32)l2;
         u32 nw1 = 0, nw2 = 0;
@@ -378,9 +379,10 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
     for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
         const u64 q = ovf_list[it];
         const u64 a = b.paired ? 2 * q : q;
-        const u64 o0 = b.seq_off[a], o1 = b.seq_off[a + 1];
-        const u64 o2 = b.paired ? b.seq_off[a + 2] : o1;
-        const u64 n1 = o1 - o0, n2 = o2 - o1;
+        u64 o0, e0, o1, e1;
+        seq_bounds(b.seq_off, b.ranges, a, o0, e0);
+        if (b.paired) seq_bounds(b.seq_off, b.ranges, a + 1, o1, e1); else { o1 = e0; e1 = e0; }
+        const u64 n1 = e0 - o0, n2 = e1 - o1;
         const u32 nw1 = num_windows(n1, W, S), nw2 = b.paired ? num_windows(n2, W, S) : 0;
         const u64 NW = (u64)nw1 + nw2;
         if (NW * db.s > sc.fmax) {                        // beyond the workspace: flag, no result
@@ -436,13 +438,13 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
 }
 
 // ------------------------------------------------------------------ staged kernels (sharded path, DB build)
-__global__ void k_count_windows(const u64* seq_off, u64 n_seqs, u32 W, u32 S, u64* cnt) {
+__global__ void k_count_windows(const u64* seq_off, u32 ranges, u64 n_seqs, u32 W, u32 S, u64* cnt) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_seqs) cnt[i] = num_windows(seq_off[i + 1] - seq_off[i], W, S);
+    if (i < n_seqs) { u64 bg, en; seq_bounds(seq_off, ranges, i, bg, en); cnt[i] = num_windows(en - bg, W, S); }
 }
 
 // one wave per window: window w belongs to the last sequence i with win_off[i] <= w
-__global__ __launch_bounds__(256) void k_sketch_windows(DbDev db, const char* bases, const u64* seq_off, u64 n_seqs,
+__global__ __launch_bounds__(256) void k_sketch_windows(DbDev db, const char* bases, const u64* seq_off, u32 ranges, u64 n_seqs,
                                                         const u64* win_off, u32* features, u32* n_feat) {
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -453,7 +455,8 @@ __global__ __launch_bounds__(256) void k_sketch_windows(DbDev db, const char* ba
     for (u64 w = (u64)blockIdx.x * 4 + wave; w < n_win; w += nwaves) {
         u64 lo = 0, hi = n_seqs;
         while (hi - lo > 1) { u64 mid = (lo + hi) >> 1; if (win_off[mid] <= w) lo = mid; else hi = mid; }
-        const u64 o0 = seq_off[lo], n = seq_off[lo + 1] - o0;
+        u64 o0, oe; seq_bounds(seq_off, ranges, lo, o0, oe);
+        const u64 n = oe - o0;
         u64 beg; u32 wl;
         window_of(n, db.winlen, db.winstride, (u32)(w - win_off[lo]), beg, wl);
         u32 m = wave_sketch(bases + o0 + beg, wl, db.k, db.s, lane, sk, sk + 64);
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256) void k_sketch_windows(DbDev db, const char* ba
 }
 
 // one wave per sequence, looping over its (few) windows: no search, window math in 32 bits
-__global__ __launch_bounds__(256) void k_sketch_seqs(DbDev db, const char* bases, const u64* seq_off, u64 n_seqs,
+__global__ __launch_bounds__(256) void k_sketch_seqs(DbDev db, const char* bases, const u64* seq_off, u32 ranges, u64 n_seqs,
                                                      const u64* win_off, u32* features, u32* n_feat) {
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -472,8 +475,8 @@ __global__ __launch_bounds__(256) void k_sketch_seqs(DbDev db, const char* bases
     __shared__ u32 s_sk[4][128];
     u32* sk = s_sk[wave];
     for (u64 i = (u64)blockIdx.x * 4 + wave; i < n_seqs; i += nwaves) {
-        const u64 o0 = seq_off[i];
-        const u32 n = (u32)(seq_off[i + 1] - o0);
+        u64 o0, oe; seq_bounds(seq_off, ranges, i, o0, oe);
+        const u32 n = (u32)(oe - o0);
         const u64 w0 = win_off[i];
         const u32 nw = (u32)(win_off[i + 1] - w0);
         for (u32 j = 0; j < nw; ++j) {
@@ -721,14 +724,67 @@ __global__ void k_scatter_len(const u32* list_len, const u32* slot, u64 n, u32* 
     if (i < n) slot_len[slot[i]] = list_len[i];
 }
 // per query: location segment start = offset of its first feature slot; length = sum of its mates
-__global__ void k_query_offsets(u64 nq, u32 qstep, u32 s, const u64* win_off, const u64* seq_off, const u64* dst_off, u64 n_slots,
+__global__ void k_query_offsets(u64 nq, u32 qstep, u32 s, const u64* win_off, const u64* seq_off, u32 ranges, const u64* dst_off, u64 n_slots,
                                 u64* loc_off, u32* query_len) {
     const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (q < nq) {
         loc_off[q] = dst_off[win_off[q * qstep] * s];
-        query_len[q] = (u32)(seq_off[(q + 1) * qstep] - seq_off[q * qstep]);
+        u64 len = 0;
+        for (u32 m = 0; m < qstep; ++m) { u64 bg, en; seq_bounds(seq_off, ranges, q * qstep + m, bg, en); len += en - bg; }
+        query_len[q] = (u32)len;
     }
     if (q == 0) loc_off[nq] = dst_off[n_slots];
+}
+
+// ------------------------------------------------------------------ row f4: FASTQ text -> sequence ranges on the GPU
+// FASTQ is four lines per record and the reference reads it exactly so (fastq_reader::read_next,
+// src/sequence_io.cpp:251-285: getline header, getline data, getline '+', getline qualities), so
+// the sequence of record r is line 4r+1.  Workgroup tiles of 4 KiB count their newlines, a scan
+// gives every newline its line number, and the newline that ends line 4r (4r+1) writes the
+// begin (end) of sequence r.  The text is not copied: mcq_query reads the bases in place
+// (MCQ_BATCH_RANGES).  Like getline, a '\r' before the newline stays part of the line.
+#define MCQ_FQ_TILE 4096
+__global__ __launch_bounds__(256) void k_fq_count(const char* text, u64 n, u64* tile_cnt) {
+    __shared__ u32 s_c;
+    if (threadIdx.x == 0) s_c = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * MCQ_FQ_TILE + (u64)threadIdx.x * 16;
+    u32 c = 0;
+    for (u32 j = 0; j < 16; ++j) c += (base + j < n && text[base + j] == '\n');
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_c, c);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_c;
+}
+__global__ __launch_bounds__(256) void k_fq_ranges(const char* text, u64 n, const u64* tile_off, u64 n_tiles, u64* ranges, u64 max_seqs,
+                                                   u64* n_seqs_out) {
+    __shared__ u32 s_w[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = (u64)blockIdx.x * MCQ_FQ_TILE + (u64)tid * 16;
+    u32 c = 0;
+    for (u32 j = 0; j < 16; ++j) c += (base + j < n && text[base + j] == '\n');
+    u32 incl = wave_incl_scan(c, lane);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 w = 0; w < wave; ++w) woff += s_w[w];
+    u64 line = tile_off[blockIdx.x] + woff + incl - c;         // index of the line my first newline terminates
+    for (u32 j = 0; j < 16; ++j) {
+        const u64 p = base + j;
+        if (p < n && text[p] == '\n') {
+            const u64 rec = line >> 2;
+            if (rec < max_seqs) {
+                if ((line & 3) == 0) ranges[2 * rec] = p + 1;
+                else if ((line & 3) == 1) ranges[2 * rec + 1] = p;
+            }
+            ++line;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        const u64 total = tile_off[n_tiles];
+        u64 ns = (total + 2) / 4;                               // records whose sequence line is complete
+        *n_seqs_out = ns < max_seqs ? ns : max_seqs;
+    }
 }
 
 // ------------------------------------------------------------------ host helpers
@@ -996,6 +1052,8 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     if (nq > ws->max_queries) return fail(MCQ_E_ARG, "batch has more queries than the workspace allows");
     const bool dev_in = (in->flags & MCQ_DEVICE_PTRS) != 0, dev_out = (out->flags & MCQ_DEVICE_PTRS) != 0;
     BatchDev b; b.n_seq = in->n_seqs; b.nq = nq; b.paired = in->paired ? 1 : 0;
+    b.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
+    if (b.ranges && !dev_in) return fail(MCQ_E_ARG, "MCQ_BATCH_RANGES needs device pointers");
     OutDev o;
     u64 nbases = 0;
     if (!dev_in) {
@@ -1054,7 +1112,7 @@ extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* 
     HIPCHK(hipMemcpy(ws->d_seq_off, in->seq_off, (in->n_seqs + 1) * 8, hipMemcpyHostToDevice));
     mcq_query_opts qo; qo.max_cand = 1; qo.emulate_ranks = 1; qo.insert_size_max = 0; qo.flags = 0;
     OptDev od; rc = make_opt(&qo, od); if (rc) return rc;
-    BatchDev b; b.bases = ws->d_bases; b.seq_off = ws->d_seq_off; b.n_seq = in->n_seqs; b.nq = nq; b.paired = in->paired ? 1 : 0;
+    BatchDev b; b.bases = ws->d_bases; b.seq_off = ws->d_seq_off; b.n_seq = in->n_seqs; b.nq = nq; b.paired = in->paired ? 1 : 0; b.ranges = 0;
     OutDev o; o.cands = ws->d_cands; o.ncand = ws->d_ncand;
     u64 *d_cnt = nullptr, *d_off = nullptr, *d_m = nullptr;
     HIPCHK(hipMalloc(&d_cnt, std::max<u64>(1, nq) * 8));
@@ -1089,7 +1147,7 @@ extern "C" int mcq_count_windows(const mcq_db* db, const mcq_batch* in, uint64_t
     const u64 n = in->n_seqs;
     u64* cnt = nullptr;
     HIPCHK(hipMallocAsync((void**)&cnt, std::max<u64>(1, n) * 8, st));
-    if (n) hipLaunchKernelGGL(k_count_windows, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, in->seq_off, n, db->d.winlen, db->d.winstride, cnt);
+    if (n) hipLaunchKernelGGL(k_count_windows, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, in->seq_off, (in->flags & MCQ_BATCH_RANGES) ? 1u : 0u, n, db->d.winlen, db->d.winstride, cnt);
     { int rcs = device_exclusive_scan<u64>((const u64*)cnt, win_off, n, st); if (rcs) return rcs; }
     HIPCHK(hipFreeAsync(cnt, st));
     HIPCHK(hipGetLastError());
@@ -1106,10 +1164,10 @@ extern "C" int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t*
     if (in->n_seqs >= 4096) {
         u32 grid = (u32)std::min<u64>((in->n_seqs + 3) / 4, 256ull * 32);
         hipLaunchKernelGGL(k_sketch_seqs, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, in->bases, in->seq_off,
-                           in->n_seqs, win_off, features, n_feat);
+                           (in->flags & MCQ_BATCH_RANGES) ? 1u : 0u, in->n_seqs, win_off, features, n_feat);
     } else {
         hipLaunchKernelGGL(k_sketch_windows, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, db->d, in->bases, in->seq_off,
-                           in->n_seqs, win_off, features, n_feat);
+                           (in->flags & MCQ_BATCH_RANGES) ? 1u : 0u, in->n_seqs, win_off, features, n_feat);
     }
     HIPCHK(hipGetLastError());
     return MCQ_OK;
@@ -1168,7 +1226,7 @@ extern "C" int mcq_assemble(const mcq_db* db, uint64_t n_lists, const uint32_t* 
         else               hipLaunchKernelGGL(k_scatter_lists<u64>, dim3(grid), dim3(256), 0, st, n_lists, (const u64*)src_off, src_slot, (const u64*)dst_off, (const u64*)src_locs, (u64*)dst_locs);
     }
     hipLaunchKernelGGL(k_query_offsets, dim3((u32)((nq + 256) / 256)), dim3(256), 0, st, nq, in->paired ? 2u : 1u, db->d.s, win_off,
-                       in->seq_off, (const u64*)dst_off, n_slots, loc_off, query_len);
+                       in->seq_off, (in->flags & MCQ_BATCH_RANGES) ? 1u : 0u, (const u64*)dst_off, n_slots, loc_off, query_len);
     HIPCHK(hipFreeAsync(slot_len, st)); HIPCHK(hipFreeAsync(dst_off, st)); HIPCHK(hipFreeAsync(src_off, st));
     HIPCHK(hipGetLastError());
     return MCQ_OK;
@@ -1251,6 +1309,24 @@ extern "C" int mcq_bucket_features(const uint32_t* features, uint64_t n, uint32_
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, st, blk, n_shards, grid, (unsigned long long*)counts);
     hipLaunchKernelGGL(k_bucket_fill, dim3(grid), dim3(256), 0, st, features, n, n_shards, tile, (const unsigned long long*)blk, bucketed, src_index);
     HIPCHK(hipFreeAsync(blk, st));
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+// ------------------------------------------------------------------ row f4 entry point
+extern "C" int mcq_fastq_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs,
+                               uint64_t* n_seqs_out, void* stream) {
+    if (!seq_ranges || !n_seqs_out || (n_bytes && !text)) return fail(MCQ_E_ARG, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const u64 n_tiles = std::max<u64>(1, (n_bytes + MCQ_FQ_TILE - 1) / MCQ_FQ_TILE);
+    if (n_tiles >= (1ull << 31)) return fail(MCQ_E_UNSUPPORTED, "text too large for one call");
+    u64 *cnt = nullptr, *off = nullptr;
+    HIPCHK(hipMallocAsync((void**)&cnt, n_tiles * 8, st));
+    HIPCHK(hipMallocAsync((void**)&off, (n_tiles + 1) * 8, st));
+    hipLaunchKernelGGL(k_fq_count, dim3((u32)n_tiles), dim3(256), 0, st, text, n_bytes, cnt);
+    int rc = device_exclusive_scan<u64>((const u64*)cnt, off, n_tiles, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_fq_ranges, dim3((u32)n_tiles), dim3(256), 0, st, text, n_bytes, (const u64*)off, n_tiles, seq_ranges, max_seqs, n_seqs_out);
+    HIPCHK(hipFreeAsync(cnt, st)); HIPCHK(hipFreeAsync(off, st));
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }

@@ -12,6 +12,7 @@ from .build import lib_path
 
 MCQ_DEVICE_PTRS = 1
 MCQ_QUIRK_SEQ_DROP = 2
+MCQ_BATCH_RANGES = 8             # seq_off = (begin,end) pairs into `bases` (device pointers only)
 MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-query path
 MCQ_DB_LOCS_64 = 0x200           # Database(flags=...): keep 64-bit locations
 
@@ -87,6 +88,7 @@ def lib():
         L.mcq_bucket_features.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Batch),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mcq_fastq_index.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         _lib = L
@@ -215,8 +217,8 @@ class Workspace:
 
     # ---- device-buffer call: raw pointers, enqueue only --------------------------
     def query_device(self, bases_ptr, seq_off_ptr, n_seqs, paired, cands_ptr, ncand_ptr, max_cand=2,
-                     emulate_ranks=1, insert_size_max=0, flags=0, stream=None):
-        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 1 if paired else 0, MCQ_DEVICE_PTRS)
+                     emulate_ranks=1, insert_size_max=0, flags=0, stream=None, ranges=False):
+        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 1 if paired else 0, MCQ_DEVICE_PTRS | (MCQ_BATCH_RANGES if ranges else 0))
         o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
         r = Result(cands_ptr, ncand_ptr, MCQ_DEVICE_PTRS)
         _chk(lib().mcq_query(self.db.h, self.h, C.byref(b), C.byref(o), C.byref(r), stream))
@@ -250,6 +252,11 @@ class Workspace:
 
 def bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream=None):
     _chk(lib().mcq_bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream))
+
+
+def fastq_index(text_ptr, n_bytes, ranges_ptr, max_seqs, n_seqs_ptr, stream=None):
+    """raw FASTQ text in HBM -> (begin,end) ranges of the sequence lines (device buffers)"""
+    _chk(lib().mcq_fastq_index(text_ptr, n_bytes, ranges_ptr, max_seqs, n_seqs_ptr, stream))
 
 
 def owner(feature, n_shards):
