@@ -88,7 +88,6 @@ def main():
     pkg = importlib.import_module("metacache-mpi_amd")
     pkg.build_hip()
     eng = importlib.import_module("metacache-mpi_amd.engine")
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
     synth = importlib.import_module("metacache-mpi_amd.synth")
 
     # N > 1: the table of this workload fits one MI355X many times over (288 GB HBM), so the reads are split and the
@@ -106,11 +105,27 @@ def main():
     t_setup = time.time()
     gen_bases, gen_off, species = synth.make_genomes(a.species, a.strains, a.genome_min, a.genome_max,
                                                      a.divergence, seed=3, device=dev)
-    keys, list_off, locs, _ = dbbuild.build_table(gen_bases, gen_off, emulate_ranks=a.emulate_ranks)
+    # table built on the GPU through the C ABI (mcq_build_table, csrc/mcq_build.hip)
+    t_build = time.time()
+    table = eng.Table(gen_bases.data_ptr(), gen_off.data_ptr(), gen_off.numel() - 1, emulate_ranks=a.emulate_ranks,
+                      device=dev.index or 0)
+    torch.cuda.synchronize(dev)
+    t_build = time.time() - t_build
+    sp32 = species.to(torch.int32).contiguous()
+
+    def make_db(n_shards=1, shard_id=0):
+        return eng.Database(None, None, None, None, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0,
+                            device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr,
+                                             tgt2tax=sp32.data_ptr(), n_keys=table.n_keys, n_locs=table.n_locs,
+                                             n_targets=sp32.numel()))
     # full table on every rank (fused single-GPU path / replicas); plus this rank's hash-range shard when sharding
-    db = dbbuild.make_database(keys, list_off, locs, species)
-    db_shard = dbbuild.make_database(keys, list_off, locs, species, n_shards=world, shard_id=rank) if with_sharded_leg else None
-    n_keys, n_locs, n_targets = keys.numel(), locs.numel(), species.numel()
+    db = make_db()
+    db_shard = make_db(world, rank) if with_sharded_leg else None
+    n_keys, n_locs, n_targets = table.n_keys, table.n_locs, species.numel()
+    keys, list_off, locs = (None, None, None)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stop_stage:
+        keys, list_off, locs, _ = table.to_host()       # only the CPU baseline (the checker) reads these
+    table.close()
     db_bp = int(gen_off[-1].item())
 
     # ---- reads (distinct batches, resident in HBM before the clock starts)
@@ -217,7 +232,7 @@ def main():
             "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "distinct_batches": nb,
             "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
                             "sharded": "feature table hash-range-sharded over %d GPUs, all-to-all of features and hits" % world}[mode],
-            "setup_s": round(t_setup, 1),
+            "setup_s": round(t_setup, 1), "db_build_s": round(t_build, 3),
         },
     }
     if sharded_elapsed is not None:
@@ -286,8 +301,7 @@ def cpu_baseline(a, keys, list_off, locs, species, batches, offsets, first, cand
     from oracle import mc_oracle as orc
     aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(aff, a.cpu_threads))
-    odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), list_off.cpu().numpy().astype(np.uint64),
-                       locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
+    odb = orc.OracleDb(keys, list_off, locs, species.cpu().numpy().astype(np.uint32))
     nq = B // 2 if paired else B
     total_t, total_n, ok, nb = 0.0, 0, None, len(batches)
     i = first

@@ -216,6 +216,38 @@ int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_launches);
 int mcq_fastq_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs,
                     uint64_t* n_seqs_out, void* stream);
 
+/* ---- row f2: building the table from reference sequences on the GPU -----------------
+ * Replaces the build-side loop add_all_window_sketches (src/sketch_database.h:1079-1097) with
+ * target t inserted on rank t % P (src/sketch_database.h:540-542): every window of every target is
+ * sketched, and per (feature, rank) the first max_locs locations in (target, window) order are
+ * kept (src/sketch_database.h:1090-1092, bucket limit 254).  The result is the union of the P rank
+ * tables in the layout mcq_db_desc takes.  Target sketching uses (k, sketch_size, winlen,
+ * winstride); target t = bases[seq_off[t] .. seq_off[t+1]).                                   */
+typedef struct {
+    uint32_t k, sketch_size, winlen, winstride;
+    uint32_t n_targets;
+    const char* bases;            /* host, or device with MCQ_DEVICE_PTRS                     */
+    const uint64_t* seq_off;      /* [n_targets+1]                                            */
+    const uint32_t* tgt2tax;      /* [n_targets]; only mcq_db_build reads it                  */
+    uint32_t emulate_ranks;       /* P of the build being reproduced (0 = 1)                  */
+    uint32_t max_locs;            /* per (feature, rank); 0 = 254                             */
+    uint32_t n_shards, shard_id;  /* mcq_db_build: as in mcq_db_desc                          */
+    uint32_t flags;               /* MCQ_DEVICE_PTRS, MCQ_DB_LOCS_64                          */
+    int32_t device;
+} mcq_build_desc;
+
+typedef struct mcq_table mcq_table;   /* keys / list_off / locs in device memory */
+
+int mcq_build_table(const mcq_build_desc* desc, mcq_table** out);
+/* device pointers into the table (valid until mcq_table_free); any out pointer may be NULL.
+ * win_off[n_targets+1] = first global window of every target.                               */
+int mcq_table_info(const mcq_table* t, uint64_t* n_keys, uint64_t* n_locs, const uint32_t** keys,
+                   const uint64_t** list_off, const uint64_t** locs, const uint64_t** win_off);
+int mcq_table_free(mcq_table* t);
+/* mcq_build_table + mcq_db_create in one call; the queryable handle is the only thing left in HBM */
+int mcq_db_build(const mcq_build_desc* desc, mcq_db** out);
+const char* mcq_build_last_error(void);
+
 /* ---- debug / parity taps (rows 5 and 8 in isolation) ----------------------------- */
 /* sorted match list of every query: match_off[q..q+1) into matches (capacity cap)   */
 int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* in,

@@ -3,9 +3,13 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SRC = [os.path.join(_HERE, "csrc", "mcq_engine.hip")]
-_DEPS = _SRC + [os.path.join(_HERE, "csrc", "mcq_device.hpp"),
-                os.path.join(os.path.dirname(_HERE), "include", "mcq.h")]
+_HDR = os.path.join(os.path.dirname(_HERE), "include", "mcq.h")
+# translation unit -> what it depends on besides itself
+_UNITS = {
+    os.path.join(_HERE, "csrc", "mcq_engine.hip"): [os.path.join(_HERE, "csrc", "mcq_device.hpp"), _HDR],
+    os.path.join(_HERE, "csrc", "mcq_build.hip"): [_HDR],       # table construction (rocPRIM sorts)
+}
+_OBJ = os.path.join(_HERE, "csrc", "_obj")
 
 
 def lib_path():
@@ -44,12 +48,26 @@ def build_host(force=False, verbose=False):
 
 
 def build_hip(force=False, verbose=False):
+    """hipcc every unit of csrc/ for gfx950 into csrc/_obj/*.o, link libmcq_hip.so"""
     out = lib_path()
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _DEPS):
-        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + _SRC + ["-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    os.makedirs(_OBJ, exist_ok=True)
+    objs, relink = [], force or not os.path.exists(out)
+    for src, deps in _UNITS.items():
+        obj = os.path.join(_OBJ, os.path.basename(src) + ".o")
+        objs.append(obj)
+        newest = max(os.path.getmtime(f) for f in [src] + deps)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            relink = True
+        elif os.path.exists(out) and os.path.getmtime(out) < os.path.getmtime(obj):
+            relink = True
+    if relink:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return out

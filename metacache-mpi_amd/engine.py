@@ -33,6 +33,13 @@ class DbDesc(C.Structure):
                 ("loc_win_bits", C.c_uint32)]
 
 
+class BuildDesc(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("sketch_size", C.c_uint32), ("winlen", C.c_uint32), ("winstride", C.c_uint32),
+                ("n_targets", C.c_uint32), ("bases", C.c_void_p), ("seq_off", C.c_void_p), ("tgt2tax", C.c_void_p),
+                ("emulate_ranks", C.c_uint32), ("max_locs", C.c_uint32), ("n_shards", C.c_uint32),
+                ("shard_id", C.c_uint32), ("flags", C.c_uint32), ("device", C.c_int32)]
+
+
 class Batch(C.Structure):
     _fields_ = [("n_seqs", C.c_uint64), ("bases", C.c_void_p), ("seq_off", C.c_void_p),
                 ("paired", C.c_uint32), ("flags", C.c_uint32)]
@@ -89,6 +96,11 @@ def lib():
         L.mcq_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Batch),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_fastq_index.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.mcq_build_table.argtypes = [C.POINTER(BuildDesc), C.POINTER(C.c_void_p)]
+        L.mcq_db_build.argtypes = [C.POINTER(BuildDesc), C.POINTER(C.c_void_p)]
+        L.mcq_table_info.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.mcq_table_free.argtypes = [C.c_void_p]
+        L.mcq_build_last_error.restype = C.c_char_p
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         _lib = L
@@ -134,6 +146,21 @@ class Database:
         h = C.c_void_p()
         _chk(lib().mcq_db_create(C.byref(d), C.byref(h)))
         self.h = h
+
+    @classmethod
+    def build(cls, bases_ptr, seq_off_ptr, tgt2tax_ptr, n_targets, emulate_ranks=1, k=16, sketch_size=16, winlen=128,
+              winstride=113, max_locs=0, n_shards=1, shard_id=0, device=0, flags=0, device_ptrs=True):
+        """mcq_db_build: reference sequences -> queryable handle, all on the GPU"""
+        d = _build_desc(bases_ptr, seq_off_ptr, tgt2tax_ptr, n_targets, emulate_ranks, k, sketch_size, winlen, winstride,
+                        max_locs, n_shards, shard_id, device, flags, device_ptrs)
+        self = cls.__new__(cls)
+        self.k, self.sketch_size, self.winlen, self.winstride, self.device = k, sketch_size, winlen, winstride, device
+        h = C.c_void_p()
+        rc = lib().mcq_db_build(C.byref(d), C.byref(h))
+        if rc != 0:
+            raise McqError(rc, (lib().mcq_build_last_error() or b"").decode())
+        self.h = h
+        return self
 
     def bytes(self):
         return int(lib().mcq_db_bytes(self.h))
@@ -252,6 +279,60 @@ class Workspace:
 
 def bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream=None):
     _chk(lib().mcq_bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream))
+
+
+def _build_desc(bases_ptr, seq_off_ptr, tgt2tax_ptr, n_targets, emulate_ranks, k, sketch_size, winlen, winstride,
+                max_locs, n_shards, shard_id, device, flags, device_ptrs):
+    d = BuildDesc()
+    d.k, d.sketch_size, d.winlen, d.winstride, d.n_targets = k, sketch_size, winlen, winstride, n_targets
+    d.bases, d.seq_off, d.tgt2tax = bases_ptr, seq_off_ptr, tgt2tax_ptr
+    d.emulate_ranks, d.max_locs, d.n_shards, d.shard_id, d.device = emulate_ranks, max_locs, n_shards, shard_id, device
+    d.flags = flags | (MCQ_DEVICE_PTRS if device_ptrs else 0)
+    return d
+
+
+class Table:
+    """mcq_build_table: keys / list_off / locs of the union table as device arrays"""
+
+    def __init__(self, bases_ptr, seq_off_ptr, n_targets, emulate_ranks=1, k=16, sketch_size=16, winlen=128, winstride=113,
+                 max_locs=0, device=0, device_ptrs=True):
+        d = _build_desc(bases_ptr, seq_off_ptr, None, n_targets, emulate_ranks, k, sketch_size, winlen, winstride,
+                        max_locs, 1, 0, device, 0, device_ptrs)
+        h = C.c_void_p()
+        rc = lib().mcq_build_table(C.byref(d), C.byref(h))
+        if rc != 0:
+            raise McqError(rc, (lib().mcq_build_last_error() or b"").decode())
+        self.h, self.n_targets, self.device = h, n_targets, device
+        nk, nl = C.c_uint64(), C.c_uint64()
+        pk, po, pl, pw = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _chk(lib().mcq_table_info(h, C.cast(C.byref(nk), C.c_void_p), C.cast(C.byref(nl), C.c_void_p),
+                                  C.cast(C.byref(pk), C.c_void_p), C.cast(C.byref(po), C.c_void_p),
+                                  C.cast(C.byref(pl), C.c_void_p), C.cast(C.byref(pw), C.c_void_p)))
+        self.n_keys, self.n_locs = int(nk.value), int(nl.value)
+        self.keys_ptr, self.list_off_ptr, self.locs_ptr, self.win_off_ptr = pk.value, po.value, pl.value, pw.value
+
+    def to_host(self):
+        """(keys u32, list_off u64, locs u64, win_off u64) as numpy arrays (hipMemcpy device -> host)"""
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+        def pull(ptr, n, dt):
+            out = np.empty(n, dt)
+            if n and hip.hipMemcpy(_np_ptr(out), ptr, out.nbytes, 2) != 0:      # hipMemcpyDeviceToHost
+                raise McqError(MCQ_E_HIP, "hipMemcpy of a table array failed")
+            return out
+        return (pull(self.keys_ptr, self.n_keys, np.uint32), pull(self.list_off_ptr, self.n_keys + 1, np.uint64),
+                pull(self.locs_ptr, self.n_locs, np.uint64), pull(self.win_off_ptr, self.n_targets + 1, np.uint64))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcq_table_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def fastq_index(text_ptr, n_bytes, ranges_ptr, max_seqs, n_seqs_ptr, stream=None):

@@ -64,3 +64,74 @@ def test_truncation_to_254_per_virtual_rank():
             for r in range(P):
                 assert (lst % P == r).sum() <= 254
         assert n.max() == (254 if P == 1 else 254 + min(254, 399 - 0))   # ranks: targets {0,2} and {1}
+
+
+# ---- the same through the C ABI (mcq_build_table / mcq_db_build, csrc/mcq_build.hip) -------------
+
+@pytest.mark.parametrize("tag,P", [("mini", 2), ("mini", 4), ("mini", 8), ("tie", 4), ("noanc", 2)])
+def test_abi_table_equals_reference_shards(tag, P):
+    engine = importlib.import_module("metacache-mpi_amd.engine")
+    dev = torch.device("cuda", 0)
+    fx = Fixture(tag, P)
+    bases, off = _load_genomes(tag, dev)
+    tb = engine.Table(bases.data_ptr(), off.data_ptr(), off.numel() - 1, emulate_ranks=P)
+    keys, loff, locs, _ = tb.to_host()
+    rk, ro, rl = dbfile.union_shards(fx.shards)
+    assert np.array_equal(keys, rk)
+    assert np.array_equal(loff, ro)
+    assert np.array_equal(locs, rl)
+    tb.close()
+
+
+def test_abi_table_host_pointers_and_truncation():
+    engine = importlib.import_module("metacache-mpi_amd.engine")
+    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    unit = rng.choice(list(b"ACGT"), 113).astype(np.uint8)
+    g = np.tile(unit, 400)
+    extra = rng.choice(list(b"ACGTN"), 5000, p=[.24, .24, .24, .24, .04]).astype(np.uint8)
+    seqs = [g.tobytes(), g.tobytes(), extra.tobytes(), g.tobytes(), b"ACGT"]      # a target shorter than k as well
+    off = np.zeros(len(seqs) + 1, np.uint64); off[1:] = np.cumsum([len(s) for s in seqs])
+    host = np.frombuffer(b"".join(seqs), dtype=np.uint8).copy()
+    bases = torch.from_numpy(host).to(dev)
+    for P in (1, 2, 3):
+        tb = engine.Table(host.ctypes.data, off.ctypes.data, len(seqs), emulate_ranks=P, device_ptrs=False)
+        keys, loff, locs, win_off = tb.to_host()
+        k2, o2, l2, w2 = dbbuild.build_table(bases, torch.from_numpy(off.astype(np.int64)).to(dev), emulate_ranks=P)
+        assert np.array_equal(keys, k2.cpu().numpy().astype(np.uint32))
+        assert np.array_equal(loff, o2.cpu().numpy().astype(np.uint64))
+        assert np.array_equal(locs, l2.cpu().numpy().astype(np.uint64))
+        assert np.array_equal(win_off, w2.cpu().numpy().astype(np.uint64))
+        tb.close()
+
+
+@pytest.mark.parametrize("flags", [0, 0x200])
+@pytest.mark.parametrize("tag,P", [("mini", 4), ("tie", 2)])
+def test_abi_db_build_queries_like_the_reference(tag, P, flags):
+    """mcq_db_build from the fixture genomes, then the fixture reads: the top hits the reference's
+    own `mpiexec -n P` run printed (final.json)"""
+    engine = importlib.import_module("metacache-mpi_amd.engine")
+    from oracle import mc_oracle as orc
+    dev = torch.device("cuda", 0)
+    fx = Fixture(tag, P)
+    bases, off = _load_genomes(tag, dev)
+    t2t = torch.from_numpy(np.asarray(fx.tgt2tax(), np.uint32).view(np.int32).copy()).to(dev)
+    db = engine.Database.build(bases.data_ptr(), off.data_ptr(), t2t.data_ptr(), off.numel() - 1, emulate_ranks=P, flags=flags)
+    assert db.loc_bytes() == (8 if flags else 4)
+    rb, ro = orc.pack_reads(fx.interleaved())
+    ws = engine.Workspace(db, len(fx.names), len(rb))
+    cands, ncand = ws.query_host(rb, ro, True, max_cand=fx.maxcand, emulate_ranks=P, flags=engine.MCQ_QUIRK_SEQ_DROP)
+    for q, name in enumerate(fx.names):
+        mine = [[fx.tax.id_of_key(c[0]), int(c[1])] for c in cands[q, :ncand[q]]]
+        assert mine == fx.final[name]["tophits"], (name, mine, fx.final[name])
+
+
+def test_abi_build_rejects_bad_arguments():
+    engine = importlib.import_module("metacache-mpi_amd.engine")
+    host = np.frombuffer(b"ACGTACGTACGTACGTACGTACGT", dtype=np.uint8).copy()
+    off = np.array([0, 24], np.uint64)
+    with pytest.raises(engine.McqError):
+        engine.Table(host.ctypes.data, off.ctypes.data, 1, k=40, device_ptrs=False)       # k > 32
+    with pytest.raises(engine.McqError):
+        engine.Table(host.ctypes.data, off.ctypes.data, 0, device_ptrs=False)             # no targets
