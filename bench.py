@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only to rehearse N>1 on a box with one GPU")
     ap.add_argument("--no-sharded-leg", action="store_true", help="N>1: skip the extra sharded (all-to-all) measurement")
+    ap.add_argument("--sharded-timeout", type=int, default=150, help="seconds the sharded leg may take before the run ends without it")
     ap.add_argument("--small", action="store_true", help="tiny DB / few reads (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -203,67 +204,85 @@ def main():
     st = ws.sync()
     kms, kn = ws.kernel_time()
     ws.timing(False)
+    def make_line(mode, sharded_elapsed, sharded_error, sh_stats):
+        if mode == "sharded" and sharded_elapsed is None:
+            mode = "replicas" if world > 1 else "single"
+        elapsed = sharded_elapsed if mode == "sharded" else fused_elapsed
+
+        total_reads = a.steps * B * world          # paired-end: each mate counts (src/printing.cpp:626-627)
+        value = total_reads / elapsed
+        out = {
+            "metric": "query reads/sec (whole node)", "value": value, "unit": "reads/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {
+                "workload": "%s: %d synthetic genomes (%d species x %d strains, %.1f%% divergence, %.2f Gbp) in HBM, %s per step per GPU, "
+                            "k=16 s=16 w=128/113" %
+                            ({"c2": "BASELINE configs[1]", "paired": "BASELINE configs[3] shape on the 1-GPU DB",
+                              "long": "BASELINE configs[4] shape on the 1-GPU DB"}[a.workload],
+                             n_targets, a.species, a.strains, 100 * a.divergence, db_bp / 1e9,
+                             {"c2": "%d x %d bp single-end reads" % (B, L), "paired": "%d reads = %d pairs of 2x%d bp" % (B, B // 2, L),
+                              "long": "%d ONT-like reads, mean %d bp, 8%% substitutions" % (B, a.long_mean)}[a.workload]),
+                "reads_total": total_reads, "db_keys": n_keys, "db_locations": n_locs, "db_hbm_bytes": db.bytes(),
+                "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "distinct_batches": nb,
+                "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
+                                "sharded": "feature table hash-range-sharded over %d GPUs, all-to-all of features and hits" % world}[mode],
+                "setup_s": round(t_setup, 1), "db_build_s": round(t_build, 3),
+            },
+        }
+        if sharded_elapsed is not None:
+            out["sharded_all_to_all"] = {"value": total_reads / sharded_elapsed, "unit": "reads/s", "ms_per_step": 1e3 * sharded_elapsed / a.steps,
+                                         "per_step_per_gpu": sh_stats,
+                                         "note": "same reads; feature table hash-range-sharded over %d GPU(s), features and hits exchanged by RCCL all-to-all" % world}
+        if mode == "sharded":
+            out["replicas_only"] = {"value": total_reads / fused_elapsed, "unit": "reads/s", "ms_per_step": 1e3 * fused_elapsed / a.steps,
+                                    "note": "same reads, table replicated on every GPU, fused kernel, no collective (the table fits one GPU)"}
+        if sharded_error:
+            out["sharded_error"] = sharded_error
+        if kn > 0:
+            traffic = None      # HBM bytes per launch from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                if a.workload == "c2" and not a.small:
+                    traffic = tj["hbm_bytes_per_launch"] * B / tj["reads_per_launch"]
+            except Exception:
+                traffic = None
+            algo = algorithmic_bytes(max_bases, st)
+            avg_ms = kms / kn
+            ach = algo / (avg_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "k_query_wave", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "traffic_source": "profiles/pmc_traffic.json (FETCH_SIZE+WRITE_SIZE of the committed rocprofv3 --pmc passes, uncorrected, see profiles/r01_fetch_calibration.txt)" if traffic else None,
+                               "binding_resource": "integer VALU issue (~1 wave64 instr / 4 cycles / SIMD, scripts/valu_rate.hip); HBM random-sector traffic is ~17% of peak",
+                               "kernel_note": "k_query_wave timed by HIP events on its stream (mcq_ws_timing); for --workload long the work is in k_query_block, timed by ms_per_step",
+                               "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": avg_ms, "launches_timed": kn,
+                               "bytes_per_read": algo / B,
+                               "per_launch": {k: st[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow")}}
+
+        return out
+
     sharded_elapsed, sharded_error, sh_stats = None, None, None
     if sharded is not None:
+        # The exchange runs on real xGMI only in the driver's multi-GPU runs.  Should a rank fail inside it and leave the
+        # others waiting in a collective, the watchdog prints the line of the leg already measured and ends every rank.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps(make_line("replicas" if world > 1 else "single", None,
+                                           "watchdog: sharded leg did not finish within %d s" % a.sharded_timeout, None)), flush=True)
+            sys.stderr.write("[bench rank %d] sharded leg timed out; exiting\n" % rank); sys.stderr.flush()
+            os._exit(0)
+        dog = threading.Timer(a.sharded_timeout, give_up)
+        dog.daemon = True
+        dog.start()
         try:
             sharded_elapsed = timed(step_sharded)
             sh_stats = sharded.last_stats()
         except Exception as e:          # keep the line; the replicas leg stands
             sharded_error = "%s: %s" % (type(e).__name__, str(e)[:300])
-    if mode == "sharded" and sharded_elapsed is None:
-        mode = "replicas" if world > 1 else "single"
-    elapsed = sharded_elapsed if mode == "sharded" else fused_elapsed
-
-    total_reads = a.steps * B * world          # paired-end: each mate counts (src/printing.cpp:626-627)
-    value = total_reads / elapsed
-    out = {
-        "metric": "query reads/sec (whole node)", "value": value, "unit": "reads/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {
-            "workload": "%s: %d synthetic genomes (%d species x %d strains, %.1f%% divergence, %.2f Gbp) in HBM, %s per step per GPU, "
-                        "k=16 s=16 w=128/113" %
-                        ({"c2": "BASELINE configs[1]", "paired": "BASELINE configs[3] shape on the 1-GPU DB",
-                          "long": "BASELINE configs[4] shape on the 1-GPU DB"}[a.workload],
-                         n_targets, a.species, a.strains, 100 * a.divergence, db_bp / 1e9,
-                         {"c2": "%d x %d bp single-end reads" % (B, L), "paired": "%d reads = %d pairs of 2x%d bp" % (B, B // 2, L),
-                          "long": "%d ONT-like reads, mean %d bp, 8%% substitutions" % (B, a.long_mean)}[a.workload]),
-            "reads_total": total_reads, "db_keys": n_keys, "db_locations": n_locs, "db_hbm_bytes": db.bytes(),
-            "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "distinct_batches": nb,
-            "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
-                            "sharded": "feature table hash-range-sharded over %d GPUs, all-to-all of features and hits" % world}[mode],
-            "setup_s": round(t_setup, 1), "db_build_s": round(t_build, 3),
-        },
-    }
-    if sharded_elapsed is not None:
-        out["sharded_all_to_all"] = {"value": total_reads / sharded_elapsed, "unit": "reads/s", "ms_per_step": 1e3 * sharded_elapsed / a.steps,
-                                     "per_step_per_gpu": sh_stats,
-                                     "note": "same reads; feature table hash-range-sharded over %d GPU(s), features and hits exchanged by RCCL all-to-all" % world}
-    if mode == "sharded":
-        out["replicas_only"] = {"value": total_reads / fused_elapsed, "unit": "reads/s", "ms_per_step": 1e3 * fused_elapsed / a.steps,
-                                "note": "same reads, table replicated on every GPU, fused kernel, no collective (the table fits one GPU)"}
-    if sharded_error:
-        out["sharded_error"] = sharded_error
-    if kn > 0:
-        traffic = None      # HBM bytes per launch from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if a.workload == "c2" and not a.small:
-                traffic = tj["hbm_bytes_per_launch"] * B / tj["reads_per_launch"]
-        except Exception:
-            traffic = None
-        algo = algorithmic_bytes(max_bases, st)
-        avg_ms = kms / kn
-        ach = algo / (avg_ms * 1e-3) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_query_wave", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                           "traffic_source": "profiles/pmc_traffic.json (FETCH_SIZE+WRITE_SIZE of the committed rocprofv3 --pmc passes, uncorrected, see profiles/r01_fetch_calibration.txt)" if traffic else None,
-                           "binding_resource": "integer VALU issue (~1 wave64 instr / 4 cycles / SIMD, scripts/valu_rate.hip); HBM random-sector traffic is ~17% of peak",
-                           "kernel_note": "k_query_wave timed by HIP events on its stream (mcq_ws_timing); for --workload long the work is in k_query_block, timed by ms_per_step",
-                           "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": avg_ms, "launches_timed": kn,
-                           "bytes_per_read": algo / B,
-                           "per_launch": {k: st[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow")}}
-
+        dog.cancel()
+    out = make_line(mode, sharded_elapsed, sharded_error, sh_stats)
     if a.stop_stage:
         out["INVALID_profiling_stop_stage"] = a.stop_stage
     if world == 1 and a.workload == "c2" and not a.stop_stage and not a.small:
@@ -288,9 +307,12 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches, offsets, (a.warmup + a.steps - 1) % nb,
                                            cands, ncand, B, paired)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1 or a.mode == "sharded":
         import torch.distributed as dist
+        if sharded_error:            # a rank that failed inside the exchange may have left its peers in a collective
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size 2 and 3 over gloo.  The routing of metacache-mpi_amd/
+"""N > 1 path on CPU: world_size 2, 3 and 8 over gloo.  The routing of metacache-mpi_amd/
 sharded.py (bucket by owner, all-to-all out and back, per-query reassembly) runs for
 real; the per-stage compute is supplied by the oracle.  The reassembled results must
 equal the reference CLI's output for the fixture."""
@@ -16,7 +16,7 @@ from golden_util import Fixture
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,tag,P", [(2, "mini", 4), (3, "tie", 2), (2, "noanc", 2)])
+@pytest.mark.parametrize("world,tag,P", [(2, "mini", 4), (3, "tie", 2), (2, "noanc", 2), (8, "mini", 8)])
 def test_sharded_routing_over_gloo(world, tag, P):
     fx = Fixture(tag, P)
     with tempfile.TemporaryDirectory() as d:
