@@ -494,6 +494,51 @@ __device__ __forceinline__ void sweep_targets_wave(const KeyT* buf, u32* H, u32 
     wave_sync();
 }
 
+// inclusive prefix sum over the wave on the VALU only: Hillis-Steele inside each row of 16 (row_shr
+// 1,2,4,8), then the row totals ripple through row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3)
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
+// Weighted form of sweep_targets_wave for a de-duplicated match list: SK[0..D) are the DISTINCT
+// sorted keys, WP[j] the inclusive prefix sum of their multiplicities.  A window range holds every
+// copy of the keys inside it, so hits(j) = WP[j] - WP[lo-1] with the same lower bound lo, and the
+// first range reaching the maximum ends at the same key as in the multiset sweep (the maximum over
+// the copies of one key is at its last copy; earlier keys still win ties).  Entry indices are now
+// indices of distinct keys: a monotone relabelling, so every later tie-break is unchanged.
+__device__ __forceinline__ void sweep_targets_weighted(const u32* SK, const u32* WP, u32* H, u32 D, u32 numWindows,
+                                                       u32 wb, u32 lane) {
+    const u32 winmask = (1u << wb) - 1;
+    for (u32 j = lane; j < D; j += 64) H[j] = 0;
+    wave_sync();
+    u32 carry_head = 0;
+    for (u32 base = 0; base < D; base += 64) {
+        const u32 j = base + lane;
+        const bool valid = j < D;
+        const u32 key = SK[valid ? j : D - 1];
+        const u32 prev = SK[(valid && j > 0) ? j - 1 : 0];
+        const bool head = valid && (j == 0 || (prev >> wb) != (key >> wb));
+        const u64 le = __ballot(head) & ((2ull << lane) - 1);
+        const u32 myhead = le ? base + (63u - (u32)__builtin_clzll(le)) : carry_head;
+        const u32 win = key & winmask;
+        const u32 lowkey = (key & ~winmask) | ((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+        u32 lo = myhead, hi = valid ? j : myhead;
+        while (lo < hi) { u32 mid = (lo + hi) >> 1; if (SK[mid] < lowkey) lo = mid + 1; else hi = mid; }
+        if (valid) {
+            const u32 h = WP[j] - (lo ? WP[lo - 1] : 0u);
+            atomicMax(&H[myhead], (h << 9) | (511u - j));
+        }
+        carry_head = bcast(myhead, 63);
+    }
+    wave_sync();
+}
+
 // window range [beg,end] of the best candidate whose packed word is hv (run head j0 irrelevant)
 template <class KeyT, class HT, int JB>
 __device__ __forceinline__ void best_range(const KeyT* buf, HT hv, u32 numWindows, u32 wb, u32& beg, u32& end) {

@@ -210,12 +210,10 @@ template <class KeyT> __device__ __forceinline__ u64 key_expand(KeyT k, u32 wb) 
     return ((u64)(k >> wb) << 32) | (u64)(k & winmask);
 }
 
-// Gather E*64 list elements into registers (r[e] = element e*64 + lane), sort them there,
-// and leave the sorted keys in the wave's LDS segment for the sweep.
+// Gather E*64 list elements into registers: r[e] = element e*64 + lane of the concatenated lists.
 // Element t belongs to the last feature lane j with pos_j <= t (6-step shuffle search).
 template <class KeyT, int E>
-__device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u32 T, u32 pos, u64 off, u32 lane, int stop) {
-    KeyT r[E];
+__device__ __forceinline__ void gather_regs(const DbDev& db, KeyT (&r)[E], u32 T, u32 pos, u64 off, u32 lane) {
     const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -233,9 +231,93 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
         r[e] = key_pad<KeyT>();
         if (t < T) r[e] = locs[(((u64)ohi << 32) | olo) + (tt - pj)];
     }
+}
+// ... sort them there and leave the sorted keys in the wave's LDS segment for the sweep.
+template <class KeyT, int E>
+__device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u32 T, u32 pos, u64 off, u32 lane, int stop) {
+    KeyT r[E];
+    gather_regs<KeyT, E>(db, r, T, pos, off, lane);
     if (stop != 3) wave_regsort<KeyT, E>(r, lane);
 #pragma unroll
     for (int e = 0; e < E; ++e) buf[e * 64 + lane] = r[e];
+}
+
+// ---- rows 8-9 on DISTINCT (tgt,win) keys (32-bit keys, T <= 192) ------------------------------
+// A read's match list repeats the same (target, window) many times (C2: 107 locations, 33 distinct),
+// and everything after the gather only needs the distinct keys and how often each occurs.  The wave
+// counts them in a 256-slot open-addressing table in its LDS segment (ds_cmpst claims a slot, ds_add
+// counts), the lanes that claimed a slot compact their keys, <= 128 distinct keys are sorted in one or
+// two registers per lane instead of 64*E raw locations, and the multiplicities come back by probing
+// the table with the sorted keys.  Output: SK[0..D) sorted distinct keys, WP[0..D) inclusive prefix
+// sums of the multiplicities (for sweep_targets_weighted).  Returns D, or ~0u when there are more
+// than 128 distinct keys: then the raw keys have been sorted into buf[] as gather_sort_store does.
+//   LDS: buf[0..256) table keys, buf[256..512) table counts, hits[0..256) compaction list then WP,
+//        hits[256..512) SK.
+__device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 24; }
+
+template <int E>
+__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane) {
+    u32 r[E];
+    gather_regs<u32, E>(db, r, T, pos, off, lane);
+    u32* tabkey = buf; u32* tabcnt = buf + 256; u32* list = hits; u32* WP = hits; u32* SK = hits + 256;
+    reinterpret_cast<uint4*>(tabkey)[lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
+    reinterpret_cast<uint4*>(tabcnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    wave_sync();
+    const u64 below = (1ull << lane) - 1;
+    u32 D = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 key = r[e];
+        bool created = false;
+        if ((u32)(e * 64) + lane < T) {
+            u32 slot = dedup_slot(key);
+            while (true) {                       // T <= 192 < 256 slots: an empty slot always exists
+                const u32 old = atomicCAS(&tabkey[slot], MCQ_EMPTY, key);
+                created = old == MCQ_EMPTY;
+                if (created || old == key) { atomicAdd(&tabcnt[slot], 1u); break; }
+                slot = (slot + 1) & 255u;
+            }
+        }
+        const u64 cm = __ballot(created);
+        if (created) list[D + (u32)__builtin_popcountll(cm & below)] = key;
+        D += (u32)__builtin_popcountll(cm);
+    }
+    wave_sync();
+    if (D > 128) {                               // rare: sort the raw keys the general way
+        constexpr int E2 = E == 3 ? 4 : E;
+        u32 r2[E2];
+#pragma unroll
+        for (int e = 0; e < E2; ++e) r2[e] = e < E ? r[e] : MCQ_EMPTY;
+        wave_regsort<u32, E2>(r2, lane);
+#pragma unroll
+        for (int e = 0; e < E2; ++e) buf[e * 64 + lane] = r2[e];
+        return ~0u;
+    }
+    if (D <= 64) {
+        u32 k = lane < D ? list[lane] : MCQ_EMPTY;
+        k = (D <= 32) ? wave_sort32_low(k, lane) : wave_sort64(k, lane);
+        u32 c = 0;
+        if (lane < D) { u32 slot = dedup_slot(k); while (tabkey[slot] != k) slot = (slot + 1) & 255u; c = tabcnt[slot]; }
+        const u32 incl = wave_incl_scan_dpp(c);
+        wave_sync();                             // list consumed: WP may overwrite it
+        SK[lane] = k; WP[lane] = incl;
+    } else {
+        u32 k[2];
+        k[0] = list[lane]; k[1] = (64 + lane < D) ? list[64 + lane] : MCQ_EMPTY;
+        wave_regsort<u32, 2>(k, lane);
+        u32 c[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            c[e] = 0;
+            if ((u32)(e * 64) + lane < D) { u32 slot = dedup_slot(k[e]); while (tabkey[slot] != k[e]) slot = (slot + 1) & 255u; c[e] = tabcnt[slot]; }
+        }
+        const u32 i0 = wave_incl_scan_dpp(c[0]);
+        const u32 i1 = wave_incl_scan_dpp(c[1]) + bcast(i0, 63);
+        wave_sync();
+        SK[lane] = k[0]; SK[64 + lane] = k[1]; WP[lane] = i0; WP[64 + lane] = i1;
+    }
+    wave_sync();                                 // table dead from here: buf[] becomes the sweep's H
+    return D;
 }
 
 template <class KeyT, int LCAP>
@@ -295,13 +377,30 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? 8 : 5) void k_query_wave(D
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
 
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
+        const u32 numWindows = range_width(l1 + l2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
+        if constexpr (sizeof(KeyT) == 4) {
+            if (T <= 192 && stop == 0 && !(force_block & 2)) {
+                u32 D;
+                if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, off, lane);
+                else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, off, lane);
+                else               D = gather_dedup_sort<3>(db, buf, hits, T, pos, off, lane);
+                if (D != ~0u) {
+                    sweep_targets_weighted(hits + 256, hits, buf, D, numWindows, db.wb, lane);
+                    st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, hits + 256, buf, D, numWindows, db.wb, q, lane);
+                } else {
+                    sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
+                    st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+                }
+                wave_sync();
+                continue;
+            }
+        }
         if (T <= 64)       gather_sort_store<KeyT, 1>(db, buf, T, pos, off, lane, stop);
         else if (T <= 128) gather_sort_store<KeyT, 2>(db, buf, T, pos, off, lane, stop);
         else if (T <= 256) gather_sort_store<KeyT, 4>(db, buf, T, pos, off, lane, stop);
         else               gather_sort_store<KeyT, 8>(db, buf, T, pos, off, lane, stop);
         wave_sync();
         if (stop == 3 || stop == 4) { if (buf[lane] == (KeyT)0x1234) out.ncand[q] = 1; continue; }
-        const u32 numWindows = range_width(l1 + l2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
         if (stop == 5) { if (hits[lane] == 0x12345u) out.ncand[q] = 1; continue; }
         st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
@@ -1070,7 +1169,7 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     if (!dev_out) { o.cands = ws->d_cands; o.ncand = ws->d_ncand; }
     else { o.cands = (u32*)out->cands; o.ncand = out->n_cand; }
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
-    rc = launch_query(db, ws, b, od, o, st, ((opt->flags & 0x100u) ? 1 : 0) | (int)((opt->flags >> 12) & 0xFu) << 4, dbg);
+    rc = launch_query(db, ws, b, od, o, st, ((opt->flags & MCQ_FORCE_BLOCK_PATH) ? 1 : 0) | ((opt->flags & MCQ_FORCE_RAW_SORT) ? 2 : 0) | (int)((opt->flags >> 12) & 0xFu) << 4, dbg);
     if (rc) return rc;
     if (!dev_out && nq) {
         HIPCHK(hipMemcpyAsync(out->cands, ws->d_cands, nq * od.max_cand * 16, hipMemcpyDeviceToHost, st));

@@ -15,6 +15,7 @@ MCQ_QUIRK_SEQ_DROP = 2
 MCQ_BATCH_RANGES = 8             # seq_off = (begin,end) pairs into `bases` (device pointers only)
 MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-query path
 MCQ_DB_LOCS_64 = 0x200           # Database(flags=...): keep 64-bit locations
+MCQ_FORCE_RAW_SORT = 0x400       # debug: wave path without the de-duplicating pass
 
 MCQ_OK, MCQ_E_ARG, MCQ_E_HIP, MCQ_E_CAPACITY, MCQ_E_UNSUPPORTED = 0, -1, -2, -3, -4
 

@@ -35,14 +35,14 @@ def _same(cands, ncand, oc, on):
 
 
 @pytest.mark.parametrize("tag,P", CASES)
-@pytest.mark.parametrize("block", [False, True], ids=["wave", "block"])
+@pytest.mark.parametrize("block", [False, True, "raw"], ids=["wave", "block", "wave-rawsort"])
 @pytest.mark.parametrize("locs64", [False, True], ids=["loc32", "loc64"])
 def test_final_vs_reference_cli(eng, tag, P, block, locs64):
     fx = Fixture(tag, P)
     db, odb = _dbs(eng, fx, flags=eng.MCQ_DB_LOCS_64 if locs64 else 0)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     ws = eng.Workspace(db, len(fx.names), len(bases))
-    flags = eng.MCQ_QUIRK_SEQ_DROP | (eng.MCQ_FORCE_BLOCK_PATH if block else 0)
+    flags = eng.MCQ_QUIRK_SEQ_DROP | {False: 0, True: eng.MCQ_FORCE_BLOCK_PATH, "raw": eng.MCQ_FORCE_RAW_SORT}[block]
     cands, ncand = ws.query_host(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=P, flags=flags)
     for q, name in enumerate(fx.names):
         mine = [[fx.tax.id_of_key(c[0]), int(c[1])] for c in cands[q, :ncand[q]]]
@@ -50,7 +50,7 @@ def test_final_vs_reference_cli(eng, tag, P, block, locs64):
     oc, on = odb.query(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=P, quirk_seq_drop=1)
     _same(cands, ncand, oc, on)
     st = ws.sync()
-    assert st["n_overflow"] == (len(fx.names) if block else st["n_overflow"])
+    assert st["n_overflow"] == (len(fx.names) if block is True else st["n_overflow"])
 
 
 @pytest.mark.parametrize("tag,P", [("mini", 2), ("mini", 8), ("tie", 4)])
@@ -62,7 +62,7 @@ def test_per_rank_candidates_with_positions(eng, tag, P):
     for r in range(P):
         db, odb = _dbs(eng, fx, [fx.shards[r]], flags=eng.MCQ_DB_LOCS_64 if r % 2 else 0)
         ws = eng.Workspace(db, len(fx.names), len(bases))
-        for flags in (0, eng.MCQ_FORCE_BLOCK_PATH):
+        for flags in (0, eng.MCQ_FORCE_BLOCK_PATH, eng.MCQ_FORCE_RAW_SORT):
             cands, ncand = ws.query_host(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=1, flags=flags)
             for q in range(len(fx.names)):
                 Cx = fx.ranks["C"][str(q)][str(r)]

@@ -50,6 +50,14 @@ def test_short_reads(world, P, M):
     _compare(cands, ncand, oc, on, "single-end P=%d M=%d" % (P, M))
     st = ws.sync()
     assert st["n_locations"] > 0
+    # the wave path without the de-duplicating pass (what 64-bit keys and T > 192 take)
+    cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P, flags=eng.MCQ_FORCE_RAW_SORT)
+    _compare(cands, ncand, oc, on, "single-end raw sort P=%d M=%d" % (P, M))
+    # wide window ranges (insertSizeMax far above the read length): long lower-bound searches
+    for ins in (700, 5000):
+        cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P, insert_size_max=ins)
+        oc2, on2 = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, insert_size_max=ins, threads=8)
+        _compare(cands, ncand, oc2, on2, "single-end insert_size_max=%d P=%d M=%d" % (ins, P, M))
     # paired: the same reads taken as mates
     cands, ncand = ws.query_host(rb, ro, True, max_cand=M, emulate_ranks=P)
     oc, on = odb.query(rb, ro, True, max_cand=M, emulate_ranks=P, threads=8)
