@@ -53,6 +53,8 @@ def parse():
                     help="c2 = BASELINE configs[1] (150 bp single-end); paired = 2x150 bp pairs (configs[3] shape); "
                          "long = ONT-like reads, mean 8 kb (configs[4] shape) -- the last two on the 1-GPU database")
     ap.add_argument("--stop-stage", type=int, default=0, help="profiling: stop the fused kernel after stage 1..5 (results invalid)")
+    ap.add_argument("--query-flags", type=lambda x: int(x, 0), default=0,
+                    help="experiments: extra mcq_query_opts.flags (0x400 raw sort); results stay exact")
     ap.add_argument("--distinct-batches", type=int, default=0, help="0 = one per step (capped by memory)")
     return ap.parse_args()
 
@@ -172,7 +174,7 @@ def main():
     def step_fused(i):
         r, ro = batches[i % nb], offsets[i % nb]
         ws.query_device(r.data_ptr(), ro.data_ptr(), B, paired, cands.data_ptr(), ncand.data_ptr(),
-                        max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=(a.stop_stage & 15) << 12, stream=stream)
+                        max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=((a.stop_stage & 15) << 12) | a.query_flags, stream=stream)
 
     def barrier():
         torch.cuda.synchronize(dev)

@@ -52,13 +52,15 @@ def build_hip(force=False, verbose=False):
     out = lib_path()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(_OBJ, exist_ok=True)
+    extra = os.environ.get("MCQ_HIPCC_FLAGS", "").split()      # tuning experiments, e.g. -DMCQ_WAVE_OCC=7
+    force = force or bool(extra)
     objs, relink = [], force or not os.path.exists(out)
     for src, deps in _UNITS.items():
         obj = os.path.join(_OBJ, os.path.basename(src) + ".o")
         objs.append(obj)
         newest = max(os.path.getmtime(f) for f in [src] + deps)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -269,15 +269,26 @@ __device__ __forceinline__ u32 wave_sort32_low(u32 v, u32 lane) {
 // (all values if c <= 64) are compacted to one per lane, sorted by a 21-stage in-register
 // bitonic network and de-duplicated.  If the filter let through more than 64 values or
 // fewer than s distinct ones, the exact repeated-wave-min selection runs instead.
-__device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, u32 k, u32 s,
-                                           u32 lane, u32* tmp, u32* dst) {
+// the two bases lane `lane` encodes for a window seq[0..n): positions 2*lane and 2*lane+1, as one
+// 16-bit word (low byte first; 'N' beyond the end).  One (unaligned) 2-byte load per lane.
+struct __attribute__((packed)) PackedU16 { unsigned short v; };
+__device__ __forceinline__ u32 window_chars2(const char* __restrict__ seq, u32 n, u32 lane) {
+    const u32 p = 2 * lane;
+    u32 c = (u32)'N' | ((u32)'N' << 8);
+    if (p + 1 < n) c = reinterpret_cast<const PackedU16*>(seq + p)->v;
+    else if (p < n) c = (u32)(unsigned char)seq[p] | ((u32)'N' << 8);
+    return c;
+}
+__device__ __forceinline__ void window_chars(const char* __restrict__ seq, u32 n, u32 lane, u32& c0, u32& c1) {
+    const u32 c = window_chars2(seq, n, lane);
+    c0 = c & 0xFFu; c1 = c >> 8;
+}
+
+// sketch of a window whose bases are already in registers (window_chars)
+__device__ __forceinline__ u32 wave_sketch_chars(u32 c0, u32 c1, u32 n, u32 k, u32 s, u32 lane, u32* tmp, u32* dst) {
     if (n < k) return 0;
     u32 cap = n - k + 1;
     u32 sl = s < cap ? s : cap;
-
-    u32 p = 2 * lane;
-    u32 c0 = (p < n) ? (u32)(unsigned char)seq[p] : (u32)'N';
-    u32 c1 = (p + 1 < n) ? (u32)(unsigned char)seq[p + 1] : (u32)'N';
     // A/a=0 C/c=1 G/g=2 T/t=3 (src/dna_encoding.h:326-336); anything else ambiguous
     u32 u0 = c0 & 0xDFu, u1 = c1 & 0xDFu;
     u32 x0 = (u0 >> 1) & 3u, x1 = (u1 >> 1) & 3u;
@@ -352,6 +363,14 @@ __device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, 
     }
     wave_sync();
     return m;
+}
+
+__device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, u32 k, u32 s,
+                                           u32 lane, u32* tmp, u32* dst) {
+    if (n < k) return 0;
+    u32 c0, c1;
+    window_chars(seq, n, lane, c0, c1);
+    return wave_sketch_chars(c0, c1, n, k, s, lane, tmp, dst);
 }
 
 // ------------------------------------------------------------------ row 6: probe

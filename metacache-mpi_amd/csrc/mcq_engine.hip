@@ -256,9 +256,7 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 __device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 24; }
 
 template <int E>
-__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane) {
-    u32 r[E];
-    gather_regs<u32, E>(db, r, T, pos, off, lane);
+__device__ __forceinline__ u32 dedup_sort(u32 (&r)[E], u32* buf, u32* hits, u32 T, u32 lane) {
     u32* tabkey = buf; u32* tabcnt = buf + 256; u32* list = hits; u32* WP = hits; u32* SK = hits + 256;
     reinterpret_cast<uint4*>(tabkey)[lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
     reinterpret_cast<uint4*>(tabcnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
@@ -319,9 +317,50 @@ __device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32*
     wave_sync();                                 // table dead from here: buf[] becomes the sweep's H
     return D;
 }
+template <int E>
+__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane) {
+    u32 r[E];
+    gather_regs<u32, E>(db, r, T, pos, off, lane);
+    return dedup_sort<E>(r, buf, hits, T, lane);
+}
 
+// geometry of one read (or pair) on the wave path
+struct ReadGeom {
+    u64 o0, o1;          // byte offsets of the mates
+    u32 n1, n2;          // their lengths
+    u32 nw1, nw2;        // their window counts
+    u64 qlen;            // l1 + l2
+    bool ovf;            // not for the wave path
+};
+__device__ __forceinline__ ReadGeom read_geom(const DbDev& db, const BatchDev& b, u64 q, int force_block) {
+    ReadGeom g;
+    const u64 a = b.paired ? 2 * q : q;
+    u64 e0, e1;
+    seq_bounds(b.seq_off, b.ranges, a, g.o0, e0);
+    if (b.paired) seq_bounds(b.seq_off, b.ranges, a + 1, g.o1, e1); else { g.o1 = e0; e1 = e0; }
+    const u64 l1 = e0 - g.o0, l2 = e1 - g.o1;
+    g.qlen = l1 + l2;
+    g.ovf = (force_block & 1) || ((l1 | l2) >> 20) != 0;
+    g.n1 = (u32)l1; g.n2 = (u32)l2; g.nw1 = 0; g.nw2 = 0;
+    if (!g.ovf) {
+        g.nw1 = num_windows32(g.n1, db.winlen, db.winstride, db.magic_stride);
+        g.nw2 = b.paired ? num_windows32(g.n2, db.winlen, db.winstride, db.magic_stride) : 0;
+        g.ovf = (g.nw1 + g.nw2) * db.s > 64;
+    }
+    return g;
+}
+// window w of the read (mate 1's windows, then mate 2's): offset into bases and length
+__device__ __forceinline__ void window_span(const DbDev& db, const ReadGeom& g, u32 w, u64& at, u32& wl) {
+    const bool m2 = w >= g.nw1;
+    u32 beg;
+    window_of32(m2 ? g.n2 : g.n1, db.winlen, db.winstride, db.magic_stride, m2 ? w - g.nw1 : w, beg, wl);
+    at = (m2 ? g.o1 : g.o0) + beg;
+}
+#ifndef MCQ_WAVE_OCC
+#define MCQ_WAVE_OCC 8          // waves per SIMD the 32-bit-key kernel is compiled for (tuning knob)
+#endif
 template <class KeyT, int LCAP>
-__global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? 8 : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
+__global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                     CountersDev* ctr, u32* ovf_list, int force_block) {
     static_assert(LCAP == 512, "wave path: 8 keys per lane at most, entry index packed into 9 bits");
     __shared__ KeyT s_buf[4][LCAP];
@@ -332,39 +371,26 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? 8 : 5) void k_query_wave(D
     u32* hits = s_hits[wave];
     u32* sk_tmp = hits;                // sketch scratch aliases the (not yet used) hit words
     u32* feat = hits + 64;
-    const u32 W = db.winlen, S = db.winstride;
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
+    const int stop = force_block >> 4;              // profiling hook: 0 = run everything
 
     for (u64 q = (u64)blockIdx.x * 4 + wave; q < b.nq; q += nwaves) {
-        const int stop = force_block >> 4;          // profiling hook: 0 = run everything
-        const u64 a = b.paired ? 2 * q : q;
-        u64 o0, e0, o1, e1;
-        seq_bounds(b.seq_off, b.ranges, a, o0, e0);
-        if (b.paired) seq_bounds(b.seq_off, b.ranges, a + 1, o1, e1); else { o1 = e0; e1 = e0; }
-        const u64 l1 = e0 - o0, l2 = e1 - o1;
-        bool ovf = (force_block & 1) || ((l1 | l2) >> 20) != 0;
-        const u32 n1 = (u32)l1, n2 = (u32)l2;
-        u32 nw1 = 0, nw2 = 0;
-        if (!ovf) {
-            nw1 = num_windows32(n1, W, S, db.magic_stride);
-            nw2 = b.paired ? num_windows32(n2, W, S, db.magic_stride) : 0;
-            ovf = (nw1 + nw2) * db.s > 64;
-        }
+        const ReadGeom g = read_geom(db, b, q, force_block);
+        bool ovf = g.ovf;
         u32 myf = MCQ_EMPTY, nfeat = 0, T = 0, len = 0, pos = 0;
         u64 off = 0;
         if (!ovf) {
-            for (u32 w = 0; w < nw1 + nw2; ++w) {
-                const bool m2 = w >= nw1;
-                u32 beg, wl;
-                window_of32(m2 ? n2 : n1, W, S, db.magic_stride, m2 ? w - nw1 : w, beg, wl);
-                nfeat += wave_sketch(b.bases + (m2 ? o1 : o0) + beg, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
+            for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
+                u64 at; u32 wl;
+                window_span(db, g, w, at, wl);
+                nfeat += wave_sketch(b.bases + at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
             }
             if (lane < nfeat) myf = feat[lane];
             if (stop == 1) { if (myf == 12345u) out.ncand[q] = nfeat; continue; }
             probe(db, myf, off, len);
             if (stop == 2) { if (len == 0x7FFFFFFFu) out.ncand[q] = (u32)off; continue; }
-            u32 incl = wave_incl_scan(len, lane);
+            u32 incl = wave_incl_scan_dpp(len);
             pos = incl - len;
             T = bcast(incl, 63);
             if (T > (u32)LCAP) ovf = true;
@@ -377,7 +403,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? 8 : 5) void k_query_wave(D
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
 
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
-        const u32 numWindows = range_width(l1 + l2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
+        const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         if constexpr (sizeof(KeyT) == 4) {
             if (T <= 192 && stop == 0 && !(force_block & 2)) {
                 u32 D;
