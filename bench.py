@@ -242,24 +242,32 @@ def main():
         if sharded_error:
             out["sharded_error"] = sharded_error
         if kn > 0:
-            traffic = None      # HBM bytes per launch from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
+            traffic, valu = None, None      # per launch, from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                 if a.workload == "c2" and not a.small:
                     traffic = tj["hbm_bytes_per_launch"] * B / tj["reads_per_launch"]
+                    valu = tj["valu_insts_per_launch"] * B / tj["reads_per_launch"]
             except Exception:
-                traffic = None
+                traffic, valu = None, None
             algo = algorithmic_bytes(max_bases, st)
             avg_ms = kms / kn
             ach = algo / (avg_ms * 1e-3) / 1e9
             out["roofline"] = {"bound": "hbm", "kernel": "k_query_wave", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "traffic_source": "profiles/pmc_traffic.json (FETCH_SIZE+WRITE_SIZE of the committed rocprofv3 --pmc passes, uncorrected, see profiles/r01_fetch_calibration.txt)" if traffic else None,
-                               "binding_resource": "integer VALU issue (~1 wave64 instr / 4 cycles / SIMD, scripts/valu_rate.hip); HBM random-sector traffic is ~17% of peak",
+                               "binding_resource": "integer VALU issue (1 wave64 instr / 4 cycles / SIMD, scripts/valu_rate.hip): see valu_issue; HBM random-sector traffic is ~19% of peak",
                                "kernel_note": "k_query_wave timed by HIP events on its stream (mcq_ws_timing); for --workload long the work is in k_query_block, timed by ms_per_step",
                                "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": avg_ms, "launches_timed": kn,
                                "bytes_per_read": algo / B,
                                "per_launch": {k: st[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow")}}
+            if valu:
+                # second, binding roofline: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) over the live
+                # kernel time, against 1 instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz
+                peak = 1024 * 2.4e9 / 4
+                out["roofline"]["valu_issue"] = {"achieved": valu / (avg_ms * 1e-3), "peak": peak, "unit": "wave64 VALU inst/s",
+                                                 "frac": valu / (avg_ms * 1e-3) / peak, "insts_per_read": valu / B,
+                                                 "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU), kernel time live"}
 
         return out
 
