@@ -147,9 +147,11 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// full-wave DPP permutation: every lane is written, so no previous value is tied to the result
+// (update_dpp(old = v, ...) would cost a v_mov copy per use)
 template <int CTRL>
 __device__ __forceinline__ u32 dpp_mov(u32 v) {
-    return (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+    return (u32)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, false);
 }
 
 // minimum over the 64 lanes, returned wave-uniform.  All lanes must be active.
@@ -186,7 +188,7 @@ __device__ __forceinline__ u32 xor_lane(u32 v, u32 lane) {
     if constexpr (J == 1) return dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
     else if constexpr (J == 2) return dpp_mov<0x4E>(v);                  // quad_perm [2,3,0,1]
     else if constexpr (J == 4) {                                          // banks 0,2 <- lane+4, banks 1,3 <- lane-4
-        u32 t = (u32)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xF, 0x5, false);   // row_shl:4
+        u32 t = (u32)__builtin_amdgcn_mov_dpp((int)v, 0x104, 0xF, 0x5, false);              // row_shl:4
         return (u32)__builtin_amdgcn_update_dpp((int)t, (int)v, 0x114, 0xF, 0xA, false);    // row_shr:4
     }
     else if constexpr (J == 8) return dpp_mov<0x128>(v);                 // row_ror:8
