@@ -53,7 +53,7 @@ enum {
                                    FASTQ text indexed by mcq_fastq_index                          */
     MCQ_FORCE_BLOCK_PATH = 0x100u, /* test hook: every query takes the workgroup path    */
     MCQ_FORCE_RAW_SORT = 0x400u,   /* test hook: the wave path sorts the raw match list instead of
-                                      de-duplicating it first (the path of T > 192 / 64-bit keys) */
+                                      de-duplicating it first (the path of T > 384 / 64-bit keys) */
     MCQ_DB_LOCS_64 = 0x200u     /* mcq_db_desc.flags: keep 64-bit locations in HBM even when
                                    (tgt,win) would fit the compact 32-bit form           */
 };

@@ -223,41 +223,88 @@ __device__ __forceinline__ u64 cmpex(u64 v, u64 o, u64 keepmin) {
     return ((u64)hi << 32) | lo;
 }
 
-template <int K, int J>
-__device__ __forceinline__ u32 bitonic_step(u32 v, u32 lane) {
-    constexpr u64 KM = keepmin_mask(K, J, true);
-    return cmpex(v, xor_lane<J>(v, lane), KM);
-}
+// ---- one u32 per lane: sorting network on v_min_u32 / v_max_u32 with DPP operands -------------
+// A compare-exchange whose partner is one DPP permutation away needs no compare, no lane mask
+// arithmetic and no VCC round trip: min and max of (own, partner) are one VOP2+DPP instruction each.
+//   MCQ_CX2: the lanes that keep the minimum are a union of 4-lane banks / 16-lane rows, so the two
+//            instructions write disjoint lane sets of the result directly (DPP bank_mask / row_mask).
+//   MCQ_CX3: any other lane pattern (period 2 or 4): min and max everywhere, v_cndmask picks per lane.
+// Network: "flip" form of the bitonic sorter (first stage of a K-block merge pairs i with i ^ (K-1),
+// then half-cleaners i ^ J), every comparator ascending, up to K = 32; for the last level the keys of
+// rows 2,3 are kept complemented during levels 2..32 so that lanes 32..63 come out descending and the
+// K = 64 merge can start with the cheap lane ^ 32 exchange (v_permlane32_swap).
+// The leading s_nop covers the 2 wait states between a VALU write of a VGPR and a DPP read of it (the
+// compiler does not look inside asm blocks).
+#define MCQ_DPP_ALL " row_mask:0xf bank_mask:0xf"
+#define MCQ_CX2(v, DPP_MIN, DPP_MAX) do { u32 r_; \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 " DPP_MIN "\n\tv_max_u32_dpp %0, %1, %1 " DPP_MAX \
+        : "=&v"(r_) : "v"(v)); v = r_; } while (0)
+#define MCQ_CX3(v, DPP, MASK32) do { u32 lo_, hi_; \
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %2, %2 " DPP MCQ_DPP_ALL "\n\tv_max_u32_dpp %1, %2, %2 " DPP MCQ_DPP_ALL "\n\t" \
+        "s_mov_b32 vcc_lo, " MASK32 "\n\ts_mov_b32 vcc_hi, " MASK32 "\n\tv_cndmask_b32_e32 %0, %1, %0, vcc" \
+        : "=&v"(lo_), "=&v"(hi_) : "v"(v) : "vcc"); v = lo_; } while (0)
 
-// ascending sort of one u32 per lane across the wave (21 compare-exchange stages)
+// half-cleaners at lane distance 8, 4, 2, 1 (ascending everywhere)
+__device__ __forceinline__ u32 cx_j8(u32 v) { MCQ_CX2(v, "row_ror:8 row_mask:0xf bank_mask:0x3", "row_ror:8 row_mask:0xf bank_mask:0xc"); return v; }
+__device__ __forceinline__ u32 cx_j4(u32 v) { MCQ_CX2(v, "row_shl:4 row_mask:0xf bank_mask:0x5", "row_shr:4 row_mask:0xf bank_mask:0xa"); return v; }
+__device__ __forceinline__ u32 cx_j2(u32 v) { MCQ_CX3(v, "quad_perm:[2,3,0,1]", "0x33333333"); return v; }
+__device__ __forceinline__ u32 cx_j1(u32 v) { MCQ_CX3(v, "quad_perm:[1,0,3,2]", "0x55555555"); return v; }
+// flips of blocks of 4, 8, 16 lanes
+__device__ __forceinline__ u32 cx_flip4(u32 v)  { MCQ_CX3(v, "quad_perm:[3,2,1,0]", "0x33333333"); return v; }
+__device__ __forceinline__ u32 cx_flip8(u32 v)  { MCQ_CX2(v, "row_half_mirror row_mask:0xf bank_mask:0x5", "row_half_mirror row_mask:0xf bank_mask:0xa"); return v; }
+__device__ __forceinline__ u32 cx_flip16(u32 v) { MCQ_CX2(v, "row_mirror row_mask:0xf bank_mask:0x3", "row_mirror row_mask:0xf bank_mask:0xc"); return v; }
+// flip of blocks of 32 lanes: partner = mirrored lane of the neighbouring row.  v_permlane16_swap of two
+// copies leaves (R0,R0,R2,R2) and (R1,R1,R3,R3): every row finds its neighbour row in place.
+__device__ __forceinline__ u32 cx_flip32(u32 v) {
+    auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    u32 r;
+    asm("s_nop 1\n\tv_min_u32_dpp %0, %2, %3 row_mirror row_mask:0x5 bank_mask:0xf\n\t"
+        "v_max_u32_dpp %0, %1, %3 row_mirror row_mask:0xa bank_mask:0xf"
+        : "=&v"(r) : "v"(sw[0]), "v"(sw[1]), "v"(v));
+    return r;
+}
+// lane ^ 16 and lane ^ 32 exchanges (ascending): both copies after the swap hold the pair in every lane
+__device__ __forceinline__ u32 cx_j16(u32 v) {
+    auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    u32 r;
+    asm("s_nop 1\n\tv_min_u32_e32 %0, %1, %2\n\tv_max_u32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xa bank_mask:0xf"
+        : "=&v"(r) : "v"(sw[0]), "v"(sw[1]));
+    return r;
+}
+__device__ __forceinline__ u32 cx_j32(u32 v) {
+    auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    u32 r;
+    asm("s_nop 1\n\tv_min_u32_e32 %0, %1, %2\n\tv_max_u32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf"
+        : "=&v"(r) : "v"(sw[0]), "v"(sw[1]));
+    return r;
+}
+// complement the keys of rows 2,3 in place
+__device__ __forceinline__ u32 not_rows23(u32 v) {
+    asm("s_nop 1\n\tv_not_b32_dpp %0, %0 quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf" : "+v"(v));
+    return v;
+}
+// every aligned block of 32 lanes sorted ascending
+__device__ __forceinline__ u32 wave_sort_blocks32(u32 v) {
+    v = cx_j1(v);                                                   // K = 2 (flip of 2 = lane ^ 1)
+    v = cx_flip4(v);  v = cx_j1(v);                                 // K = 4
+    v = cx_flip8(v);  v = cx_j2(v); v = cx_j1(v);                   // K = 8
+    v = cx_flip16(v); v = cx_j4(v); v = cx_j2(v); v = cx_j1(v);     // K = 16
+    v = cx_flip32(v); v = cx_j8(v); v = cx_j4(v); v = cx_j2(v); v = cx_j1(v);   // K = 32
+    return v;
+}
+// ascending sort of one u32 per lane across the wave
 __device__ __forceinline__ u32 wave_sort64(u32 v, u32 lane) {
-    v = bitonic_step<2, 1>(v, lane);
-    v = bitonic_step<4, 2>(v, lane);  v = bitonic_step<4, 1>(v, lane);
-    v = bitonic_step<8, 4>(v, lane);  v = bitonic_step<8, 2>(v, lane);  v = bitonic_step<8, 1>(v, lane);
-    v = bitonic_step<16, 8>(v, lane); v = bitonic_step<16, 4>(v, lane); v = bitonic_step<16, 2>(v, lane);
-    v = bitonic_step<16, 1>(v, lane);
-    v = bitonic_step<32, 16>(v, lane); v = bitonic_step<32, 8>(v, lane); v = bitonic_step<32, 4>(v, lane);
-    v = bitonic_step<32, 2>(v, lane);  v = bitonic_step<32, 1>(v, lane);
-    v = bitonic_step<64, 32>(v, lane); v = bitonic_step<64, 16>(v, lane); v = bitonic_step<64, 8>(v, lane);
-    v = bitonic_step<64, 4>(v, lane);  v = bitonic_step<64, 2>(v, lane);  v = bitonic_step<64, 1>(v, lane);
+    (void)lane;
+    v = not_rows23(v);
+    v = wave_sort_blocks32(v);
+    v = not_rows23(v);                                              // lanes 32..63 now descending
+    v = cx_j32(v); v = cx_j16(v); v = cx_j8(v); v = cx_j4(v); v = cx_j2(v); v = cx_j1(v);
     return v;
 }
-
-// ascending sort of lanes 0-31 (lanes 32-63 hold padding and sort among themselves): 15 stages
-template <int J>
-__device__ __forceinline__ u32 bitonic_final32(u32 v, u32 lane) {
-    constexpr u64 KM = keepmin_mask(64, J, true);
-    return cmpex(v, xor_lane<J>(v, lane), KM);
-}
+// ascending sort of lanes 0-31 (lanes 32-63 hold padding and sort among themselves)
 __device__ __forceinline__ u32 wave_sort32_low(u32 v, u32 lane) {
-    v = bitonic_step<2, 1>(v, lane);
-    v = bitonic_step<4, 2>(v, lane);  v = bitonic_step<4, 1>(v, lane);
-    v = bitonic_step<8, 4>(v, lane);  v = bitonic_step<8, 2>(v, lane);  v = bitonic_step<8, 1>(v, lane);
-    v = bitonic_step<16, 8>(v, lane); v = bitonic_step<16, 4>(v, lane); v = bitonic_step<16, 2>(v, lane);
-    v = bitonic_step<16, 1>(v, lane);
-    v = bitonic_final32<16>(v, lane); v = bitonic_final32<8>(v, lane); v = bitonic_final32<4>(v, lane);
-    v = bitonic_final32<2>(v, lane);  v = bitonic_final32<1>(v, lane);
-    return v;
+    (void)lane;
+    return wave_sort_blocks32(v);
 }
 
 // Sketch of seq[0..n), n <= 128, by one full wave.  Lane l encodes bases 2l and 2l+1;

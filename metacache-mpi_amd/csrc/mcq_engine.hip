@@ -242,24 +242,36 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
     for (int e = 0; e < E; ++e) buf[e * 64 + lane] = r[e];
 }
 
-// ---- rows 8-9 on DISTINCT (tgt,win) keys (32-bit keys, T <= 192) ------------------------------
-// A read's match list repeats the same (target, window) many times (C2: 107 locations, 33 distinct),
-// and everything after the gather only needs the distinct keys and how often each occurs.  The wave
-// counts them in a 256-slot open-addressing table in its LDS segment (ds_cmpst claims a slot, ds_add
-// counts), the lanes that claimed a slot compact their keys, <= 128 distinct keys are sorted in one or
-// two registers per lane instead of 64*E raw locations, and the multiplicities come back by probing
-// the table with the sorted keys.  Output: SK[0..D) sorted distinct keys, WP[0..D) inclusive prefix
-// sums of the multiplicities (for sweep_targets_weighted).  Returns D, or ~0u when there are more
-// than 128 distinct keys: then the raw keys have been sorted into buf[] as gather_sort_store does.
-//   LDS: buf[0..256) table keys, buf[256..512) table counts, hits[0..256) compaction list then WP,
-//        hits[256..512) SK.
-__device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 24; }
+// ---- rows 8-9 on DISTINCT (tgt,win) keys (32-bit keys, T <= 384) ------------------------------
+// A read's match list repeats the same (target, window) many times (C2: 107 locations, 33 distinct;
+// 2x150 bp pairs: 214 / 65), and everything after the gather only needs the distinct keys and how
+// often each occurs.  The wave counts them in a 512-slot open-addressing table in its LDS segment
+// (ds_cmpst claims a slot, ds_add counts in a byte lane), the lanes that claimed a slot compact their
+// keys, <= 128 distinct keys are sorted in one or two registers per lane instead of 64*E raw locations,
+// and the multiplicities come back by probing the table with the sorted keys.  Output: SK[0..D) sorted
+// distinct keys, WP[0..D) inclusive prefix sums of the multiplicities (for sweep_targets_weighted).
+// Returns D, or ~0u when there are more than 128 distinct keys (the caller then sorts the raw list).
+//   LDS (u32 words): buf[0..512) table keys, later the sweep's H;  hits[0..128) table counts (one byte
+//   per slot: a key occurs at most once per feature, <= 64 times), hits[128..256) compaction list,
+//   hits[256..384) SK, hits[384..512) WP.
+#define MCQ_DEDUP_MAX_T 384u
+__device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 23; }
+__device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 256; }
+__device__ __forceinline__ u32* dedup_wp(u32* hits) { return hits + 384; }
+__device__ __forceinline__ u32 dedup_count(const u32* tabkey, const u32* tabcnt, u32 k) {
+    u32 slot = dedup_slot(k);
+    while (tabkey[slot] != k) slot = (slot + 1) & 511u;
+    return (tabcnt[slot >> 2] >> (8 * (slot & 3))) & 0xFFu;
+}
 
 template <int E>
-__device__ __forceinline__ u32 dedup_sort(u32 (&r)[E], u32* buf, u32* hits, u32 T, u32 lane) {
-    u32* tabkey = buf; u32* tabcnt = buf + 256; u32* list = hits; u32* WP = hits; u32* SK = hits + 256;
+__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane) {
+    u32 r[E];
+    gather_regs<u32, E>(db, r, T, pos, off, lane);
+    u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 128; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
     reinterpret_cast<uint4*>(tabkey)[lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
-    reinterpret_cast<uint4*>(tabcnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(tabkey)[64 + lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
+    reinterpret_cast<uint2*>(tabcnt)[lane] = make_uint2(0u, 0u);
     wave_sync();
     const u64 below = (1ull << lane) - 1;
     u32 D = 0;
@@ -269,59 +281,38 @@ __device__ __forceinline__ u32 dedup_sort(u32 (&r)[E], u32* buf, u32* hits, u32 
         bool created = false;
         if ((u32)(e * 64) + lane < T) {
             u32 slot = dedup_slot(key);
-            while (true) {                       // T <= 192 < 256 slots: an empty slot always exists
+            while (true) {                       // T <= 384 < 512 slots: an empty slot always exists
                 const u32 old = atomicCAS(&tabkey[slot], MCQ_EMPTY, key);
                 created = old == MCQ_EMPTY;
-                if (created || old == key) { atomicAdd(&tabcnt[slot], 1u); break; }
-                slot = (slot + 1) & 255u;
+                if (created || old == key) { atomicAdd(&tabcnt[slot >> 2], 1u << (8 * (slot & 3))); break; }
+                slot = (slot + 1) & 511u;
             }
         }
         const u64 cm = __ballot(created);
-        if (created) list[D + (u32)__builtin_popcountll(cm & below)] = key;
+        const u32 rank = D + (u32)__builtin_popcountll(cm & below);
+        if (created && rank < 128) list[rank] = key;
         D += (u32)__builtin_popcountll(cm);
     }
     wave_sync();
-    if (D > 128) {                               // rare: sort the raw keys the general way
-        constexpr int E2 = E == 3 ? 4 : E;
-        u32 r2[E2];
-#pragma unroll
-        for (int e = 0; e < E2; ++e) r2[e] = e < E ? r[e] : MCQ_EMPTY;
-        wave_regsort<u32, E2>(r2, lane);
-#pragma unroll
-        for (int e = 0; e < E2; ++e) buf[e * 64 + lane] = r2[e];
-        return ~0u;
-    }
+    if (D > 128) return ~0u;
     if (D <= 64) {
         u32 k = lane < D ? list[lane] : MCQ_EMPTY;
         k = (D <= 32) ? wave_sort32_low(k, lane) : wave_sort64(k, lane);
-        u32 c = 0;
-        if (lane < D) { u32 slot = dedup_slot(k); while (tabkey[slot] != k) slot = (slot + 1) & 255u; c = tabcnt[slot]; }
+        const u32 c = lane < D ? dedup_count(tabkey, tabcnt, k) : 0u;
         const u32 incl = wave_incl_scan_dpp(c);
-        wave_sync();                             // list consumed: WP may overwrite it
         SK[lane] = k; WP[lane] = incl;
     } else {
         u32 k[2];
         k[0] = list[lane]; k[1] = (64 + lane < D) ? list[64 + lane] : MCQ_EMPTY;
         wave_regsort<u32, 2>(k, lane);
-        u32 c[2];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            c[e] = 0;
-            if ((u32)(e * 64) + lane < D) { u32 slot = dedup_slot(k[e]); while (tabkey[slot] != k[e]) slot = (slot + 1) & 255u; c[e] = tabcnt[slot]; }
-        }
-        const u32 i0 = wave_incl_scan_dpp(c[0]);
-        const u32 i1 = wave_incl_scan_dpp(c[1]) + bcast(i0, 63);
-        wave_sync();
+        const u32 c0 = dedup_count(tabkey, tabcnt, k[0]);
+        const u32 c1 = (64 + lane < D) ? dedup_count(tabkey, tabcnt, k[1]) : 0u;
+        const u32 i0 = wave_incl_scan_dpp(c0);
+        const u32 i1 = wave_incl_scan_dpp(c1) + bcast(i0, 63);
         SK[lane] = k[0]; SK[64 + lane] = k[1]; WP[lane] = i0; WP[64 + lane] = i1;
     }
     wave_sync();                                 // table dead from here: buf[] becomes the sweep's H
     return D;
-}
-template <int E>
-__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane) {
-    u32 r[E];
-    gather_regs<u32, E>(db, r, T, pos, off, lane);
-    return dedup_sort<E>(r, buf, hits, T, lane);
 }
 
 // geometry of one read (or pair) on the wave path
@@ -405,20 +396,20 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         if constexpr (sizeof(KeyT) == 4) {
-            if (T <= 192 && stop == 0 && !(force_block & 2)) {
+            if (T <= MCQ_DEDUP_MAX_T && stop == 0 && !(force_block & 2)) {
                 u32 D;
                 if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, off, lane);
                 else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, off, lane);
-                else               D = gather_dedup_sort<3>(db, buf, hits, T, pos, off, lane);
+                else if (T <= 192) D = gather_dedup_sort<3>(db, buf, hits, T, pos, off, lane);
+                else if (T <= 256) D = gather_dedup_sort<4>(db, buf, hits, T, pos, off, lane);
+                else               D = gather_dedup_sort<6>(db, buf, hits, T, pos, off, lane);
                 if (D != ~0u) {
-                    sweep_targets_weighted(hits + 256, hits, buf, D, numWindows, db.wb, lane);
-                    st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, hits + 256, buf, D, numWindows, db.wb, q, lane);
-                } else {
-                    sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
-                    st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+                    sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
+                    st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, dedup_sk(hits), buf, D, numWindows, db.wb, q, lane);
+                    wave_sync();
+                    continue;
                 }
-                wave_sync();
-                continue;
+                wave_sync();                       // more than 128 distinct keys: the raw list is sorted below
             }
         }
         if (T <= 64)       gather_sort_store<KeyT, 1>(db, buf, T, pos, off, lane, stop);
