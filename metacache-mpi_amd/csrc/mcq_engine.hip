@@ -265,9 +265,7 @@ __device__ __forceinline__ u32 dedup_count(const u32* tabkey, const u32* tabcnt,
 }
 
 template <int E>
-__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane) {
-    u32 r[E];
-    gather_regs<u32, E>(db, r, T, pos, off, lane);
+__device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits, u32 T, u32 lane) {
     u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 128; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
     reinterpret_cast<uint4*>(tabkey)[lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
     reinterpret_cast<uint4*>(tabkey)[64 + lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
@@ -313,6 +311,20 @@ __device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32*
     }
     wave_sync();                                 // table dead from here: buf[] becomes the sweep's H
     return D;
+}
+template <int E>
+__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane) {
+    u32 r[E];
+    gather_regs<u32, E>(db, r, T, pos, off, lane);
+    return dedup_sort<E>(r, buf, hits, T, lane);
+}
+// the same for a match list that already sits in global memory (staged / sharded path)
+template <int E>
+__device__ __forceinline__ u32 load_dedup_sort(const u32* __restrict__ src, u32* buf, u32* hits, u32 T, u32 lane) {
+    u32 r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const u32 t = e * 64 + lane; r[e] = t < T ? src[t] : MCQ_EMPTY; }
+    return dedup_sort<E>(r, buf, hits, T, lane);
 }
 
 // geometry of one read (or pair) on the wave path
@@ -683,12 +695,30 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         const u32 T = (u32)T64;
         st_loc += T;
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
+        const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
+        if constexpr (sizeof(KeyT) == 4) {
+            if (T <= MCQ_DEDUP_MAX_T && !opt.raw_sort) {
+                const u32* src = locs + b0;
+                u32 D;
+                if (T <= 64)       D = load_dedup_sort<1>(src, buf, hits, T, lane);
+                else if (T <= 128) D = load_dedup_sort<2>(src, buf, hits, T, lane);
+                else if (T <= 192) D = load_dedup_sort<3>(src, buf, hits, T, lane);
+                else if (T <= 256) D = load_dedup_sort<4>(src, buf, hits, T, lane);
+                else               D = load_dedup_sort<6>(src, buf, hits, T, lane);
+                if (D != ~0u) {
+                    sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
+                    st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, dedup_sk(hits), buf, D, numWindows, db.wb, q, lane);
+                    wave_sync();
+                    continue;
+                }
+                wave_sync();
+            }
+        }
         if (T <= 64)       load_sort_store<KeyT, 1>(buf, locs + b0, T, lane);
         else if (T <= 128) load_sort_store<KeyT, 2>(buf, locs + b0, T, lane);
         else if (T <= 256) load_sort_store<KeyT, 4>(buf, locs + b0, T, lane);
         else               load_sort_store<KeyT, 8>(buf, locs + b0, T, lane);
         wave_sync();
-        const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
         st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
@@ -951,6 +981,7 @@ static int make_opt(const mcq_query_opts* o, OptDev& d) {
     memset(&d, 0, sizeof(d));
     d.max_cand = o->max_cand; d.P = P; d.seg = seg;
     d.quirk_seq_drop = (o->flags & MCQ_QUIRK_SEQ_DROP) ? 1 : 0;
+    d.raw_sort = (o->flags & MCQ_FORCE_RAW_SORT) ? 1 : 0;
     d.insert_size_max = o->insert_size_max;
     std::vector<std::pair<u32, u32>> sched;
     fold_schedule(P, sched);

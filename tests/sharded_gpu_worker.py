@@ -50,6 +50,13 @@ def main():
     if ok:
         mask = np.arange(M)[None, :] < on[:, None]
         ok = bool(np.array_equal(gc[mask], oc[mask]))
+    # the reduce kernel without its de-duplicating pass must agree as well
+    cands2 = torch.zeros_like(cands); ncand2 = torch.zeros_like(ncand)
+    sq.query(reads, roff, n_seqs, bool(paired), cands2, ncand2, max_cand=M, emulate_ranks=P, flags=eng.MCQ_FORCE_RAW_SORT)
+    torch.cuda.synchronize()
+    if ok:
+        g2 = cands2.cpu().numpy().view(np.uint32); n2 = ncand2.cpu().numpy().view(np.uint32)
+        ok = bool(np.array_equal(n2, on)) and bool(np.array_equal(g2[mask], oc[mask]))
     np.savez(outp + ".%d.npz" % rank, ok=np.array([ok]), served=np.array([st["n_features_served"]]),
              overflow=np.array([st["n_overflow"]]), nq=np.array([nq]))
     dist.barrier()
