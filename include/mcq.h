@@ -54,6 +54,10 @@ enum {
     MCQ_FORCE_BLOCK_PATH = 0x100u, /* test hook: every query takes the workgroup path    */
     MCQ_FORCE_RAW_SORT = 0x400u,   /* test hook: the wave path sorts the raw match list instead of
                                       de-duplicating it first (the path of T > 384 / 64-bit keys) */
+    MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000u, /* mcq_build_desc.flags: the build option
+                                   -remove-overpopulated-features (src/mode_build.cpp:847-1074): a feature whose
+                                   per-rank location counts (after the per-rank limit) sum to more than
+                                   max_locs - 1 is removed from every rank                                  */
     MCQ_DB_LOCS_64 = 0x200u     /* mcq_db_desc.flags: keep 64-bit locations in HBM even when
                                    (tgt,win) would fit the compact 32-bit form           */
 };
@@ -234,7 +238,7 @@ typedef struct {
     uint32_t emulate_ranks;       /* P of the build being reproduced (0 = 1)                  */
     uint32_t max_locs;            /* per (feature, rank); 0 = 254                             */
     uint32_t n_shards, shard_id;  /* mcq_db_build: as in mcq_db_desc                          */
-    uint32_t flags;               /* MCQ_DEVICE_PTRS, MCQ_DB_LOCS_64                          */
+    uint32_t flags;               /* MCQ_DEVICE_PTRS, MCQ_DB_LOCS_64, MCQ_BUILD_REMOVE_OVERPOPULATED */
     int32_t device;
 } mcq_build_desc;
 

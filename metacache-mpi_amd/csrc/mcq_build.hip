@@ -72,6 +72,23 @@ __global__ void k_compact(const u64* key, const u32* val, const u32* keep, const
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         if (keep[i]) out[pos[i]] = ((key[i] / P) << 32) | val[i];               // (feature << 32) | global window
 }
+// -remove-overpopulated-features: entries of features with more than `limit` locations are dropped
+__global__ void k_keep_small(const u64* fw, const u32* head, const u64* kid_excl, const u64* first, u64 n, u64 n_keys, u64 limit, u32* keep) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 kx = kid_excl[i] + head[i] - 1;
+        const u64 end = (kx + 1 < n_keys) ? first[kx + 1] : n;
+        keep[i] = (end - first[kx] <= limit) ? 1u : 0u;
+    }
+}
+__global__ void k_first_of_key(const u32* head, const u64* kid_excl, u64 n, u64* first) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) if (head[i]) first[kid_excl[i]] = i;
+}
+__global__ void k_compact_u64(const u64* in, const u32* keep, const u64* pos, u64 n, u64* out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) if (keep[i]) out[pos[i]] = in[i];
+}
 __global__ void k_feat_heads(const u64* fw, u64 n, u32* head) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -231,6 +248,20 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     BCHK(hipMalloc(&head, (n_kept ? n_kept : 1) * 4)); BCHK(hipMalloc(&kid, (n_kept ? n_kept : 1) * 8));
     if (n_kept) hipLaunchKernelGGL(k_feat_heads, grid_for(n_kept), dim3(TB), 0, 0, fw, n_kept, head);
     MCHK(excl_scan(head, kid, n_kept, &n_keys));
+    if ((d->flags & MCQ_BUILD_REMOVE_OVERPOPULATED) && n_kept && max_locs > 1) {
+        u64 *first = nullptr, *pos2 = nullptr, *fw2 = nullptr; u32* keep2 = nullptr; u64 n2 = 0;
+        BCHK(hipMalloc(&first, (n_keys ? n_keys : 1) * 8)); BCHK(hipMalloc(&pos2, n_kept * 8)); BCHK(hipMalloc(&keep2, n_kept * 4));
+        hipLaunchKernelGGL(k_first_of_key, grid_for(n_kept), dim3(TB), 0, 0, head, kid, n_kept, first);
+        hipLaunchKernelGGL(k_keep_small, grid_for(n_kept), dim3(TB), 0, 0, fw, head, kid, first, n_kept, n_keys, (u64)max_locs - 1, keep2);
+        MCHK(excl_scan(keep2, pos2, n_kept, &n2));
+        BCHK(hipMalloc(&fw2, (n2 ? n2 : 1) * 8));
+        hipLaunchKernelGGL(k_compact_u64, grid_for(n_kept), dim3(TB), 0, 0, fw, keep2, pos2, n_kept, fw2);
+        BCHK(hipDeviceSynchronize());
+        (void)hipFree(first); (void)hipFree(pos2); (void)hipFree(keep2); (void)hipFree(fw);
+        fw = fw2; n_kept = n2;
+        if (n_kept) hipLaunchKernelGGL(k_feat_heads, grid_for(n_kept), dim3(TB), 0, 0, fw, n_kept, head);
+        MCHK(excl_scan(head, kid, n_kept, &n_keys));
+    }
     T->n_keys = n_keys; T->n_locs = n_kept;
     BCHK(hipMalloc(&T->keys, (n_keys ? n_keys : 1) * 4)); BCHK(hipMalloc(&T->list_off, (n_keys + 1) * 8));
     BCHK(hipMalloc(&T->locs, (n_kept ? n_kept : 1) * 8));

@@ -44,7 +44,7 @@ def sketch_windows(bases, seq_off, k=16, s=16, winlen=128, winstride=113, sketch
 
 
 def build_table(bases, seq_off, emulate_ranks=1, k=16, s=16, winlen=128, winstride=113, maxlocs=MAXLOCS,
-                sketcher=None):
+                sketcher=None, remove_overpopulated=False):
     """Returns (keys int64 [nk] ascending, list_off int64 [nk+1], locs int64 [(tgt<<32)|win], win_off)."""
     dev = bases.device
     win_off, feats, _ = sketch_windows(bases, seq_off, k, s, winlen, winstride, sketcher)
@@ -76,6 +76,11 @@ def build_table(bases, seq_off, emulate_ranks=1, k=16, s=16, winlen=128, winstri
         k2, order = torch.sort((f << 31) | gwin)
         f, gwin, tgt = f[order], gwin[order], tgt[order]
         del k2, order
+    if remove_overpopulated:
+        # -remove-overpopulated-features (src/mode_build.cpp:847-1074): per-rank counts summed over the ranks
+        _, inv, cnt = torch.unique_consecutive(f, return_inverse=True, return_counts=True)
+        ok = cnt[inv] <= maxlocs - 1
+        f, gwin, tgt = f[ok], gwin[ok], tgt[ok]
     win = gwin - win_off[tgt]
     locs = (tgt << 32) | win
     keys, counts = torch.unique_consecutive(f, return_counts=True)

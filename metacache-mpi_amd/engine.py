@@ -15,6 +15,7 @@ MCQ_QUIRK_SEQ_DROP = 2
 MCQ_BATCH_RANGES = 8             # seq_off = (begin,end) pairs into `bases` (device pointers only)
 MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-query path
 MCQ_DB_LOCS_64 = 0x200           # Database(flags=...): keep 64-bit locations
+MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000   # Table / Database.build: -remove-overpopulated-features
 MCQ_FORCE_RAW_SORT = 0x400       # debug: wave path without the de-duplicating pass
 
 MCQ_OK, MCQ_E_ARG, MCQ_E_HIP, MCQ_E_CAPACITY, MCQ_E_UNSUPPORTED = 0, -1, -2, -3, -4
@@ -296,9 +297,9 @@ class Table:
     """mcq_build_table: keys / list_off / locs of the union table as device arrays"""
 
     def __init__(self, bases_ptr, seq_off_ptr, n_targets, emulate_ranks=1, k=16, sketch_size=16, winlen=128, winstride=113,
-                 max_locs=0, device=0, device_ptrs=True):
+                 max_locs=0, device=0, device_ptrs=True, flags=0):
         d = _build_desc(bases_ptr, seq_off_ptr, None, n_targets, emulate_ranks, k, sketch_size, winlen, winstride,
-                        max_locs, 1, 0, device, 0, device_ptrs)
+                        max_locs, 1, 0, device, flags, device_ptrs)
         h = C.c_void_p()
         rc = lib().mcq_build_table(C.byref(d), C.byref(h))
         if rc != 0:

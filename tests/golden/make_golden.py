@@ -157,9 +157,9 @@ def write_fastq(path, names, seqs):
             f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
 
 
-def ref_build(work, name, P):
+def ref_build(work, name, P, extra=()):
     sh([os.path.join("/opt/conda/bin/mpiexec"), "-n", str(P), os.path.join(REF, "metacache_mpi"),
-        "build", name, "genomes", "-taxonomy", "tax"], cwd=work)
+        "build", name, "genomes", "-taxonomy", "tax"] + list(extra), cwd=work)
 
 
 def parse_tophits(col):
@@ -233,7 +233,7 @@ def sample_reads(rng, genomes, n_pairs, rlen_lo=100, rlen_hi=150, err=0.01):
     return names, r1, r2, truth
 
 
-def run_db_fixture(tag, nodes, genomes, names, r1, r2, Ps, maxcand, lowest):
+def run_db_fixture(tag, nodes, genomes, names, r1, r2, Ps, maxcand, lowest, build_extra=()):
     outdir = os.path.join(HERE, tag)
     shutil.rmtree(outdir, ignore_errors=True)
     os.makedirs(outdir)
@@ -257,7 +257,7 @@ def run_db_fixture(tag, nodes, genomes, names, r1, r2, Ps, maxcand, lowest):
     for P in Ps:
         pd = os.path.join(outdir, "P%d" % P)
         os.makedirs(pd)
-        ref_build(work, tag, P)
+        ref_build(work, tag, P, build_extra)
         for r in range(P):
             shutil.copy(os.path.join(work, "%s.db_%d" % (tag, r)), pd)
         dump = ref_ranks_dump(work, tag, P, maxcand, lowest)
@@ -355,6 +355,27 @@ def make_noanc():
     run_db_fixture("noanc", nodes, genomes, names, r1, r2, Ps=(2, 4), maxcand=4, lowest="species")
 
 
+def make_overpop():
+    rng = random.Random(17)
+    # build with -remove-overpopulated-features (src/mode_build.cpp:847-1074): a feature whose location counts,
+    # summed over the ranks, exceed 253 is removed everywhere.  Tandem repeats of a 113-base unit (= the window
+    # stride) put the same 16 features into every window of the repeat:
+    #   U: 130 copies in targets 0 and 1  -> 130 + 130 = 260 over two ranks: removed, no rank truncated
+    #   V: 100 copies in targets 2 and 3  -> 200: kept
+    #   W: 300 copies in target 0         -> truncated to 254 on its rank, 254 > 253: removed
+    nodes = [(1, 1, "no rank", "root"), (2, 1, "superkingdom", "Bacteria"),
+             (10, 2, "genus", "GenR"), (11, 10, "species", "GenR one"), (12, 10, "species", "GenR two"),
+             (20, 2, "genus", "GenS"), (21, 20, "species", "GenS one"), (22, 20, "species", "GenS two")]
+    U, V, W = rand_seq(rng, 113), rand_seq(rng, 113), rand_seq(rng, 113)
+    genomes = [("NC_000001.1", 11, rand_seq(rng, 3000) + U * 130 + rand_seq(rng, 2000) + W * 300 + rand_seq(rng, 1500)),
+               ("NC_000002.1", 12, rand_seq(rng, 2500) + U * 130 + rand_seq(rng, 3000)),
+               ("NC_000003.1", 21, rand_seq(rng, 3000) + V * 100 + rand_seq(rng, 3000)),
+               ("NC_000004.1", 22, rand_seq(rng, 2000) + V * 100 + rand_seq(rng, 2500))]
+    names, r1, r2, _ = sample_reads(rng, genomes, 80)
+    run_db_fixture("overpop", nodes, genomes, names, r1, r2, Ps=(2, 4), maxcand=4, lowest="species",
+                   build_extra=("-remove-overpopulated-features",))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -362,6 +383,6 @@ if __name__ == "__main__":
     if not os.path.isdir("/root/reference"):
         sys.exit("needs /root/reference (build container only)")
     ensure_mpilib()
-    todo = [a.only] if a.only else ["kat", "mini", "tie", "noanc"]
+    todo = [a.only] if a.only else ["kat", "mini", "tie", "noanc", "overpop"]
     for t in todo:
-        {"kat": make_kat, "mini": make_mini, "tie": make_tie, "noanc": make_noanc}[t]()
+        {"kat": make_kat, "mini": make_mini, "tie": make_tie, "noanc": make_noanc, "overpop": make_overpop}[t]()

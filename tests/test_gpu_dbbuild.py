@@ -135,3 +135,25 @@ def test_abi_build_rejects_bad_arguments():
         engine.Table(host.ctypes.data, off.ctypes.data, 1, k=40, device_ptrs=False)       # k > 32
     with pytest.raises(engine.McqError):
         engine.Table(host.ctypes.data, off.ctypes.data, 0, device_ptrs=False)             # no targets
+
+
+@pytest.mark.parametrize("P", [2, 4])
+def test_remove_overpopulated_features_like_the_reference(P):
+    """fixture built by the reference with -remove-overpopulated-features: counts are summed over the ranks"""
+    engine = importlib.import_module("metacache-mpi_amd.engine")
+    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dev = torch.device("cuda", 0)
+    fx = Fixture("overpop", P)
+    bases, off = _load_genomes("overpop", dev)
+    rk, ro, rl = dbfile.union_shards(fx.shards)
+    tb = engine.Table(bases.data_ptr(), off.data_ptr(), off.numel() - 1, emulate_ranks=P,
+                      flags=engine.MCQ_BUILD_REMOVE_OVERPOPULATED)
+    keys, loff, locs, _ = tb.to_host()
+    assert np.array_equal(keys, rk) and np.array_equal(loff, ro) and np.array_equal(locs, rl)
+    k2, o2, l2, _ = dbbuild.build_table(bases, off, emulate_ranks=P, remove_overpopulated=True)
+    assert np.array_equal(k2.cpu().numpy().astype(np.uint32), rk)
+    assert np.array_equal(o2.cpu().numpy().astype(np.uint64), ro)
+    assert np.array_equal(l2.cpu().numpy().astype(np.uint64), rl)
+    # without the option the repeats stay (and the table differs)
+    tb2 = engine.Table(bases.data_ptr(), off.data_ptr(), off.numel() - 1, emulate_ranks=P)
+    assert tb2.n_keys > tb.n_keys and tb2.n_locs > tb.n_locs

@@ -11,7 +11,7 @@ from oracle import mc_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("mini", 2), ("mini", 4), ("mini", 8), ("tie", 2), ("tie", 4), ("noanc", 2), ("noanc", 4)]
+CASES = [("mini", 2), ("mini", 4), ("mini", 8), ("tie", 2), ("tie", 4), ("noanc", 2), ("noanc", 4), ("overpop", 2), ("overpop", 4)]
 
 
 @pytest.fixture(scope="module")

@@ -10,7 +10,7 @@ from golden_util import Fixture
 from oracle import dbfile
 from oracle import mc_oracle as orc
 
-CASES = [("mini", 2), ("mini", 8), ("tie", 2), ("tie", 4), ("noanc", 4)]
+CASES = [("mini", 2), ("mini", 8), ("tie", 2), ("tie", 4), ("noanc", 4), ("overpop", 2)]
 
 
 @pytest.fixture(scope="module")

@@ -11,7 +11,7 @@ from golden_util import Fixture
 from oracle import dbfile
 from oracle import mc_oracle as orc
 
-CASES = [("mini", 2), ("mini", 4), ("mini", 8), ("tie", 2), ("tie", 4), ("noanc", 2), ("noanc", 4)]
+CASES = [("mini", 2), ("mini", 4), ("mini", 8), ("tie", 2), ("tie", 4), ("noanc", 2), ("noanc", 4), ("overpop", 2), ("overpop", 4)]
 
 
 @pytest.fixture(scope="module", params=CASES, ids=lambda c: "%s-P%d" % c)
