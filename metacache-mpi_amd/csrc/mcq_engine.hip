@@ -275,6 +275,7 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
     u32 D = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
+        if (e > 0 && (u32)(e * 64) >= T) break;  // wave-uniform: nothing left in the higher registers
         const u32 key = r[e];
         bool created = false;
         if ((u32)(e * 64) + lane < T) {
@@ -313,9 +314,16 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
     return D;
 }
 template <int E>
-__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane) {
+__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane, int stop) {
     u32 r[E];
     gather_regs<u32, E>(db, r, T, pos, off, lane);
+    if (stop == 3) {                             // stage-ablation hook: keep the loads alive, skip the rest
+        u32 x = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) x ^= r[e];
+        buf[lane] = x;
+        return ~1u;
+    }
     return dedup_sort<E>(r, buf, hits, T, lane);
 }
 // the same for a match list that already sits in global memory (staged / sharded path)
@@ -408,15 +416,17 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         if constexpr (sizeof(KeyT) == 4) {
-            if (T <= MCQ_DEDUP_MAX_T && stop == 0 && !(force_block & 2)) {
+            if (T <= MCQ_DEDUP_MAX_T && !(force_block & 2)) {
                 u32 D;
-                if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, off, lane);
-                else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, off, lane);
-                else if (T <= 192) D = gather_dedup_sort<3>(db, buf, hits, T, pos, off, lane);
-                else if (T <= 256) D = gather_dedup_sort<4>(db, buf, hits, T, pos, off, lane);
-                else               D = gather_dedup_sort<6>(db, buf, hits, T, pos, off, lane);
+                if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, off, lane, stop);
+                else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, off, lane, stop);
+                else if (T <= 192) D = gather_dedup_sort<3>(db, buf, hits, T, pos, off, lane, stop);
+                else if (T <= 256) D = gather_dedup_sort<4>(db, buf, hits, T, pos, off, lane, stop);
+                else               D = gather_dedup_sort<6>(db, buf, hits, T, pos, off, lane, stop);
+                if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
                     sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
+                    if (stop == 5) { if (buf[lane] == 0x12345u) out.ncand[q] = 1; wave_sync(); continue; }
                     st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, dedup_sk(hits), buf, D, numWindows, db.wb, q, lane);
                     wave_sync();
                     continue;
@@ -1043,7 +1053,11 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
         for (u64 i = 0; i < nk; ++i) nk_local += h_len[i] > 0;
     }
     db->n_keys_local = nk_local; db->n_locs_local = nl_local;
-    db->nslots = std::max<u64>(1024, pow2ceil64(nk_local * 2));      // load factor <= 0.5
+    // load factor <= 0.25: 43 % of a read's features are not in the table and an unsuccessful linear probe
+    // walks 2.5 slots at load 0.5 but 1.4 at 0.25 -- fewer 64-B sectors per read for 16 B per key more
+    u64 slots_per_key = 4;
+    if (const char* e = getenv("MCQ_SLOTS_PER_KEY")) slots_per_key = std::max<u64>(1, strtoull(e, nullptr, 10));   // tuning knob
+    db->nslots = std::max<u64>(1024, pow2ceil64(nk_local * slots_per_key));
     if (db->nslots > (1ull << 32)) { return fail(MCQ_E_UNSUPPORTED, "table too large"); }
     // compact locations: (tgt << wb) | win in 32 bits when target and window ids fit
     u32 wb = 32, compact = 0;
