@@ -63,6 +63,8 @@ struct OptDev {
     u32 raw_sort;            // test hook: no de-duplicating pass (staged reduce kernel)
     u64 insert_size_max;
     u32 n_fold;              // fold schedule: (snd -> rcv) in the reference's order
+    u32 n_levels;            // rounds of the tree; the edges of one round touch disjoint ranks
+    unsigned char level_end[8];          // edges [level_end[l-1], level_end[l]) belong to round l
     unsigned char fold_snd[MCQ_MAX_FOLD];
     unsigned char fold_rcv[MCQ_MAX_FOLD];
 };
@@ -734,6 +736,114 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
         u32 beg = 0, end = 0;
         if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, wb, beg, end);
         uint4 v; v.x = Ltax; v.y = (u32)(Lhv >> JB); v.z = beg; v.w = end;
+        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
+    }
+    if (lane == 0) out.ncand[q] = n;
+    return n;
+}
+
+// ---- rows 10-11 with the wave-wide maxima taken in LDS (dedup path: 32-bit keys, packed u32 words) ----
+// Same closed form and the same lane layout of the P virtual-rank lists as topk_fold_write, but a selection
+// round is one ds_max per candidate into the word of its rank instead of a DPP reduction per rank: all P
+// ranks advance in the same round (M rounds per 64 candidates instead of P x M), and a round costs a dozen
+// VALU instructions.  scr: 128 words of this wave's LDS segment (scr[0..64) maxima, scr[64..128) winner taxa).
+__device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev& opt, const OutDev& out,
+                                                   const u32* buf, u32* H, u32 T, u32 numWindows, u32 wb,
+                                                   u64 q, u32 lane, u32* scr) {
+    constexpr int JB = 9;
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    const bool p2 = (P & (P - 1)) == 0;
+    const u32 JMASK = (1u << JB) - 1;
+    const u64 below = (1ull << lane) - 1;
+    u32* mx = scr; u32* wt = scr + 64;
+
+    // 1. compact the run heads' packed words to H[0..nheads)
+    u32 nheads = 0;
+    for (u32 base = 0; base < T; base += 64) {
+        const u32 j = base + lane;
+        const u32 hv = (j < T) ? H[j] : 0;
+        const u64 hm = __ballot(hv != 0);
+        if (hv != 0) H[nheads + (u32)__builtin_popcountll(hm & below)] = hv;
+        nheads += (u32)__builtin_popcountll(hm);
+    }
+    wave_sync();
+
+    // 2. stream the candidates through the lists, 64 at a time; every round serves all ranks
+    const u32 rl = lane / seg, li = lane - rl * seg;
+    const bool lslot = (li < M) && (rl < P);
+    u32 Ltax = MCQ_EMPTY, Lhv = 0;
+    for (u32 base = 0; base < nheads; base += 64) {
+        const u32 k = base + lane;
+        u32 cv = (k < nheads) ? H[k] : 0;
+        const u32 jb = JMASK - (cv & JMASK);
+        const u32 tgt = buf[cv ? jb : 0] >> wb;
+        u32 ctax = MCQ_EMPTY;
+        if (cv != 0 && tgt < db.n_targets) ctax = db.tgt2tax[tgt];
+        if (ctax == MCQ_EMPTY) cv = 0;
+        const u32 cr = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+        u32 Ntax = MCQ_EMPTY, Nhv = 0;
+        bool lalive = lslot && Lhv != 0;
+        for (u32 i = 0; i < M; ++i) {
+            mx[lane] = 0;
+            wave_sync();
+            if (cv != 0) atomicMax(&mx[cr], cv);
+            if (lalive) atomicMax(&mx[rl], Lhv);
+            wave_sync();
+            const u32 mc = mx[cr], ml = mx[rl];
+            if (cv != 0 && cv == mc) wt[cr] = ctax;            // packed words are unique: one winner per rank
+            if (lalive && Lhv == ml) wt[rl] = Ltax;
+            wave_sync();
+            const u32 wtc = wt[cr], wtl = wt[rl];
+            if (lslot && li == i && ml != 0) { Ntax = wtl; Nhv = ml; }
+            if (cv != 0 && ctax == wtc) cv = 0;                // mc != 0 here, so wt[cr] is this round's winner
+            if (lalive && Ltax == wtl) lalive = false;
+            wave_sync();
+        }
+        Ltax = Ntax; Lhv = Nhv;
+    }
+
+    // 3. tree fold, one round of the tree at a time: its edges touch disjoint ranks, so every receiver
+    //    selects from receiver-list ++ sender-list in the same M rounds (positions decide ties)
+    if (P > 1) {
+        u32 lb = 0;
+        for (u32 L = 0; L < opt.n_levels; ++L) {
+            const u32 le = opt.level_end[L];
+            u32 my_rcv = 63; bool part = false, is_snd = false;
+            for (u32 e = lb; e < le; ++e) {
+                const u32 snd = opt.fold_snd[e], rcv = opt.fold_rcv[e];
+                if (rl == snd) { my_rcv = rcv; part = true; is_snd = true; }
+                if (rl == rcv) { my_rcv = rcv; part = true; }
+            }
+            lb = le;
+            part = part && lslot;
+            const bool mine = part && Lhv != 0 && !(opt.quirk_seq_drop && is_snd && (Ltax & 0x80000000u));
+            u32 fk = mine ? ((Lhv >> JB) << 8) | (255u - (is_snd ? M + li : li)) : 0u;
+            u32 Ntax = MCQ_EMPTY, Nhv = 0;
+            for (u32 i = 0; i < M; ++i) {
+                mx[lane] = 0;
+                wave_sync();
+                if (fk != 0) atomicMax(&mx[my_rcv], fk);
+                wave_sync();
+                const u32 m = mx[my_rcv];
+                if (fk != 0 && fk == m) wt[my_rcv] = Ltax;
+                wave_sync();
+                const u32 wtax = wt[my_rcv];
+                if (part && m != 0) {
+                    if (!is_snd && li == i) { Ntax = wtax; Nhv = (m >> 8) << JB; }
+                    if (fk != 0 && Ltax == wtax) fk = 0;
+                }
+                wave_sync();
+            }
+            if (part) { Ltax = Ntax; Lhv = Nhv; }
+        }
+    }
+
+    // list 0 is the result
+    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lhv != 0));
+    if (lane < n) {
+        u32 beg = 0, end = 0;
+        if (P == 1) best_range<u32, u32, JB>(buf, Lhv, numWindows, wb, beg, end);
+        uint4 v; v.x = Ltax; v.y = Lhv >> JB; v.z = beg; v.w = end;
         reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
     }
     if (lane == 0) out.ncand[q] = n;

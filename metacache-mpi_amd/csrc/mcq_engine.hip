@@ -255,6 +255,11 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 //   per slot: a key occurs at most once per feature, <= 64 times), hits[128..256) compaction list,
 //   hits[256..384) SK, hits[384..512) WP.
 #define MCQ_DEDUP_MAX_T 384u
+#ifdef MCQ_TOPK_DPP        // tuning knob: DPP reductions per rank instead of LDS maxima for all ranks at once
+#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write<u32, u32, 9>(db, opt, out, sk, h, D, nw, wb, q, lane)
+#else
+#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write_lds(db, opt, out, sk, h, D, nw, wb, q, lane, (h) + 256)
+#endif
 __device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 23; }
 __device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 256; }
 __device__ __forceinline__ u32* dedup_wp(u32* hits) { return hits + 384; }
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                 if (D != ~0u) {
                     sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
                     if (stop == 5) { if (buf[lane] == 0x12345u) out.ncand[q] = 1; wave_sync(); continue; }
-                    st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, dedup_sk(hits), buf, D, numWindows, db.wb, q, lane);
+                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, q, lane);
                     wave_sync();
                     continue;
                 }
@@ -717,7 +722,7 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
                 else               D = load_dedup_sort<6>(src, buf, hits, T, lane);
                 if (D != ~0u) {
                     sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
-                    st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, dedup_sk(hits), buf, D, numWindows, db.wb, q, lane);
+                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, q, lane);
                     wave_sync();
                     continue;
                 }
@@ -964,13 +969,14 @@ static int device_exclusive_scan(const InT* in, u64* out, u64 n, hipStream_t st)
 // Fold schedule of the reference's merge loop (src/querying.h:867-1073): senders = odd
 // ranks, receivers = even ranks, i-th sender -> i-th receiver; used senders retire, every
 // second used receiver becomes a sender; floor(log2 P) rounds.
-static void fold_schedule(u32 P, std::vector<std::pair<u32, u32>>& sched) {
+static void fold_schedule(u32 P, std::vector<std::pair<u32, u32>>& sched, std::vector<u32>* level_end = nullptr) {
     std::vector<u32> snd, rcv;
     for (u32 i = 0; i < P; ++i) (i % 2 ? snd : rcv).push_back(i);
     for (u32 k = P; k > 1; k /= 2) {
         size_t np = std::min(snd.size(), rcv.size());
         std::vector<u32> us(snd.begin(), snd.begin() + np), ur(rcv.begin(), rcv.begin() + np);
         for (size_t i = 0; i < np; ++i) sched.emplace_back(us[i], ur[i]);
+        if (level_end && np) level_end->push_back((u32)sched.size());
         std::vector<u32> ns(snd.begin() + np, snd.end()), nr;
         for (size_t i = 0; i < rcv.size(); ++i) {
             if (i < np && (i % 2) == 1) ns.push_back(rcv[i]); else nr.push_back(rcv[i]);
@@ -994,9 +1000,12 @@ static int make_opt(const mcq_query_opts* o, OptDev& d) {
     d.raw_sort = (o->flags & MCQ_FORCE_RAW_SORT) ? 1 : 0;
     d.insert_size_max = o->insert_size_max;
     std::vector<std::pair<u32, u32>> sched;
-    fold_schedule(P, sched);
-    if (sched.size() > MCQ_MAX_FOLD) return fail(MCQ_E_UNSUPPORTED, "fold schedule too long");
+    std::vector<u32> level_end;
+    fold_schedule(P, sched, &level_end);
+    if (sched.size() > MCQ_MAX_FOLD || level_end.size() > 8) return fail(MCQ_E_UNSUPPORTED, "fold schedule too long");
     d.n_fold = (u32)sched.size();
+    d.n_levels = (u32)level_end.size();
+    for (size_t i = 0; i < level_end.size(); ++i) d.level_end[i] = (unsigned char)level_end[i];
     for (size_t i = 0; i < sched.size(); ++i) { d.fold_snd[i] = (unsigned char)sched[i].first; d.fold_rcv[i] = (unsigned char)sched[i].second; }
     return MCQ_OK;
 }

@@ -121,3 +121,20 @@ def test_db_roundtrip_lookup(world):
             src = locs[torch.repeat_interleave(starts, exp_len[mine]) + within]
             assert torch.equal(out[:-1], src)
         assert total == keys.numel()
+
+
+@pytest.mark.parametrize("P,M", [(3, 2), (5, 4), (6, 4), (8, 4), (8, 8), (16, 4), (32, 2), (64, 1)])
+def test_fold_orders_of_other_rank_counts(world, P, M):
+    """tree-fold schedules with several edges per round and the reference's non-power-of-two behaviour"""
+    eng, synth, gb, goff, dbs = world
+    db, odb = dbs[2]
+    n, L = 20000, 150
+    reads, off, _ = synth.sample_reads(gb, goff, n, L, 0.01, 0.002, seed=300 + P)
+    ws = eng.Workspace(db, n, n * L)
+    rb = reads.cpu().numpy().tobytes(); ro = off.cpu().numpy().astype(np.uint64)
+    for quirk in (0, 1):
+        oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, quirk_seq_drop=quirk, threads=8)
+        for flags in (0, eng.MCQ_FORCE_RAW_SORT):
+            cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P,
+                                         flags=flags | (eng.MCQ_QUIRK_SEQ_DROP if quirk else 0))
+            _compare(cands, ncand, oc, on, "P=%d M=%d quirk=%d flags=%x" % (P, M, quirk, flags))
