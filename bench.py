@@ -73,6 +73,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly one JSON line: libraries that print to fd 1 (RCCL's version banner at communicator
+    # creation does) are sent to stderr; emit() below writes the line to the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     if world > 1 or a.mode == "sharded":
         import datetime
         import torch.distributed as dist
@@ -168,8 +178,10 @@ def main():
     t_setup = time.time() - t_setup
 
     def step_sharded(i):
+        # the next step's batch is announced so that its sketching runs on the second stream under this step's exchange
+        nxt = (batches[(i + 1) % nb], offsets[(i + 1) % nb], B) if i + 1 < a.warmup + a.steps else None
         sharded.query(batches[i % nb], offsets[i % nb], B, paired, cands, ncand, max_cand=a.max_cand,
-                      emulate_ranks=a.emulate_ranks, n_win_hint=n_win_per_batch)
+                      emulate_ranks=a.emulate_ranks, n_win_hint=n_win_per_batch, next_batch=nxt)
 
     def step_fused(i):
         r, ro = batches[i % nb], offsets[i % nb]
@@ -279,8 +291,8 @@ def main():
 
         def give_up():
             if rank == 0:
-                print(json.dumps(make_line("replicas" if world > 1 else "single", None,
-                                           "watchdog: sharded leg did not finish within %d s" % a.sharded_timeout, None)), flush=True)
+                emit(make_line("replicas" if world > 1 else "single", None,
+                               "watchdog: sharded leg did not finish within %d s" % a.sharded_timeout, None))
             sys.stderr.write("[bench rank %d] sharded leg timed out; exiting\n" % rank); sys.stderr.flush()
             os._exit(0)
         dog = threading.Timer(a.sharded_timeout, give_up)
@@ -317,7 +329,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches, offsets, (a.warmup + a.steps - 1) % nb,
                                            cands, ncand, B, paired)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1 or a.mode == "sharded":
         import torch.distributed as dist
         if sharded_error:            # a rank that failed inside the exchange may have left its peers in a collective

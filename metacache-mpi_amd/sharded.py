@@ -96,6 +96,24 @@ class HipBackend:
     def stats(self):
         return self.ws.sync(self._st())
 
+    def prepare(self, bases, seq_off, n_seqs, n_shards, n_win_hint, stream):
+        """Steps 1-2 (sketch + bucket) enqueued on `stream` with no host wait: the per-shard counts go to
+        pinned memory behind an event.  Lets the next batch's sketching run under this batch's exchange."""
+        with torch.cuda.stream(stream):
+            win_off, feats = self.sketch(bases, seq_off, n_seqs, n_win_hint)
+            flat = feats.reshape(-1)
+            n = flat.numel()
+            counts = torch.empty(2 * n_shards, dtype=torch.int64, device=self.dev)
+            bucketed = torch.empty(max(n, 1), dtype=torch.int32, device=self.dev)
+            src = torch.empty(max(n, 1), dtype=torch.int32, device=self.dev)
+            engine.bucket_features(flat.data_ptr(), n, n_shards, counts.data_ptr(), bucketed.data_ptr(), src.data_ptr(), self._st())
+            host_counts = torch.empty(n_shards, dtype=torch.int64, pin_memory=True)
+            host_counts.copy_(counts[:n_shards], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return {"win_off": win_off, "F": n, "bucketed": bucketed, "src": src, "host_counts": host_counts, "event": ev,
+                "keep": (feats, counts), "key": (bases.data_ptr(), seq_off.data_ptr(), n_seqs)}
+
 
 def _a2a(out_numel, inp, send_counts, recv_counts, group):
     """all_to_all_single with explicit split sizes.  On the GPU node the backend is nccl (RCCL)
@@ -116,16 +134,38 @@ class ShardedQuery:
         self.be = backend if backend is not None else HipBackend(db, dev, max_queries)
         self.s = self.be.s
         self._last = {}
+        self._prepared = None
+        self._side = torch.cuda.Stream(device=dev) if (backend is None and torch.cuda.is_available()) else None
 
     def query(self, bases, seq_off, n_seqs, paired, cands, ncand, max_cand=2, emulate_ranks=1, insert_size_max=0,
-              flags=0, n_win_hint=None):
+              flags=0, n_win_hint=None, next_batch=None):
+        """next_batch = (bases, seq_off, n_seqs) of the following call (needs n_win_hint): its sketching and
+        bucketing are enqueued on a second stream now and run under this batch's exchange."""
         N, be, s = self.world, self.be, self.s
         nq = n_seqs // 2 if paired else n_seqs
-        # 1-2. sketch, bucket by owner
-        win_off, feats = be.sketch(bases, seq_off, n_seqs, n_win_hint)
-        F = feats.numel()
-        send_counts, bucketed, src_idx = be.bucket(feats.reshape(-1), N)
-        m = bucketed.numel()
+        # 1-2. sketch, bucket by owner (already under way if the previous call was told about this batch)
+        prep, self._prepared = self._prepared, None
+        if prep is not None and prep["key"] != (bases.data_ptr(), seq_off.data_ptr(), n_seqs):
+            prep["event"].synchronize()
+            prep = None
+        if prep is not None:
+            main = torch.cuda.current_stream(self.dev)
+            prep["event"].synchronize()                    # host: the counts are in pinned memory
+            main.wait_event(prep["event"])
+            send_counts = prep["host_counts"].tolist()
+            m = sum(send_counts)
+            win_off, F = prep["win_off"], prep["F"]
+            bucketed, src_idx = prep["bucketed"][:m], prep["src"][:m]
+            for t in (win_off, prep["bucketed"], prep["src"]) + tuple(prep["keep"]):
+                t.record_stream(main)
+        else:
+            win_off, feats = be.sketch(bases, seq_off, n_seqs, n_win_hint)
+            F = feats.numel()
+            send_counts, bucketed, src_idx = be.bucket(feats.reshape(-1), N)
+            m = bucketed.numel()
+        if next_batch is not None and self._side is not None and n_win_hint is not None and hasattr(be, "prepare"):
+            self._side.wait_stream(torch.cuda.current_stream(self.dev))     # the next batch's inputs are ready
+            self._prepared = be.prepare(next_batch[0], next_batch[1], next_batch[2], N, n_win_hint, self._side)
         # 3. counts, then features to their owners
         sc = torch.tensor(send_counts, dtype=torch.int64, device=bucketed.device)
         rc = _a2a(N, sc, [1] * N, [1] * N, self.group)
