@@ -662,19 +662,31 @@ __global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* feat
         u32 incl = wave_incl_scan(len, lane);
         u32 pos = incl - len;
         const u32 T = bcast(incl, 63);
-        for (u32 base = 0; base < T; base += 64) {
-            const u32 t = base + lane;
-            const u32 tt = t < T ? t : T - 1;
-            u32 lo = 0;
+        for (u32 base = 0; base < T; base += 256) {           // four 64-element chunks in flight per round trip
+            KeyT v[4];
 #pragma unroll
-            for (u32 step = 32; step > 0; step >>= 1) {
-                u32 c = lo + step;
-                u32 pc = __shfl(pos, (int)(c & 63), 64);
-                if (c < 64 && pc <= tt) lo = c;
+            for (int u = 0; u < 4; ++u) {
+                v[u] = 0;
+                if (base + (u32)(u * 64) < T) {
+                    const u32 t = base + u * 64 + lane;
+                    const u32 tt = t < T ? t : T - 1;
+                    u32 lo = 0;
+#pragma unroll
+                    for (u32 step = 32; step > 0; step >>= 1) {
+                        u32 c = lo + step;
+                        u32 pc = __shfl(pos, (int)(c & 63), 64);
+                        if (c < 64 && pc <= tt) lo = c;
+                    }
+                    u32 pj = __shfl(pos, (int)lo, 64);
+                    u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
+                    if (t < T) v[u] = locs[(((u64)ohi << 32) | olo) + (tt - pj)];
+                }
             }
-            u32 pj = __shfl(pos, (int)lo, 64);
-            u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
-            if (t < T) out_locs[obase + t] = locs[(((u64)ohi << 32) | olo) + (tt - pj)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u32 t = base + u * 64 + lane;
+                if (t < T) out_locs[obase + t] = v[u];
+            }
         }
     }
 }
