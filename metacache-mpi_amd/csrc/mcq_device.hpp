@@ -243,8 +243,9 @@ __device__ __forceinline__ u64 cmpex(u64 v, u64 o, u64 keepmin) {
     asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 " DPP_MIN "\n\tv_max_u32_dpp %0, %1, %1 " DPP_MAX \
         : "=&v"(r_) : "v"(v)); v = r_; } while (0)
 #define MCQ_CX3(v, DPP, MASK32) do { u32 lo_, hi_; \
-    asm("s_nop 1\n\tv_min_u32_dpp %0, %2, %2 " DPP MCQ_DPP_ALL "\n\tv_max_u32_dpp %1, %2, %2 " DPP MCQ_DPP_ALL "\n\t" \
-        "s_mov_b32 vcc_lo, " MASK32 "\n\ts_mov_b32 vcc_hi, " MASK32 "\n\tv_cndmask_b32_e32 %0, %1, %0, vcc" \
+    asm("s_mov_b32 vcc_lo, " MASK32 "\n\ts_mov_b32 vcc_hi, " MASK32 "\n\t"   /* the two wait states before the DPP reads */ \
+        "v_min_u32_dpp %0, %2, %2 " DPP MCQ_DPP_ALL "\n\tv_max_u32_dpp %1, %2, %2 " DPP MCQ_DPP_ALL "\n\t" \
+        "v_cndmask_b32_e32 %0, %1, %0, vcc" \
         : "=&v"(lo_), "=&v"(hi_) : "v"(v) : "vcc"); v = lo_; } while (0)
 
 // half-cleaners at lane distance 8, 4, 2, 1 (ascending everywhere)
