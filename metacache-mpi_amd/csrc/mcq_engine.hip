@@ -461,10 +461,11 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 // ------------------------------------------------------------------ kernel: workgroup per query
 // exclusive scan of a[0..n) in place by the whole workgroup; returns the total
 __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w /* >= 18 words */) {
+    const u32 NTB = blockDim.x;
     const u32 lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_w[17] = 0;
     __syncthreads();
-    for (u32 base = 0; base < n; base += 1024) {
+    for (u32 base = 0; base < n; base += NTB) {
         u32 i = base + tid;
         u32 v = (i < n) ? a[i] : 0;
         u32 x = wave_incl_scan(v, lane);
@@ -475,37 +476,46 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
         u32 carry = s_w[17];
         if (i < n) a[i] = carry + woff + x - v;
         __syncthreads();
-        if (tid == 1023) s_w[17] = carry + woff + x;
+        if (tid == NTB - 1) s_w[17] = carry + woff + x;
         __syncthreads();
     }
     return s_w[17];
 }
 
 // Tail of the workgroup path: fill B[0..n2p) through `load(t)`, sort, sweep, top lists.
-template <class KeyT, bool kLds, class Load>
+// HT/JB: packed (hits << JB | index) word of the sweep: u32 with JB = 13 when the list fits the workgroup's LDS
+// (<= 8192 entries, hits <= 8192), u64 with JB = 32 in global scratch
+template <class KeyT, class HT, int JB, class Fill>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
-                                           KeyT* B, u64* H, u32 T, u32 numWindows, u32 wb, u64 q, u32 tid,
-                                           const DebugDev& dbg, Load load) {
-    const u32 n2p = pow2ceil(T);
-    for (u32 t = tid; t < n2p; t += 1024) B[t] = (t < T) ? load(t) : key_pad<KeyT>();
+                                           KeyT* B, HT* H, u32 T, u32 numWindows, u32 wb, u64 q, u32 tid,
+                                           const DebugDev& dbg, Fill fill) {
+    const u32 n2p = pow2ceil(T), NTB = blockDim.x;
+    fill(B);                                                   // B[0..T) = the unsorted match list
+    for (u32 t = T + tid; t < n2p; t += NTB) B[t] = key_pad<KeyT>();
     __syncthreads();
-    bitonic_sort(B, n2p, tid, 1024u, [] { __syncthreads(); });
+    bitonic_sort(B, n2p, tid, NTB, [] { __syncthreads(); });
     if (dbg.mode == 2) {
-        for (u32 t = tid; t < T; t += 1024) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], wb);
+        for (u32 t = tid; t < T; t += NTB) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], wb);
     }
-    sweep_targets<KeyT, u64, 32>(B, H, T, numWindows, wb, tid, 1024u, [] { __syncthreads(); });
+    sweep_targets<KeyT, HT, JB>(B, H, T, numWindows, wb, tid, NTB, [] { __syncthreads(); });
     if (tid < 64) {
-        u32 n = topk_fold_write<KeyT, u64, 32>(db, opt, out, B, H, T, numWindows, wb, q, tid);
+        u32 n = topk_fold_write<KeyT, HT, JB>(db, opt, out, B, H, T, numWindows, wb, q, tid);
         if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
     }
     __syncthreads();
 }
 
-template <class KeyT, int LCAPB>
-__global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
+// NT threads per workgroup; LCAPB entries of the match list fit its LDS (longer lists are sorted in global scratch).
+// 32-bit keys: 8192 x (4 + 4) B = 64 KB of LDS and 64 VGPRs, so two 1024-thread workgroups share a CU -- the phases
+// of a query are serialised by workgroup barriers, and the second workgroup fills the gaps (+45 % on 8 kb reads;
+// <4096, 512> with four per CU is slower: 15 % of those reads then sort in global scratch).
+template <class KeyT, int LCAPB, int NT>
+__global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                       CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg) {
+    static_assert(LCAPB <= 8192, "packed sweep word: 13 index bits");
+    constexpr u32 NW16 = NT / 64;
     __shared__ KeyT s_buf[LCAPB];
-    __shared__ u64 s_hits[LCAPB];
+    __shared__ u32 s_hits[LCAPB];
     __shared__ u32 s_w[20];
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -517,7 +527,7 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
     u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
     const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
     const u32 n_ovf = ctr->ovf_count;
-    u32* sk = reinterpret_cast<u32*>(s_hits) + wave * 128;     // per-wave sketch scratch (hit words unused yet)
+    u32* sk = s_hits + wave * 128;                             // per-wave sketch scratch (hit words unused yet)
 
     for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
         const u64 q = ovf_list[it];
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
         }
         if (tid == 0) { s_w[18] = 0; s_w[19] = 0; }
         __syncthreads();
-        for (u32 w = wave; w < (u32)NW; w += 16) {
+        for (u32 w = wave; w < (u32)NW; w += NW16) {
             const bool m2 = w >= nw1;
             const u64 n = m2 ? n2 : n1;
             const u64 sb = m2 ? o1 : o0;
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
         __syncthreads();
         const u32 F = s_w[18];
         u32 nhit = 0;
-        for (u32 i = tid; i < F; i += 1024) {
+        for (u32 i = tid; i < F; i += NT) {
             u64 off; u32 len;
             probe(db, feat[i], off, len);
             foff[i] = off; fpos[i] = len; nhit += (len > 0);
@@ -570,13 +580,50 @@ __global__ __launch_bounds__(1024) void k_query_block(DbDev db, BatchDev b, OptD
             continue;
         }
         const u32 numWindows = range_width(n1 + n2, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        auto load = [&](u32 t) -> KeyT {
-            u32 lo = 0, hi = F;                       // last j in [0,F) with fpos[j] <= t
-            while (hi - lo > 1) { u32 mid = (lo + hi) >> 1; if (fpos[mid] <= t) lo = mid; else hi = mid; }
-            return locs[foff[lo] + (t - fpos[lo])];
+        // every wave copies the lists of 64 features at a time (fpos = exclusive scan of the list lengths): list of
+        // an element by a shuffle search inside the group, four 64-element chunks of loads in flight
+        auto fill = [&](KeyT* B) {
+            for (u32 g = wave; g * 64 < F; g += NW16) {
+                const u32 i = g * 64 + lane;
+                const bool valid = i < F;
+                const u32 start = valid ? fpos[i] : T;
+                const u32 next = (i + 1 < F) ? fpos[i + 1] : T;
+                const u32 len = valid ? next - start : 0;
+                const u64 off = valid ? foff[i] : 0;
+                const u32 incl = wave_incl_scan_dpp(len);
+                const u32 pos = incl - len;
+                const u32 Tg = bcast(incl, 63);
+                const u32 gbase = bcast(start, 0);
+                for (u32 base = 0; base < Tg; base += 256) {
+                    KeyT v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v[u] = 0;
+                        if (base + (u32)(u * 64) < Tg) {
+                            const u32 t = base + u * 64 + lane;
+                            const u32 tt = t < Tg ? t : Tg - 1;
+                            u32 lo = 0;
+#pragma unroll
+                            for (u32 step = 32; step > 0; step >>= 1) {
+                                u32 c = lo + step;
+                                u32 pc = __shfl(pos, (int)(c & 63), 64);
+                                if (c < 64 && pc <= tt) lo = c;
+                            }
+                            const u32 pj = __shfl(pos, (int)lo, 64);
+                            const u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
+                            if (t < Tg) v[u] = locs[(((u64)ohi << 32) | olo) + (tt - pj)];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const u32 t = base + u * 64 + lane;
+                        if (t < Tg) B[gbase + t] = v[u];
+                    }
+                }
+            }
         };
-        if (pow2ceil(T) <= (u32)LCAPB) block_tail<KeyT, true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, load);
-        else                           block_tail<KeyT, false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, load);
+        if (pow2ceil(T) <= (u32)LCAPB) block_tail<KeyT, u32, 13>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, fill);
+        else                           block_tail<KeyT, u64, 32>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, fill);
     }
 }
 
@@ -757,7 +804,7 @@ template <class KeyT, int LCAPB>
 __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
                                                        ScratchDev sc, const u64* loc_off, const KeyT* locs, const u32* query_len) {
     __shared__ KeyT s_buf[LCAPB];
-    __shared__ u64 s_hits[LCAPB];
+    __shared__ u32 s_hits[LCAPB];
     const u32 tid = threadIdx.x;
     KeyT* gbuf = reinterpret_cast<KeyT*>(sc.gbuf + (u64)blockIdx.x * sc.lmax);
     u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
@@ -773,9 +820,9 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
         const u32 T = (u32)T64;
         if (tid == 0) atomicAdd(&ctr->n_locations, (unsigned long long)T);
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        auto load = [&](u32 t) -> KeyT { return locs[b0 + t]; };
-        if (pow2ceil(T) <= (u32)LCAPB) block_tail<KeyT, true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, load);
-        else                           block_tail<KeyT, false>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, load);
+        auto fill = [&](KeyT* B) { for (u32 t = tid; t < T; t += 1024) B[t] = locs[b0 + t]; };
+        if (pow2ceil(T) <= (u32)LCAPB) block_tail<KeyT, u32, 13>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, fill);
+        else                           block_tail<KeyT, u64, 32>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, fill);
     }
 }
 
@@ -1153,7 +1200,7 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     if (lmax > (1ull << 30)) return fail(MCQ_E_UNSUPPORTED, "max_locs_per_query too large");
     ws->sc.lmax = (u32)lmax;
     ws->sc.fmax = 1u << 15;
-    ws->n_block_wgs = 256;
+    ws->n_block_wgs = 512;                   // two resident workgroups per CU (32-bit keys: 64 KB of LDS, 64 VGPRs)
     ws->ev_used = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     ws->ev_free = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     const u64 nb = (u64)ws->n_block_wgs;
@@ -1213,9 +1260,9 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     if (db->d.compact) hipLaunchKernelGGL((k_query_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
     else               hipLaunchKernelGGL((k_query_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
     if (ws->timing) { HIPCHK(hipEventRecord(e1, st)); ws->ev_used->emplace_back(e0, e1); }
-    if (db->d.compact) hipLaunchKernelGGL((k_query_block<u32, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
+    if (db->d.compact) hipLaunchKernelGGL((k_query_block<u32, kLcapBlock, 1024>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
                                           (const u32*)ws->ovf_list, ws->sc, dbg);
-    else               hipLaunchKernelGGL((k_query_block<u64, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
+    else               hipLaunchKernelGGL((k_query_block<u64, kLcapBlock, 1024>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
                                           (const u32*)ws->ovf_list, ws->sc, dbg);
     HIPCHK(hipGetLastError());
     ws->last_nq = b.nq;
