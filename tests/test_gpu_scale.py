@@ -138,3 +138,32 @@ def test_fold_orders_of_other_rank_counts(world, P, M):
             cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P,
                                          flags=flags | (eng.MCQ_QUIRK_SEQ_DROP if quirk else 0))
             _compare(cands, ncand, oc, on, "P=%d M=%d quirk=%d flags=%x" % (P, M, quirk, flags))
+
+
+def test_many_strains_cross_every_list_size_boundary():
+    """36 strains per species: 300-700 locations and 80-160 distinct (target, window) keys per read, so single-end
+    reads cross the dedup limits (384 locations, 128 distinct keys), the wave kernel's raw-sort sizes and its
+    512-location limit into the workgroup kernel -- all in one batch, against the oracle"""
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    synth = importlib.import_module("metacache-mpi_amd.synth")
+    dev = torch.device("cuda", 0)
+    gb, goff, species = synth.make_genomes(3, 36, 100_000, 140_000, 0.012, seed=77, device=dev)
+    keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=2)
+    odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), off.cpu().numpy().astype(np.uint64),
+                       locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
+    n, L = 30000, 150
+    reads, roff, _ = synth.sample_reads(gb, goff, n, L, 0.004, 0.001, seed=5)
+    rb = reads.cpu().numpy().tobytes(); ro = roff.cpu().numpy().astype(np.uint64)
+    oc, on, st = odb.query(rb, ro, False, max_cand=4, emulate_ranks=2, threads=8, want_stats=True)
+    for flags in (0, eng.MCQ_DB_LOCS_64):
+        db = dbbuild.make_database(keys, off, locs, species, flags=flags)
+        ws = eng.Workspace(db, n, n * L)
+        for qf in (0, eng.MCQ_FORCE_RAW_SORT):
+            cands, ncand = ws.query_host(rb, ro, False, max_cand=4, emulate_ranks=2, flags=qf)
+            _compare(cands, ncand, oc, on, "many strains flags=%x qf=%x" % (flags, qf))
+        s = ws.sync()
+        moff, m = ws.debug_matches(rb[:2000 * L], ro[:2001], False)
+        T = np.diff(moff.astype(np.int64))
+        assert T.max() > 512 and (T <= 384).any() and ((T > 384) & (T <= 512)).any(), np.percentile(T, [1, 25, 50, 75, 99])
+        assert 0 < s["n_overflow"] < n, s         # some reads went to the workgroup kernel, most did not
