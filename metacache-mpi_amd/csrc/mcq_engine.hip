@@ -493,7 +493,7 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
     fill(B);                                                   // B[0..T) = the unsorted match list
     for (u32 t = T + tid; t < n2p; t += NTB) B[t] = key_pad<KeyT>();
     __syncthreads();
-    bitonic_sort(B, n2p, tid, NTB, [] { __syncthreads(); });
+    bitonic_sort_block(B, n2p, tid, NTB, [] { __syncthreads(); });
     if (dbg.mode == 2) {
         for (u32 t = tid; t < T; t += NTB) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], wb);
     }
