@@ -796,6 +796,62 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
     return n;
 }
 
+// Tree fold of the P virtual-rank lists held one entry per lane (list r in lanes [r*seg, r*seg + M)) and the
+// final write of list 0: one round of the tree at a time -- its edges touch disjoint ranks, so every receiver
+// selects from receiver-list ++ sender-list in the same M rounds (positions decide ties).  One wave; mx, wt:
+// 64 words of LDS each.
+template <class KeyT, class HT, int JB>
+__device__ __forceinline__ u32 fold_lists_write(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* buf,
+                                                u32 Ltax, HT Lhv, u32 numWindows, u32 wb, u64 q, u32 lane, u32* mx, u32* wt) {
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    const u32 rl = lane / seg, li = lane - rl * seg;
+    const bool lslot = (li < M) && (rl < P);
+    if (P > 1) {
+        u32 lb = 0;
+        for (u32 L = 0; L < opt.n_levels; ++L) {
+            const u32 le = opt.level_end[L];
+            u32 my_rcv = 63; bool part = false, is_snd = false;
+            for (u32 e = lb; e < le; ++e) {
+                const u32 snd = opt.fold_snd[e], rcv = opt.fold_rcv[e];
+                if (rl == snd) { my_rcv = rcv; part = true; is_snd = true; }
+                if (rl == rcv) { my_rcv = rcv; part = true; }
+            }
+            lb = le;
+            part = part && lslot;
+            const bool mine = part && Lhv != 0 && !(opt.quirk_seq_drop && is_snd && (Ltax & 0x80000000u));
+            u32 fk = mine ? ((u32)(Lhv >> JB) << 8) | (255u - (is_snd ? M + li : li)) : 0u;
+            u32 Ntax = MCQ_EMPTY; HT Nhv = 0;
+            for (u32 i = 0; i < M; ++i) {
+                mx[lane] = 0;
+                wave_sync();
+                if (fk != 0) atomicMax(&mx[my_rcv], fk);
+                wave_sync();
+                const u32 m = mx[my_rcv];
+                if (fk != 0 && fk == m) wt[my_rcv] = Ltax;
+                wave_sync();
+                const u32 wtax = wt[my_rcv];
+                if (part && m != 0) {
+                    if (!is_snd && li == i) { Ntax = wtax; Nhv = (HT)(m >> 8) << JB; }
+                    if (fk != 0 && Ltax == wtax) fk = 0;
+                }
+                wave_sync();
+            }
+            if (part) { Ltax = Ntax; Lhv = Nhv; }
+        }
+    }
+
+    // list 0 is the result
+    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lhv != 0));
+    if (lane < n) {
+        u32 beg = 0, end = 0;
+        if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, wb, beg, end);
+        uint4 v; v.x = Ltax; v.y = (u32)(Lhv >> JB); v.z = beg; v.w = end;
+        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
+    }
+    if (lane == 0) out.ncand[q] = n;
+    return n;
+}
+
 // ---- rows 10-11 with the wave-wide maxima taken in LDS (dedup path: 32-bit keys, packed u32 words) ----
 // Same closed form and the same lane layout of the P virtual-rank lists as topk_fold_write, but a selection
 // round is one ds_max per candidate into the word of its rank instead of a DPP reduction per rank: all P
@@ -856,51 +912,56 @@ __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev
         Ltax = Ntax; Lhv = Nhv;
     }
 
-    // 3. tree fold, one round of the tree at a time: its edges touch disjoint ranks, so every receiver
-    //    selects from receiver-list ++ sender-list in the same M rounds (positions decide ties)
-    if (P > 1) {
-        u32 lb = 0;
-        for (u32 L = 0; L < opt.n_levels; ++L) {
-            const u32 le = opt.level_end[L];
-            u32 my_rcv = 63; bool part = false, is_snd = false;
-            for (u32 e = lb; e < le; ++e) {
-                const u32 snd = opt.fold_snd[e], rcv = opt.fold_rcv[e];
-                if (rl == snd) { my_rcv = rcv; part = true; is_snd = true; }
-                if (rl == rcv) { my_rcv = rcv; part = true; }
-            }
-            lb = le;
-            part = part && lslot;
-            const bool mine = part && Lhv != 0 && !(opt.quirk_seq_drop && is_snd && (Ltax & 0x80000000u));
-            u32 fk = mine ? ((Lhv >> JB) << 8) | (255u - (is_snd ? M + li : li)) : 0u;
-            u32 Ntax = MCQ_EMPTY, Nhv = 0;
-            for (u32 i = 0; i < M; ++i) {
-                mx[lane] = 0;
-                wave_sync();
-                if (fk != 0) atomicMax(&mx[my_rcv], fk);
-                wave_sync();
-                const u32 m = mx[my_rcv];
-                if (fk != 0 && fk == m) wt[my_rcv] = Ltax;
-                wave_sync();
-                const u32 wtax = wt[my_rcv];
-                if (part && m != 0) {
-                    if (!is_snd && li == i) { Ntax = wtax; Nhv = (m >> 8) << JB; }
-                    if (fk != 0 && Ltax == wtax) fk = 0;
-                }
-                wave_sync();
-            }
-            if (part) { Ltax = Ntax; Lhv = Nhv; }
-        }
-    }
+    return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, wb, q, lane, mx, wt);
+}
 
-    // list 0 is the result
-    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lhv != 0));
-    if (lane < n) {
-        u32 beg = 0, end = 0;
-        if (P == 1) best_range<u32, u32, JB>(buf, Lhv, numWindows, wb, beg, end);
-        uint4 v; v.x = Ltax; v.y = Lhv >> JB; v.z = beg; v.w = end;
-        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
+// ---- rows 10-11 for the workgroup kernels ----------------------------------------------------------
+// After the sweep H[j] != 0 marks the head of a target's run and holds its packed best.  All threads offer
+// their heads to the list of the head's virtual rank (ds_max per rank; all ranks in the same round, M rounds,
+// retired heads are zeroed in H), then wave 0 folds the P lists.  scr: 64 HT maxima, 64 winner taxa, the lists
+// (64 taxa + 64 HT words) in lane layout -- LDS of the workgroup.
+template <class HT> struct TopkBlockScratch { HT mx[64]; HT lhv[64]; u32 wt[64]; u32 ltax[64]; u32 fmx[64]; u32 fwt[64]; };
+
+template <class KeyT, class HT, int JB, class Sync>
+__device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* B, HT* H,
+                                          u32 T, u32 numWindows, u32 wb, u64 q, u32 tid, u32 NTB,
+                                          TopkBlockScratch<HT>* scr, Sync sync) {
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    const bool p2 = (P & (P - 1)) == 0;
+    if (tid < 64) { scr->ltax[tid] = MCQ_EMPTY; scr->lhv[tid] = 0; }
+    for (u32 i = 0; i < M; ++i) {
+        if (tid < 64) scr->mx[tid] = 0;
+        sync();
+        for (u32 j = tid; j < T; j += NTB) {
+            const HT v = H[j];
+            if (v == 0) continue;
+            const u32 tgt = (u32)(B[j] >> wb);
+            const u32 tax = tgt < db.n_targets ? db.tgt2tax[tgt] : MCQ_EMPTY;
+            if (tax == MCQ_EMPTY) { H[j] = 0; continue; }
+            const u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+            atomicMax(&scr->mx[r], v);
+        }
+        sync();
+        for (u32 j = tid; j < T; j += NTB) {
+            const HT v = H[j];
+            if (v == 0) continue;
+            const u32 tgt = (u32)(B[j] >> wb);
+            const u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+            if (v == scr->mx[r]) scr->wt[r] = db.tgt2tax[tgt];       // packed words are unique: one winner per rank
+        }
+        sync();
+        for (u32 j = tid; j < T; j += NTB) {
+            const HT v = H[j];
+            if (v == 0) continue;
+            const u32 tgt = (u32)(B[j] >> wb);
+            const u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+            if (db.tgt2tax[tgt] == scr->wt[r]) H[j] = 0;            // every head of the winner's taxon retires
+        }
+        if (tid < P && scr->mx[tid] != 0) { scr->ltax[tid * seg + i] = scr->wt[tid]; scr->lhv[tid * seg + i] = scr->mx[tid]; }
+        sync();
     }
-    if (lane == 0) out.ncand[q] = n;
+    u32 n = 0;
+    if (tid < 64) n = fold_lists_write<KeyT, HT, JB>(db, opt, out, B, scr->ltax[tid], scr->lhv[tid], numWindows, wb, q, tid, scr->fmx, scr->fwt);
     return n;
 }
 
