@@ -12,6 +12,7 @@
  *   mcq_refdb_classify  classify()                        src/classification.cpp:235-265
  *                       ranked_lca()                      src/taxonomy.h:531-537
  *   mcq_rank_from_name  taxonomy::rank_from_name          src/taxonomy.h:173-213
+ *   mcq_refdb_write_shard  sketch_database::write         src/sketch_database.h:959-998
  *
  * A taxon *key* is the index of the taxon in the database's taxon list; bit 31 marks a
  * sequence-level taxon (rank Sequence), 0xFFFFFFFF is "no taxon".  These are the keys
@@ -41,6 +42,29 @@ typedef struct {
 #define MCQ_RANK_DOMAIN 19u
 #define MCQ_RANK_ROOT 20u
 #define MCQ_RANK_NONE 21u
+
+/* ---- writing a shard file the reference can read (sketch_database::write src/sketch_database.h:959-998,
+ * hash_multimap::serialize src/hash_multimap.h:972-1029, taxon write_binary src/taxonomy.h:326-335) ------
+ * One file = one rank: its parameters, the whole taxon list (sequence-level taxa have id -(target+1);
+ * `windows` is non-zero only for the targets this rank owns) and this rank's table.  keys / list_off /
+ * locs as in mcq_db_desc ((tgt << 32) | win, lists sorted, at most 255 entries each), host memory.
+ * Keys are written in the order given (the reference's reader inserts them one by one, any order works). */
+typedef struct {
+    int64_t id, parent;
+    uint8_t rank;               /* MCQ_RANK_* / taxonomy::rank, 21 = none */
+    const char* name;
+    const char* file;           /* source file name of a sequence-level taxon, "" otherwise */
+    uint64_t index;             /* source.index */
+    uint64_t windows;           /* source.windows */
+} mcq_taxon_rec;
+typedef struct {
+    uint64_t k, sketch_size, winlen, winstride;         /* target sketcher            */
+    uint64_t q_k, q_sketch_size, q_winlen, q_winstride; /* query sketcher             */
+    uint64_t max_locs_per_feature;
+} mcq_shard_params;
+int mcq_refdb_write_shard(const char* path, const mcq_shard_params* params, const mcq_taxon_rec* taxa, uint64_t n_taxa,
+                          uint32_t n_targets, const uint32_t* keys, const uint64_t* list_off, const uint64_t* locs,
+                          uint64_t n_keys);
 
 /* reads <prefix>.db_0 .. <prefix>.db_<n_ranks-1> and unions their tables */
 int mcq_refdb_open(const char* prefix, uint32_t n_ranks, mcq_refdb** out);

@@ -134,6 +134,65 @@ extern "C" int mcq_refdb_open(const char* prefix, uint32_t n_ranks, mcq_refdb** 
 }
 
 extern "C" int mcq_refdb_close(mcq_refdb* db) { delete db; return 0; }
+
+// ---- shard writer: the exact inverse of the reader above
+namespace {
+struct Writer {
+    FILE* f; bool ok = true;
+    template <class T> void put(T v) { if (ok && std::fwrite(&v, sizeof(T), 1, f) != 1) ok = false; }
+    void str(const char* s) {
+        const uint64_t n = s ? std::strlen(s) : 0;
+        put<uint64_t>(n);
+        if (ok && n && std::fwrite(s, 1, n, f) != n) ok = false;
+    }
+};
+}  // namespace
+
+extern "C" int mcq_refdb_write_shard(const char* path, const mcq_shard_params* p, const mcq_taxon_rec* taxa, uint64_t n_taxa,
+                                     uint32_t n_targets, const uint32_t* keys, const uint64_t* list_off, const uint64_t* locs,
+                                     uint64_t n_keys) {
+    if (!path || !p || (n_taxa && !taxa) || (n_keys && (!keys || !list_off || !locs))) return fail("bad argument");
+    for (uint64_t i = 0; i < n_keys; ++i)
+        if (list_off[i + 1] < list_off[i] || list_off[i + 1] - list_off[i] > 255)
+            return fail("a list has more than 255 locations (bucket size type is uint8, src/config.h:77)");
+    Writer w; w.f = std::fopen(path, "wb");
+    if (!w.f) return fail(std::string("can't open file ") + path);
+    w.put<uint64_t>(kDbVersion);
+    const uint8_t widths[6] = {4, 4, 4, 1, 8, (uint8_t)kNumRanks};
+    for (uint8_t x : widths) w.put<uint8_t>(x);
+    const uint64_t pv[9] = {p->k, p->sketch_size, p->winlen, p->winstride, p->q_k, p->q_sketch_size, p->q_winlen, p->q_winstride,
+                            p->max_locs_per_feature};
+    for (uint64_t x : pv) w.put<uint64_t>(x);
+    w.put<uint64_t>(n_taxa);
+    for (uint64_t i = 0; i < n_taxa; ++i) {
+        w.put<int64_t>(taxa[i].id); w.put<int64_t>(taxa[i].parent); w.put<uint8_t>(taxa[i].rank);
+        w.str(taxa[i].name); w.str(taxa[i].file);
+        w.put<uint64_t>(taxa[i].index); w.put<uint64_t>(taxa[i].windows);
+    }
+    w.put<uint32_t>(n_targets);
+    if (n_targets >= 1) {
+        uint64_t nonempty = 0;
+        for (uint64_t i = 0; i < n_keys; ++i) nonempty += list_off[i + 1] > list_off[i];
+        w.put<uint64_t>(nonempty);
+        w.put<uint64_t>(n_keys ? list_off[n_keys] - list_off[0] : 0);
+        std::vector<uint32_t> col;
+        for (uint64_t i = 0; i < n_keys; ++i) {
+            const uint64_t b = list_off[i], n = list_off[i + 1] - b;
+            if (n == 0) continue;
+            w.put<uint32_t>(keys[i]); w.put<uint8_t>((uint8_t)n);
+            col.resize(n);
+            w.put<uint64_t>(n);
+            for (uint64_t j = 0; j < n; ++j) col[j] = (uint32_t)(locs[b + j] >> 32);
+            if (w.ok && std::fwrite(col.data(), 4, n, w.f) != n) w.ok = false;
+            w.put<uint64_t>(n);
+            for (uint64_t j = 0; j < n; ++j) col[j] = (uint32_t)locs[b + j];
+            if (w.ok && std::fwrite(col.data(), 4, n, w.f) != n) w.ok = false;
+        }
+    }
+    const bool ok = w.ok;
+    if (std::fclose(w.f) != 0 || !ok) return fail(std::string("write error on ") + path);
+    return 0;
+}
 extern "C" int mcq_refdb_get_info(const mcq_refdb* db, mcq_refdb_info* out) { if (!db || !out) return fail("bad argument"); *out = db->info; return 0; }
 extern "C" const uint32_t* mcq_refdb_keys(const mcq_refdb* db) { return db->keys.data(); }
 extern "C" const uint64_t* mcq_refdb_list_off(const mcq_refdb* db) { return db->off.empty() ? nullptr : db->off.data(); }

@@ -16,7 +16,35 @@ class Info(C.Structure):
                 ("n_taxa", C.c_uint32), ("n_keys", C.c_uint64), ("n_locs", C.c_uint64)]
 
 
+class TaxonRec(C.Structure):
+    _fields_ = [("id", C.c_int64), ("parent", C.c_int64), ("rank", C.c_uint8), ("name", C.c_char_p), ("file", C.c_char_p),
+                ("index", C.c_uint64), ("windows", C.c_uint64)]
+
+
+class ShardParams(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("k", "sketch_size", "winlen", "winstride", "q_k", "q_sketch_size", "q_winlen",
+                                         "q_winstride", "max_locs_per_feature")]
+
+
 _lib = None
+
+
+def write_shard(path, params, taxa, n_targets, keys, list_off, locs):
+    """mcq_refdb_write_shard.  params: dict with the ShardParams field names; taxa: list of dicts
+    (id, parent, rank, name, file, index, windows); keys u32, list_off u64 [n+1], locs u64 (tgt<<32|win)."""
+    sp = ShardParams(**{k: int(v) for k, v in params.items()})
+    arr = (TaxonRec * len(taxa))()
+    keep = []
+    for i, t in enumerate(taxa):
+        nm, fl = t["name"].encode("latin-1"), t["file"].encode("latin-1")
+        keep += [nm, fl]
+        arr[i] = TaxonRec(t["id"], t["parent"], t["rank"], nm, fl, t["index"], t["windows"])
+    keys = np.ascontiguousarray(keys, np.uint32); list_off = np.ascontiguousarray(list_off, np.uint64)
+    locs = np.ascontiguousarray(locs, np.uint64)
+    rc = lib().mcq_refdb_write_shard(path.encode(), C.byref(sp), arr, len(taxa), n_targets, keys.ctypes.data_as(C.c_void_p),
+                                     list_off.ctypes.data_as(C.c_void_p), locs.ctypes.data_as(C.c_void_p), len(keys))
+    if rc != 0:
+        raise RuntimeError(lib().mcq_host_last_error().decode())
 
 
 def lib():
@@ -43,6 +71,8 @@ def lib():
         L.mcq_rank_from_name.restype = C.c_uint32; L.mcq_rank_from_name.argtypes = [C.c_char_p]
         L.mcq_rank_name.restype = C.c_char_p; L.mcq_rank_name.argtypes = [C.c_uint32]
         L.mcq_host_last_error.restype = C.c_char_p
+        L.mcq_refdb_write_shard.argtypes = [C.c_char_p, C.POINTER(ShardParams), C.POINTER(TaxonRec), C.c_uint64, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
         _lib = L
     return _lib
 

@@ -157,3 +157,48 @@ def test_remove_overpopulated_features_like_the_reference(P):
     # without the option the repeats stay (and the table differs)
     tb2 = engine.Table(bases.data_ptr(), off.data_ptr(), off.numel() - 1, emulate_ranks=P)
     assert tb2.n_keys > tb.n_keys and tb2.n_locs > tb.n_locs
+
+
+# ---- f2 -> f1: shard files written from the GPU-built table, read and queried by the reference's own code ----
+REF_QUERY = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "ref_query")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_QUERY), reason="oracle/_ref/ref_query (the reference's reader, built in the build container) not present")
+@pytest.mark.parametrize("tag,P", [("mini", 4), ("overpop", 2)])
+def test_reference_reads_and_queries_shards_written_from_the_gpu_build(tag, P, tmp_path):
+    import subprocess
+    engine = importlib.import_module("metacache-mpi_amd.engine")
+    host = importlib.import_module("metacache-mpi_amd.host")
+    importlib.import_module("metacache-mpi_amd").build_host()
+    dev = torch.device("cuda", 0)
+    fx = Fixture(tag, P)
+    bases, off = _load_genomes(tag, dev)
+    flags = engine.MCQ_BUILD_REMOVE_OVERPOPULATED if tag == "overpop" else 0
+    tb = engine.Table(bases.data_ptr(), off.data_ptr(), off.numel() - 1, emulate_ranks=P, flags=flags)
+    keys, loff, locs, _ = tb.to_host()
+    key_of = np.repeat(np.arange(len(keys)), np.diff(loff.astype(np.int64)))
+    rank_of = (locs >> np.uint64(32)).astype(np.int64) % P
+    for r in range(P):
+        sel = rank_of == r
+        kk, cnt = np.unique(key_of[sel], return_counts=True)
+        o = np.zeros(len(kk) + 1, np.uint64); o[1:] = np.cumsum(cnt)
+        s = fx.shards[r]
+        p = s["params"]
+        host.write_shard(str(tmp_path / ("%s.db_%d" % (tag, r))),
+                         dict(k=p["k"], sketch_size=p["s"], winlen=p["winlen"], winstride=p["winstride"], q_k=p["qk"],
+                              q_sketch_size=p["qs"], q_winlen=p["qwinlen"], q_winstride=p["qwinstride"],
+                              max_locs_per_feature=p["maxlocs"]),
+                         s["taxa"], s["target_count"], keys[kk], o, locs[sel])
+    with open(tmp_path / "queries.txt", "w") as f:
+        for a, b in zip(fx.r1, fx.r2):
+            f.write("%s %s\n" % (a if a else "-", b if b else "-"))
+    res = subprocess.run([REF_QUERY, tag, str(P), "queries.txt", str(fx.maxcand), fx.q["lowest"], "0"], cwd=tmp_path,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = {"M": {}, "T": {}, "C": {}}
+    for line in res.stdout.split("\n"):
+        t = line.split(" ")
+        if t[0] in got:
+            got[t[0]].setdefault(t[1], {})[t[2]] = [[int(x) for x in it.split(":")] for it in t[4:] if it]
+    for kind in ("M", "T", "C"):
+        assert got[kind] == fx.ranks[kind], kind

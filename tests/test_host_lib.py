@@ -70,3 +70,29 @@ def test_classify_matches_reference_cli(host, tag, P):
     for q, name in enumerate(fx.names):
         best = db.classify(cand[q, :ncand[q]], fx.hitmin, fx.hitdiff, fx.highest)
         assert db.taxon_id(best) == fx.final[name]["best"], (name, cand[q, :ncand[q]])
+
+
+# ---- shard writer (row f1, the other direction) ----------------------------------------------------
+def _shard_params(s):
+    p = s["params"]
+    return dict(k=p["k"], sketch_size=p["s"], winlen=p["winlen"], winstride=p["winstride"], q_k=p["qk"],
+                q_sketch_size=p["qs"], q_winlen=p["qwinlen"], q_winstride=p["qwinstride"], max_locs_per_feature=p["maxlocs"])
+
+
+@pytest.mark.parametrize("tag,P", [("mini", 4), ("tie", 2), ("overpop", 2)])
+def test_written_shards_are_byte_identical_to_the_reference_files(host, tag, P, tmp_path):
+    """parse a reference shard (numpy restatement), write it back through the C library: the same bytes"""
+    fx = Fixture(tag, P)
+    for r, s in enumerate(fx.shards):
+        locs = (s["tgt"].astype(np.uint64) << np.uint64(32)) | s["win"].astype(np.uint64)
+        out = str(tmp_path / ("w.db_%d" % r))
+        host.write_shard(out, _shard_params(s), s["taxa"], s["target_count"], s["keys"], s["off"], locs)
+        assert open(out, "rb").read() == open(fx.shard_paths[r], "rb").read()
+
+
+def test_writer_rejects_oversized_lists(host, tmp_path):
+    fx = Fixture("mini", 2)
+    s = fx.shards[0]
+    with pytest.raises(RuntimeError):
+        host.write_shard(str(tmp_path / "x"), _shard_params(s), s["taxa"], s["target_count"], np.array([5], np.uint32),
+                         np.array([0, 300], np.uint64), np.zeros(300, np.uint64))
