@@ -963,13 +963,30 @@ __global__ void k_query_offsets(u64 nq, u32 qstep, u32 s, const u64* win_off, co
 // begin (end) of sequence r.  The text is not copied: mcq_query reads the bases in place
 // (MCQ_BATCH_RANGES).  Like getline, a '\r' before the newline stays part of the line.
 #define MCQ_FQ_TILE 4096
+// 16-bit mask of the newlines among text[base .. base+16): one 16-B load and exact per-byte zero detection of
+// (word ^ 0x0A0A0A0A) when the address is aligned and inside the buffer, a byte loop otherwise
+__device__ __forceinline__ u32 fq_newline_mask(const char* __restrict__ text, u64 base, u64 n) {
+    u32 mask = 0;
+    if (base + 16 <= n && ((reinterpret_cast<uintptr_t>(text) + base) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + base);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 m = w[i] ^ 0x0A0A0A0Au;
+            const u32 z = ~(((m & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | m) & 0x80808080u;     // bit 7 of every zero byte
+            mask |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * i);
+        }
+    } else {
+        for (u32 j = 0; j < 16; ++j) mask |= (u32)(base + j < n && text[base + j] == '\n') << j;
+    }
+    return mask;
+}
 __global__ __launch_bounds__(256) void k_fq_count(const char* text, u64 n, u64* tile_cnt) {
     __shared__ u32 s_c;
     if (threadIdx.x == 0) s_c = 0;
     __syncthreads();
     const u64 base = (u64)blockIdx.x * MCQ_FQ_TILE + (u64)threadIdx.x * 16;
-    u32 c = 0;
-    for (u32 j = 0; j < 16; ++j) c += (base + j < n && text[base + j] == '\n');
+    u32 c = (u32)__builtin_popcount(fq_newline_mask(text, base, n));
     for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(&s_c, c);
     __syncthreads();
@@ -980,24 +997,24 @@ __global__ __launch_bounds__(256) void k_fq_ranges(const char* text, u64 n, cons
     __shared__ u32 s_w[4];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 base = (u64)blockIdx.x * MCQ_FQ_TILE + (u64)tid * 16;
-    u32 c = 0;
-    for (u32 j = 0; j < 16; ++j) c += (base + j < n && text[base + j] == '\n');
-    u32 incl = wave_incl_scan(c, lane);
+    u32 mask = fq_newline_mask(text, base, n);
+    const u32 c = (u32)__builtin_popcount(mask);
+    u32 incl = wave_incl_scan_dpp(c);
     if (lane == 63) s_w[wave] = incl;
     __syncthreads();
     u32 woff = 0;
     for (u32 w = 0; w < wave; ++w) woff += s_w[w];
     u64 line = tile_off[blockIdx.x] + woff + incl - c;         // index of the line my first newline terminates
-    for (u32 j = 0; j < 16; ++j) {
+    while (mask) {
+        const u32 j = (u32)__builtin_ctz(mask);
+        mask &= mask - 1;
         const u64 p = base + j;
-        if (p < n && text[p] == '\n') {
-            const u64 rec = line >> 2;
-            if (rec < max_seqs) {
-                if ((line & 3) == 0) ranges[2 * rec] = p + 1;
-                else if ((line & 3) == 1) ranges[2 * rec + 1] = p;
-            }
-            ++line;
+        const u64 rec = line >> 2;
+        if (rec < max_seqs) {
+            if ((line & 3) == 0) ranges[2 * rec] = p + 1;
+            else if ((line & 3) == 1) ranges[2 * rec + 1] = p;
         }
+        ++line;
     }
     if (blockIdx.x == 0 && tid == 0) {
         const u64 total = tile_off[n_tiles];

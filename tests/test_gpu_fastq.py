@@ -87,3 +87,28 @@ def test_query_from_raw_fastq_pair(tag, P):
         if fx.r1[q] and fx.r2[q]:
             mine = [[fx.tax.id_of_key(c[0]), int(c[1])] for c in gc[q, :gn[q]]]
             assert mine == fx.final[name]["tophits"]
+
+
+@pytest.mark.parametrize("shift", [0, 1, 7, 13])
+def test_index_of_unaligned_text_and_odd_bytes(shift):
+    """the 16-byte fast path needs alignment: shifted buffers take the byte path; bytes 0x0B right after a newline
+    (one off '\\n' in the xor domain), runs of newlines and a tail shorter than 16 bytes must all come out exact"""
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(3000):
+        n = int(rng.integers(1, 200))
+        recs.append("@r%d\n%s\n+\x0b\n%s\n" % (i, "".join(rng.choice(list("ACGTN"), n)), "\x0b" * n))
+    text = "".join(recs) + "@tail\nACGT"                        # last record incomplete: its sequence line has no newline
+    raw = np.frombuffer(text.encode("latin-1"), dtype=np.uint8)
+    big = torch.zeros(len(raw) + 64, dtype=torch.uint8, device=dev)
+    big[shift:shift + len(raw)] = torch.from_numpy(raw.copy()).to(dev)
+    cap = len(recs) + 4
+    ranges = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    eng.fastq_index(big.data_ptr() + shift, len(raw), ranges.data_ptr(), cap, n.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    exp = _py_ranges(text)
+    assert int(n.item()) == len(exp) == len(recs)
+    assert ranges.cpu().numpy()[: 2 * len(exp)].reshape(-1, 2).tolist() == [list(x) for x in exp]
