@@ -1,4 +1,4 @@
-"""debug helper: full-size synthetic DB, one batch, GPU vs oracle, print mismatches."""
+"""debug helper (test infrastructure, run by hand): full-size synthetic DB, one batch, GPU vs oracle, print mismatches."""
 import importlib, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
