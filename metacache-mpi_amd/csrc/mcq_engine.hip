@@ -519,9 +519,9 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 W = db.winlen, S = db.winstride;
-    u32* feat = sc.feat + (u64)blockIdx.x * sc.fmax;
-    u32* fpos = sc.fpos + (u64)blockIdx.x * ((u64)sc.fmax + 1);
-    u64* foff = sc.foff + (u64)blockIdx.x * sc.fmax;
+    u32* g_feat = sc.feat + (u64)blockIdx.x * sc.fmax;
+    u32* g_fpos = sc.fpos + (u64)blockIdx.x * ((u64)sc.fmax + 1);
+    u64* g_foff = sc.foff + (u64)blockIdx.x * sc.fmax;
     KeyT* gbuf = reinterpret_cast<KeyT*>(sc.gbuf + (u64)blockIdx.x * sc.lmax);
     u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
     const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
@@ -541,6 +541,12 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             if (tid == 0) { out.ncand[q] = 0; atomicAdd(&ctr->err_count, 1u); if (dbg.mode == 1) dbg.match_cnt[q] = 0; }
             continue;
         }
+        // features, list lengths and list starts of the query live in LDS when it has at most 2048 features
+        // (behind the waves' sketch scratch in the hit words, which the sweep only needs later), else in global scratch
+        const bool f_lds = NW * db.s <= 2048 && NT == 1024;
+        u32* feat = f_lds ? s_hits + 2048 : g_feat;
+        u32* fpos = f_lds ? s_hits + 2048 : g_fpos;             // a feature's word becomes its list length, then its start
+        u64* foff = f_lds ? reinterpret_cast<u64*>(s_hits + 4096) : g_foff;
         if (tid == 0) { s_w[18] = 0; s_w[19] = 0; }
         __syncthreads();
         for (u32 w = wave; w < (u32)NW; w += NW16) {
