@@ -246,14 +246,14 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 // A read's match list repeats the same (target, window) many times (C2: 107 locations, 33 distinct;
 // 2x150 bp pairs: 214 / 65), and everything after the gather only needs the distinct keys and how
 // often each occurs.  The wave counts them in a 512-slot open-addressing table in its LDS segment
-// (ds_cmpst claims a slot, ds_add counts in a byte lane), the lanes that claimed a slot compact their
+// (ds_cmpst claims a slot, ds_add counts in a 16-bit lane), the lanes that claimed a slot compact their
 // keys, <= 128 distinct keys are sorted in one or two registers per lane instead of 64*E raw locations,
 // and the multiplicities come back by probing the table with the sorted keys.  Output: SK[0..D) sorted
 // distinct keys, WP[0..D) inclusive prefix sums of the multiplicities (for sweep_targets_weighted).
 // Returns D, or ~0u when there are more than 128 distinct keys (the caller then sorts the raw list).
-//   LDS (u32 words): buf[0..512) table keys, later the sweep's H;  hits[0..128) table counts (one byte
-//   per slot: a key occurs at most once per feature, <= 64 times), hits[128..256) compaction list,
-//   hits[256..384) SK, hits[384..512) WP.
+//   LDS (u32 words): buf[0..512) table keys, later the sweep's H;  hits[0..256) table counts (16 bits per
+//   slot: any multiset of up to 384 locations is counted exactly, whatever the caller of mcq_reduce hands over),
+//   later WP in hits[0..128);  hits[256..384) compaction list;  hits[384..512) SK.
 #define MCQ_DEDUP_MAX_T 384u
 #ifdef MCQ_TOPK_DPP        // tuning knob: DPP reductions per rank instead of LDS maxima for all ranks at once
 #define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write<u32, u32, 9>(db, opt, out, sk, h, D, nw, wb, q, lane)
@@ -261,20 +261,20 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 #define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write_lds(db, opt, out, sk, h, D, nw, wb, q, lane, (h) + 256)
 #endif
 __device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 23; }
-__device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 256; }
-__device__ __forceinline__ u32* dedup_wp(u32* hits) { return hits + 384; }
+__device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 384; }
+__device__ __forceinline__ u32* dedup_wp(u32* hits) { return hits; }
 __device__ __forceinline__ u32 dedup_count(const u32* tabkey, const u32* tabcnt, u32 k) {
     u32 slot = dedup_slot(k);
     while (tabkey[slot] != k) slot = (slot + 1) & 511u;
-    return (tabcnt[slot >> 2] >> (8 * (slot & 3))) & 0xFFu;
+    return (tabcnt[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu;
 }
 
 template <int E>
 __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits, u32 T, u32 lane) {
-    u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 128; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
+    u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 256; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
     reinterpret_cast<uint4*>(tabkey)[lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
     reinterpret_cast<uint4*>(tabkey)[64 + lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
-    reinterpret_cast<uint2*>(tabcnt)[lane] = make_uint2(0u, 0u);
+    reinterpret_cast<uint4*>(tabcnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
     const u64 below = (1ull << lane) - 1;
     u32 D = 0;
@@ -288,7 +288,7 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
             while (true) {                       // T <= 384 < 512 slots: an empty slot always exists
                 const u32 old = atomicCAS(&tabkey[slot], MCQ_EMPTY, key);
                 created = old == MCQ_EMPTY;
-                if (created || old == key) { atomicAdd(&tabcnt[slot >> 2], 1u << (8 * (slot & 3))); break; }
+                if (created || old == key) { atomicAdd(&tabcnt[slot >> 1], 1u << (16 * (slot & 1))); break; }
                 slot = (slot + 1) & 511u;
             }
         }
@@ -304,6 +304,7 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
         k = (D <= 32) ? wave_sort32_low(k, lane) : wave_sort64(k, lane);
         const u32 c = lane < D ? dedup_count(tabkey, tabcnt, k) : 0u;
         const u32 incl = wave_incl_scan_dpp(c);
+        wave_sync();                             // counts consumed: WP overwrites them
         SK[lane] = k; WP[lane] = incl;
     } else {
         u32 k[2];
@@ -313,6 +314,7 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
         const u32 c1 = (64 + lane < D) ? dedup_count(tabkey, tabcnt, k[1]) : 0u;
         const u32 i0 = wave_incl_scan_dpp(c0);
         const u32 i1 = wave_incl_scan_dpp(c1) + bcast(i0, 63);
+        wave_sync();
         SK[lane] = k[0]; SK[64 + lane] = k[1]; WP[lane] = i0; WP[64 + lane] = i1;
     }
     wave_sync();                                 // table dead from here: buf[] becomes the sweep's H

@@ -86,3 +86,50 @@ def test_capacity_error_is_reported_not_hidden():
     big = eng.Workspace(db, 4, len(rb))
     c, n = big.query_host(rb, ro, False, max_cand=2)
     assert (n > 0).all() and big.sync()["n_overflow"] == 4
+
+
+def test_reduce_counts_any_multiset_exactly():
+    """mcq_reduce on caller-made location lists with hundreds of copies of one (target, window): the de-duplicating
+    tail must count them exactly (16-bit table counters), like the oracle's reduce on the same multiset"""
+    import torch
+    from golden_util import Fixture
+    from oracle import dbfile
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    dev = torch.device("cuda", 0)
+    fx = Fixture("mini", 2)
+    keys, off, locs = dbfile.union_shards(fx.shards)
+    p = fx.params
+    t2t = fx.tgt2tax()
+    db = eng.Database(keys, off, locs, t2t, k=p["qk"], sketch_size=p["qs"], winlen=p["qwinlen"], winstride=p["qwinstride"],
+                      tgt_winstride=p["winstride"])
+    odb = orc.OracleDb(keys, off, locs, t2t, k=p["qk"], s=p["qs"], winlen=p["qwinlen"], winstride=p["qwinstride"],
+                       tgt_winstride=p["winstride"])
+    rng = np.random.default_rng(9)
+    lists = []
+    for q in range(300):
+        base = rng.choice(locs, size=int(rng.integers(1, 12)))
+        reps = rng.integers(1, 330, size=len(base))
+        reps = np.minimum(reps, max(1, 380 // len(base)))
+        lists.append(np.sort(np.repeat(base, reps)))                 # up to ~380 locations, a few distinct keys
+    loc_off = np.zeros(len(lists) + 1, np.int64); loc_off[1:] = np.cumsum([len(x) for x in lists])
+    allv = np.concatenate(lists)
+    wb = db.win_bits()
+    if db.loc_bytes() == 4:
+        dl = torch.from_numpy((((allv >> np.uint64(32)) << np.uint64(wb)) | (allv & np.uint64(0xFFFFFFFF))).astype(np.uint32).view(np.int32)).to(dev)
+    else:
+        dl = torch.from_numpy(allv.view(np.int64)).to(dev)
+    qlen = torch.full((len(lists),), 150, dtype=torch.int32, device=dev)
+    doff = torch.from_numpy(loc_off).to(dev)
+    ws = eng.Workspace(db, len(lists), 1)
+    for P, M in ((1, 4), (2, 2)):
+        for flags in (0, eng.MCQ_FORCE_RAW_SORT):
+            cands = torch.zeros((len(lists), M, 4), dtype=torch.int32, device=dev)
+            ncand = torch.zeros(len(lists), dtype=torch.int32, device=dev)
+            ws.reduce_device(len(lists), doff.data_ptr(), dl.data_ptr(), qlen.data_ptr(), cands.data_ptr(), ncand.data_ptr(),
+                             max_cand=M, emulate_ranks=P, flags=flags, stream=torch.cuda.current_stream(dev).cuda_stream)
+            ws.sync()
+            gc = cands.cpu().numpy().view(np.uint32); gn = ncand.cpu().numpy().view(np.uint32)
+            for q, lst in enumerate(lists):
+                oc, on = odb.reduce_query(lst, 150, max_cand=M, emulate_ranks=P)
+                assert gn[q] == on, (q, P, M, flags)
+                assert np.array_equal(gc[q, :on], oc[:on]), (q, P, M, flags, gc[q], oc)
