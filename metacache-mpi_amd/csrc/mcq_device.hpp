@@ -631,6 +631,18 @@ __device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v) {
     return v;
 }
 
+// inclusive prefix MAXIMUM over the wave, same DPP ladder as wave_incl_scan_dpp (values >= 0, identity 0)
+__device__ __forceinline__ u32 wave_incl_max_dpp(u32 v) {
+    u32 t;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;
+    t = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;
+    return v;
+}
+
 // Weighted form of sweep_targets_wave for a de-duplicated match list: SK[0..D) are the DISTINCT
 // sorted keys, WP[j] the inclusive prefix sum of their multiplicities.  A window range holds every
 // copy of the keys inside it, so hits(j) = WP[j] - WP[lo-1] with the same lower bound lo, and the

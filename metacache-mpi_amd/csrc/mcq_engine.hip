@@ -211,32 +211,37 @@ template <class KeyT> __device__ __forceinline__ u64 key_expand(KeyT k, u32 wb) 
 }
 
 // Gather E*64 list elements into registers: r[e] = element e*64 + lane of the concatenated lists.
-// Element t belongs to the last feature lane j with pos_j <= t (6-step shuffle search).
+// Which list an element belongs to: every non-empty list marks its first element's slot with (its lane + 1)
+// in `mark` (64 * E words of the wave's LDS), an inclusive prefix maximum over the slots spreads the marks
+// to the right (6 DPP steps per register instead of a 6-step shuffle search per element).
 template <class KeyT, int E>
-__device__ __forceinline__ void gather_regs(const DbDev& db, KeyT (&r)[E], u32 T, u32 pos, u64 off, u32 lane) {
+__device__ __forceinline__ void gather_regs(const DbDev& db, KeyT (&r)[E], u32 T, u32 pos, u32 len, u64 off, u32 lane, u32* mark) {
     const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
+#pragma unroll
+    for (int e = 0; e < E; ++e) mark[e * 64 + lane] = 0;
+    wave_sync();
+    if (len > 0) mark[pos] = lane + 1;
+    wave_sync();
+    u32 carry = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const u32 t = e * 64 + lane;
-        const u32 tt = t < T ? t : T - 1;
-        u32 lo = 0;
-#pragma unroll
-        for (u32 step = 32; step > 0; step >>= 1) {
-            u32 c = lo + step;
-            u32 pc = __shfl(pos, (int)(c & 63), 64);
-            if (c < 64 && pc <= tt) lo = c;
-        }
-        u32 pj = __shfl(pos, (int)lo, 64);
-        u32 olo = __shfl((u32)off, (int)lo, 64), ohi = __shfl((u32)(off >> 32), (int)lo, 64);
+        u32 v = wave_incl_max_dpp(mark[t]);
+        v = v > carry ? v : carry;
+        carry = bcast(v, 63);
+        const u32 j = v - 1;                             // v >= 1: the first list starts at slot 0
+        const u32 pj = __shfl(pos, (int)j, 64);
+        const u32 olo = __shfl((u32)off, (int)j, 64), ohi = __shfl((u32)(off >> 32), (int)j, 64);
         r[e] = key_pad<KeyT>();
-        if (t < T) r[e] = locs[(((u64)ohi << 32) | olo) + (tt - pj)];
+        if (t < T) r[e] = locs[(((u64)ohi << 32) | olo) + (t - pj)];
     }
+    wave_sync();                                         // mark[] is the caller's again
 }
 // ... sort them there and leave the sorted keys in the wave's LDS segment for the sweep.
 template <class KeyT, int E>
-__device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u32 T, u32 pos, u64 off, u32 lane, int stop) {
+__device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u32* hits, u32 T, u32 pos, u32 len, u64 off, u32 lane, int stop) {
     KeyT r[E];
-    gather_regs<KeyT, E>(db, r, T, pos, off, lane);
+    gather_regs<KeyT, E>(db, r, T, pos, len, off, lane, hits);
     if (stop != 3) wave_regsort<KeyT, E>(r, lane);
 #pragma unroll
     for (int e = 0; e < E; ++e) buf[e * 64 + lane] = r[e];
@@ -321,9 +326,9 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
     return D;
 }
 template <int E>
-__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u64 off, u32 lane, int stop) {
+__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u32 len, u64 off, u32 lane, int stop) {
     u32 r[E];
-    gather_regs<u32, E>(db, r, T, pos, off, lane);
+    gather_regs<u32, E>(db, r, T, pos, len, off, lane, hits);
     if (stop == 3) {                             // stage-ablation hook: keep the loads alive, skip the rest
         u32 x = 0;
 #pragma unroll
@@ -425,11 +430,11 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         if constexpr (sizeof(KeyT) == 4) {
             if (T <= MCQ_DEDUP_MAX_T && !(force_block & 2)) {
                 u32 D;
-                if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, off, lane, stop);
-                else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, off, lane, stop);
-                else if (T <= 192) D = gather_dedup_sort<3>(db, buf, hits, T, pos, off, lane, stop);
-                else if (T <= 256) D = gather_dedup_sort<4>(db, buf, hits, T, pos, off, lane, stop);
-                else               D = gather_dedup_sort<6>(db, buf, hits, T, pos, off, lane, stop);
+                if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, len, off, lane, stop);
+                else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, len, off, lane, stop);
+                else if (T <= 192) D = gather_dedup_sort<3>(db, buf, hits, T, pos, len, off, lane, stop);
+                else if (T <= 256) D = gather_dedup_sort<4>(db, buf, hits, T, pos, len, off, lane, stop);
+                else               D = gather_dedup_sort<6>(db, buf, hits, T, pos, len, off, lane, stop);
                 if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
                     sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
@@ -441,10 +446,10 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                 wave_sync();                       // more than 128 distinct keys: the raw list is sorted below
             }
         }
-        if (T <= 64)       gather_sort_store<KeyT, 1>(db, buf, T, pos, off, lane, stop);
-        else if (T <= 128) gather_sort_store<KeyT, 2>(db, buf, T, pos, off, lane, stop);
-        else if (T <= 256) gather_sort_store<KeyT, 4>(db, buf, T, pos, off, lane, stop);
-        else               gather_sort_store<KeyT, 8>(db, buf, T, pos, off, lane, stop);
+        if (T <= 64)       gather_sort_store<KeyT, 1>(db, buf, hits, T, pos, len, off, lane, stop);
+        else if (T <= 128) gather_sort_store<KeyT, 2>(db, buf, hits, T, pos, len, off, lane, stop);
+        else if (T <= 256) gather_sort_store<KeyT, 4>(db, buf, hits, T, pos, len, off, lane, stop);
+        else               gather_sort_store<KeyT, 8>(db, buf, hits, T, pos, len, off, lane, stop);
         wave_sync();
         if (stop == 3 || stop == 4) { if (buf[lane] == (KeyT)0x1234) out.ncand[q] = 1; continue; }
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
