@@ -676,6 +676,34 @@ __device__ __forceinline__ void sweep_targets_weighted(const u32* SK, const u32*
     wave_sync();
 }
 
+// The same for at most 64 distinct keys held one per lane (k sorted, lanes >= D padded; incl = inclusive
+// multiplicity sums) and a narrow window range: distinct keys of one target have distinct windows, so the range
+// ending at an entry reaches back over at most numWindows - 1 predecessors -- checked with wave_shr:1 shifts
+// instead of a binary search through LDS.  numWindows <= 8.
+__device__ __forceinline__ void sweep_targets_regs(u32 k, u32 incl, u32* H, u32 D, u32 numWindows, u32 wb, u32 lane) {
+    const u32 winmask = (1u << wb) - 1;
+    H[lane] = 0;
+    wave_sync();
+    const bool valid = lane < D;
+    const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)k, 0x138, 0xF, 0xF, false);      // wave_shr:1
+    const bool head = valid && (lane == 0 || (prev >> wb) != (k >> wb));
+    const u64 le = __ballot(head) & ((2ull << lane) - 1);
+    const u32 myhead = le ? 63u - (u32)__builtin_clzll(le) : 0u;
+    const u32 win = k & winmask;
+    const u32 lowkey = (k & ~winmask) | ((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+    u32 cnt = 0, kk = k;
+    bool ok = valid;
+    for (u32 i = 1; i < numWindows; ++i) {
+        kk = (u32)__builtin_amdgcn_update_dpp(0, (int)kk, 0x138, 0xF, 0xF, false);
+        ok = ok && lane >= i && kk >= lowkey;
+        cnt += ok ? 1u : 0u;
+    }
+    const u32 below = __shfl(incl, (int)((lane - cnt - 1) & 63), 64);                           // WP[lo - 1]
+    const u32 hits = incl - (lane > cnt ? below : 0u);
+    if (valid) atomicMax(&H[myhead], (hits << 9) | (511u - lane));
+    wave_sync();
+}
+
 // window range [beg,end] of the best candidate whose packed word is hv (run head j0 irrelevant)
 template <class KeyT, class HT, int JB>
 __device__ __forceinline__ void best_range(const KeyT* buf, HT hv, u32 numWindows, u32 wb, u32& beg, u32& end) {

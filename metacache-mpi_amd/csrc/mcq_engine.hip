@@ -274,8 +274,10 @@ __device__ __forceinline__ u32 dedup_count(const u32* tabkey, const u32* tabcnt,
     return (tabcnt[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu;
 }
 
+// k1/incl1: the sorted keys and inclusive multiplicity sums one per lane when D <= 64 (for sweep_targets_regs)
 template <int E>
-__device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits, u32 T, u32 lane) {
+__device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits, u32 T, u32 lane, u32& k1, u32& incl1) {
+    k1 = MCQ_EMPTY; incl1 = 0;
     u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 256; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
     reinterpret_cast<uint4*>(tabkey)[lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
     reinterpret_cast<uint4*>(tabkey)[64 + lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
@@ -311,6 +313,7 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
         const u32 incl = wave_incl_scan_dpp(c);
         wave_sync();                             // counts consumed: WP overwrites them
         SK[lane] = k; WP[lane] = incl;
+        k1 = k; incl1 = incl;
     } else {
         u32 k[2];
         k[0] = list[lane]; k[1] = (64 + lane < D) ? list[64 + lane] : MCQ_EMPTY;
@@ -326,7 +329,8 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
     return D;
 }
 template <int E>
-__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u32 len, u64 off, u32 lane, int stop) {
+__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u32 len, u64 off, u32 lane, int stop,
+                                                 u32& k1, u32& incl1) {
     u32 r[E];
     gather_regs<u32, E>(db, r, T, pos, len, off, lane, hits);
     if (stop == 3) {                             // stage-ablation hook: keep the loads alive, skip the rest
@@ -334,17 +338,18 @@ __device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32*
 #pragma unroll
         for (int e = 0; e < E; ++e) x ^= r[e];
         buf[lane] = x;
+        k1 = MCQ_EMPTY; incl1 = 0;
         return ~1u;
     }
-    return dedup_sort<E>(r, buf, hits, T, lane);
+    return dedup_sort<E>(r, buf, hits, T, lane, k1, incl1);
 }
 // the same for a match list that already sits in global memory (staged / sharded path)
 template <int E>
-__device__ __forceinline__ u32 load_dedup_sort(const u32* __restrict__ src, u32* buf, u32* hits, u32 T, u32 lane) {
+__device__ __forceinline__ u32 load_dedup_sort(const u32* __restrict__ src, u32* buf, u32* hits, u32 T, u32 lane, u32& k1, u32& incl1) {
     u32 r[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { const u32 t = e * 64 + lane; r[e] = t < T ? src[t] : MCQ_EMPTY; }
-    return dedup_sort<E>(r, buf, hits, T, lane);
+    return dedup_sort<E>(r, buf, hits, T, lane, k1, incl1);
 }
 
 // geometry of one read (or pair) on the wave path
@@ -429,15 +434,16 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         if constexpr (sizeof(KeyT) == 4) {
             if (T <= MCQ_DEDUP_MAX_T && !(force_block & 2)) {
-                u32 D;
-                if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, len, off, lane, stop);
-                else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, len, off, lane, stop);
-                else if (T <= 192) D = gather_dedup_sort<3>(db, buf, hits, T, pos, len, off, lane, stop);
-                else if (T <= 256) D = gather_dedup_sort<4>(db, buf, hits, T, pos, len, off, lane, stop);
-                else               D = gather_dedup_sort<6>(db, buf, hits, T, pos, len, off, lane, stop);
+                u32 D, k1, incl1;
+                if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
+                else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
+                else if (T <= 192) D = gather_dedup_sort<3>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
+                else if (T <= 256) D = gather_dedup_sort<4>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
+                else               D = gather_dedup_sort<6>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
                 if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
-                    sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
+                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
+                    else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
                     if (stop == 5) { if (buf[lane] == 0x12345u) out.ncand[q] = 1; wave_sync(); continue; }
                     st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, q, lane);
                     wave_sync();
@@ -785,14 +791,15 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         if constexpr (sizeof(KeyT) == 4) {
             if (T <= MCQ_DEDUP_MAX_T && !opt.raw_sort) {
                 const u32* src = locs + b0;
-                u32 D;
-                if (T <= 64)       D = load_dedup_sort<1>(src, buf, hits, T, lane);
-                else if (T <= 128) D = load_dedup_sort<2>(src, buf, hits, T, lane);
-                else if (T <= 192) D = load_dedup_sort<3>(src, buf, hits, T, lane);
-                else if (T <= 256) D = load_dedup_sort<4>(src, buf, hits, T, lane);
-                else               D = load_dedup_sort<6>(src, buf, hits, T, lane);
+                u32 D, k1, incl1;
+                if (T <= 64)       D = load_dedup_sort<1>(src, buf, hits, T, lane, k1, incl1);
+                else if (T <= 128) D = load_dedup_sort<2>(src, buf, hits, T, lane, k1, incl1);
+                else if (T <= 192) D = load_dedup_sort<3>(src, buf, hits, T, lane, k1, incl1);
+                else if (T <= 256) D = load_dedup_sort<4>(src, buf, hits, T, lane, k1, incl1);
+                else               D = load_dedup_sort<6>(src, buf, hits, T, lane, k1, incl1);
                 if (D != ~0u) {
-                    sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
+                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
+                    else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
                     st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, q, lane);
                     wave_sync();
                     continue;
