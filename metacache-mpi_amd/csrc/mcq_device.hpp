@@ -142,6 +142,11 @@ __device__ __forceinline__ u32 lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// number of set bits of a wave-wide mask below this lane (v_mbcnt_lo/hi: the lane id itself is mbcnt(~0))
+__device__ __forceinline__ u32 lane_rank(u64 mask) {
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
+}
+
 // Orders this wave's LDS/global accesses across lanes.  A wave executes its memory
 // instructions in order, so only the compiler has to be stopped from reordering.
 __device__ __forceinline__ void wave_sync() {
@@ -379,16 +384,17 @@ __device__ __forceinline__ u32 wave_sketch_chars(u32 c0, u32 c1, u32 n, u32 k, u
     const u32 c = (u32)__builtin_popcountll(__ballot(h[0] != MCQ_EMPTY)) + (u32)__builtin_popcountll(__ballot(h[1] != MCQ_EMPTY));
     if (c == 0) return 0;
     const bool all_in = c <= 64;
-    const u32 thr = all_in ? MCQ_EMPTY : (0xFFFFFFFFu / c) * 40u;
+    // 40/c of the hash range; any threshold gives the same sketch (the fallback below is exact), so a float
+    // reciprocal replaces the integer division (c <= 128: the product stays below 2^32)
+    const u32 thr = all_in ? MCQ_EMPTY : (u32)(__builtin_amdgcn_rcpf((float)c) * 171798691840.0f);
     const bool s0 = h[0] < thr, s1 = h[1] < thr;
     const u64 m0 = __ballot(s0), m1 = __ballot(s1);
     const u32 n0 = (u32)__builtin_popcountll(m0), cnt = n0 + (u32)__builtin_popcountll(m1);
     bool fallback = cnt > 64;
     u32 m = 0;
     if (!fallback) {
-        const u64 below = (1ull << lane) - 1;
-        if (s0) tmp[(u32)__builtin_popcountll(m0 & below)] = h[0];
-        if (s1) tmp[n0 + (u32)__builtin_popcountll(m1 & below)] = h[1];
+        if (s0) tmp[lane_rank(m0)] = h[0];
+        if (s1) tmp[n0 + lane_rank(m1)] = h[1];
         wave_sync();
         u32 v = lane < cnt ? tmp[lane] : MCQ_EMPTY;
         v = (cnt <= 32) ? wave_sort32_low(v, lane) : wave_sort64(v, lane);     // 15 stages when the low half suffices
@@ -399,7 +405,7 @@ __device__ __forceinline__ u32 wave_sketch_chars(u32 c0, u32 c1, u32 n, u32 k, u
         if (!all_in && D < sl) fallback = true;
         else {
             m = D < sl ? D : sl;
-            u32 rank = (u32)__builtin_popcountll(km & below);
+            u32 rank = lane_rank(km);
             if (keep && rank < m) dst[rank] = v;
         }
     }
@@ -759,7 +765,6 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
     const HT JMASK = ((HT)1 << JB) - 1;
-    const u64 below = (1ull << lane) - 1;
 
     // 1. compact the run heads' packed words to H[0..nheads) (in place: writes trail reads)
     u32 nheads = 0;
@@ -767,7 +772,7 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
         const u32 j = base + lane;
         const HT hv = (j < T) ? H[j] : 0;
         const u64 hm = __ballot(hv != 0);
-        if (hv != 0) H[nheads + (u32)__builtin_popcountll(hm & below)] = hv;
+        if (hv != 0) H[nheads + lane_rank(hm)] = hv;
         nheads += (u32)__builtin_popcountll(hm);
     }
     wave_sync();
@@ -904,7 +909,6 @@ __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
     const u32 JMASK = (1u << JB) - 1;
-    const u64 below = (1ull << lane) - 1;
     u32* mx = scr; u32* wt = scr + 64;
 
     // 1. compact the run heads' packed words to H[0..nheads)
@@ -913,7 +917,7 @@ __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev
         const u32 j = base + lane;
         const u32 hv = (j < T) ? H[j] : 0;
         const u64 hm = __ballot(hv != 0);
-        if (hv != 0) H[nheads + (u32)__builtin_popcountll(hm & below)] = hv;
+        if (hv != 0) H[nheads + lane_rank(hm)] = hv;
         nheads += (u32)__builtin_popcountll(hm);
     }
     wave_sync();

@@ -283,7 +283,6 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
     reinterpret_cast<uint4*>(tabkey)[64 + lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
     reinterpret_cast<uint4*>(tabcnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
     wave_sync();
-    const u64 below = (1ull << lane) - 1;
     u32 D = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -300,7 +299,7 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
             }
         }
         const u64 cm = __ballot(created);
-        const u32 rank = D + (u32)__builtin_popcountll(cm & below);
+        const u32 rank = D + lane_rank(cm);
         if (created && rank < 128) list[rank] = key;
         D += (u32)__builtin_popcountll(cm);
     }
@@ -905,7 +904,6 @@ __global__ __launch_bounds__(256) void k_bucket_fill(const u32* features, u64 n,
                                                      const unsigned long long* blk_off, u32* bucketed, u32* src_index) {
     __shared__ unsigned long long s_cur[MCQ_BUCKET_MAX_SHARDS];
     const u32 lane = threadIdx.x & 63;
-    const u64 below = (1ull << lane) - 1;
     if (threadIdx.x < n_shards) s_cur[threadIdx.x] = blk_off[(u64)threadIdx.x * gridDim.x + blockIdx.x];
     __syncthreads();
     const u64 t0 = (u64)blockIdx.x * tile, t1 = t0 + tile < n ? t0 + tile : n;
@@ -920,7 +918,7 @@ __global__ __launch_bounds__(256) void k_bucket_fill(const u32* features, u64 n,
             if (lane == 0 && c) start = atomicAdd(&s_cur[o], (unsigned long long)c);
             start = ((unsigned long long)__builtin_amdgcn_readfirstlane((u32)(start >> 32)) << 32) | __builtin_amdgcn_readfirstlane((u32)start);
             if (own == o) {
-                const u64 d = start + (u32)__builtin_popcountll(m & below);
+                const u64 d = start + lane_rank(m);
                 bucketed[d] = f; src_index[d] = (u32)i;
             }
         }
