@@ -398,7 +398,8 @@ __device__ __forceinline__ u32 wave_sketch_chars(u32 c0, u32 c1, u32 n, u32 k, u
         wave_sync();
         u32 v = lane < cnt ? tmp[lane] : MCQ_EMPTY;
         v = (cnt <= 32) ? wave_sort32_low(v, lane) : wave_sort64(v, lane);     // 15 stages when the low half suffices
-        u32 prev = __shfl_up(v, 1, 64);
+        asm("s_nop 1" : "+v"(v));                 // v was written inside an asm block: 2 wait states before a DPP read
+        const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);    // wave_shr:1
         bool keep = (v != MCQ_EMPTY) && (lane == 0 || v != prev);
         u64 km = __ballot(keep);
         u32 D = (u32)__builtin_popcountll(km);
@@ -691,6 +692,7 @@ __device__ __forceinline__ void sweep_targets_regs(u32 k, u32 incl, u32* H, u32 
     H[lane] = 0;
     wave_sync();
     const bool valid = lane < D;
+    asm("s_nop 1" : "+v"(k));                     // k may come straight out of an asm sort block (DPP read hazard)
     const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)k, 0x138, 0xF, 0xF, false);      // wave_shr:1
     const bool head = valid && (lane == 0 || (prev >> wb) != (k >> wb));
     const u64 le = __ballot(head) & ((2ull << lane) - 1);
