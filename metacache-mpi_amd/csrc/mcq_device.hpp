@@ -175,16 +175,6 @@ __device__ __forceinline__ u32 wave_min_u32(u32 v) {
     return a < c ? a : c;
 }
 
-// inclusive prefix sum over the wave
-__device__ __forceinline__ u32 wave_incl_scan(u32 v, u32 lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if (lane >= (u32)d) v += t;
-    }
-    return v;
-}
-
 __device__ __forceinline__ u32 bcast(u32 v, u32 src_lane) {       // src_lane wave-uniform
     return __builtin_amdgcn_readlane(v, src_lane);
 }

@@ -480,7 +480,7 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
     for (u32 base = 0; base < n; base += NTB) {
         u32 i = base + tid;
         u32 v = (i < n) ? a[i] : 0;
-        u32 x = wave_incl_scan(v, lane);
+        u32 x = wave_incl_scan_dpp(v);
         if (lane == 63) s_w[wave] = x;
         __syncthreads();
         u32 woff = 0;
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             probe(db, feat[i], off, len);
             foff[i] = off; fpos[i] = len; nhit += (len > 0);
         }
-        nhit = wave_incl_scan(nhit, lane);
+        nhit = wave_incl_scan_dpp(nhit);
         if (lane == 63 && nhit) atomicAdd(&s_w[19], nhit);
         __syncthreads();
         const u32 T = block_excl_scan(fpos, F, tid, s_w);
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void k_lookup_gather(DbDev db, const u32* feat
             else probe(db, features[i], off, len);
         }
         const u64 obase = out_off[g * 64];
-        u32 incl = wave_incl_scan(len, lane);
+        u32 incl = wave_incl_scan_dpp(len);
         u32 pos = incl - len;
         const u32 T = bcast(incl, 63);
         for (u32 base = 0; base < T; base += 256) {           // four 64-element chunks in flight per round trip
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256) void k_scatter_lists(u64 n_lists, const u64* s
         u64 so = 0, d = 0; u32 len = 0;
         if (i < n_lists) { so = src_off[i]; len = (u32)(src_off[i + 1] - so); d = dst_off[dst_slot[i]]; }
         const u64 sbase = src_off[g * 64];
-        u32 incl = wave_incl_scan(len, lane);
+        u32 incl = wave_incl_scan_dpp(len);
         u32 pos = incl - len;
         const u32 T = bcast(incl, 63);
         for (u32 base = 0; base < T; base += 64) {
