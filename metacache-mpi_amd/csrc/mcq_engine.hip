@@ -281,7 +281,9 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
     u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 256; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
     reinterpret_cast<uint4*>(tabkey)[lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
     reinterpret_cast<uint4*>(tabkey)[64 + lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
-    reinterpret_cast<uint4*>(tabcnt)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    u32 zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));     // not hoistable: a loop-invariant zero quad gets spilled to scratch otherwise
+    reinterpret_cast<uint4*>(tabcnt)[lane] = make_uint4(zero, zero, zero, zero);
     wave_sync();
     u32 D = 0;
 #pragma unroll
