@@ -466,6 +466,42 @@ __device__ __forceinline__ u64 xlane(u64 v, u32 lane) {
     return ((u64)xor_lane<J>((u32)(v >> 32), lane) << 32) | xor_lane<J>((u32)v, lane);
 }
 
+// cmpex with the lane mask as a compile-time constant: its two halves are 32-bit literals of the s_xor, so no
+// SGPR pair per mask stays live (the compiler otherwise materialises all masks of a sort up front and spills them)
+template <u64 KM>
+__device__ __forceinline__ u64 take_mask(u64 lt) {
+    u32 lo, hi;
+    asm("s_xor_b32 %0, %2, %4\n\ts_xor_b32 %1, %3, %5"
+        : "=&s"(lo), "=s"(hi) : "s"((u32)lt), "s"((u32)(lt >> 32)), "i"((int)(u32)KM), "i"((int)(u32)(KM >> 32)) : "scc");
+    return ((u64)hi << 32) | lo;
+}
+template <u64 KM>
+__device__ __forceinline__ u32 cmpex_c(u32 v, u32 o) {
+    const u64 take = take_mask<KM>(__ballot(v < o));
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(o), "s"(take));
+    return r;
+}
+template <u64 KM>
+__device__ __forceinline__ u64 cmpex_c(u64 v, u64 o) {
+    const u64 take = take_mask<KM>(__ballot(v < o));
+    u32 lo, hi;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(lo) : "v"((u32)v), "v"((u32)o), "s"(take));
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(hi) : "v"((u32)(v >> 32)), "v"((u32)(o >> 32)), "s"(take));
+    return ((u64)hi << 32) | lo;
+}
+// cross-lane stage J < 64 of level K for register e .. E-1 (e is a template parameter: the mask is a constant)
+template <class KeyT, int E, int K, int J, int e>
+__device__ __forceinline__ void regsort_xstage(KeyT (&r)[E], u32 lane) {
+    if constexpr (e < E) {
+        // bit 6+ of the element index lives in e, so for K >= 64 the direction is static
+        constexpr u64 km = (K >= 64) ? ((((e * 64) & K) == 0) ? keepmin_mask(64, J, true) : keepmin_mask(64, J, false))
+                                     : keepmin_mask(K, J, true);
+        r[e] = cmpex_c<km>(r[e], xlane<J>(r[e], lane));
+        regsort_xstage<KeyT, E, K, J, e + 1>(r, lane);
+    }
+}
+
 template <class KeyT, int E, int K, int J>
 __device__ __forceinline__ void regsort_stage(KeyT (&r)[E], u32 lane) {
     if constexpr (J >= 64) {
@@ -480,13 +516,16 @@ __device__ __forceinline__ void regsort_stage(KeyT (&r)[E], u32 lane) {
             }
         }
     } else {
+#ifdef MCQ_CMPEX_GENERIC        // tuning knob: masks as SGPR constants chosen by the compiler
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            // bit 6+ of the element index lives in e, so for K >= 64 the direction is static
             const u64 km = (K >= 64) ? ((((e * 64) & K) == 0) ? keepmin_mask(64, J, true) : keepmin_mask(64, J, false))
                                      : keepmin_mask(K, J, true);
             r[e] = cmpex(r[e], xlane<J>(r[e], lane), km);
         }
+#else
+        regsort_xstage<KeyT, E, K, J, 0>(r, lane);
+#endif
     }
 }
 template <class KeyT, int E, int K, int J>
