@@ -274,11 +274,11 @@ __device__ __forceinline__ u32 dedup_count(const u32* tabkey, const u32* tabcnt,
     return (tabcnt[slot >> 1] >> (16 * (slot & 1))) & 0xFFFFu;
 }
 
-// k1/incl1: the sorted keys and inclusive multiplicity sums one per lane when D <= 64 (for sweep_targets_regs)
+// Insertion half (depends on the number of registers E): counts the keys in the table and leaves the distinct
+// ones in the compaction list; returns their number D.
 template <int E>
-__device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits, u32 T, u32 lane, u32& k1, u32& incl1) {
-    k1 = MCQ_EMPTY; incl1 = 0;
-    u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 256; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
+__device__ __forceinline__ u32 dedup_insert(const u32 (&r)[E], u32* buf, u32* hits, u32 T, u32 lane) {
+    u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 256;
     reinterpret_cast<uint4*>(tabkey)[lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
     reinterpret_cast<uint4*>(tabkey)[64 + lane] = make_uint4(MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY, MCQ_EMPTY);
     u32 zero;
@@ -306,6 +306,14 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
         D += (u32)__builtin_popcountll(cm);
     }
     wave_sync();
+    return D;
+}
+// Second half, the same code for every E: sort the D distinct keys, fetch their multiplicities, prefix sums.
+// k1/incl1: the sorted keys and inclusive sums one per lane when D <= 64 (for sweep_targets_regs).
+// Returns D, or ~0u when D > 128.
+__device__ __forceinline__ u32 dedup_finish(u32 D, u32* buf, u32* hits, u32 lane, u32& k1, u32& incl1) {
+    u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 256; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
+    k1 = MCQ_EMPTY; incl1 = 0;
     if (D > 128) return ~0u;
     if (D <= 64) {
         u32 k = lane < D ? list[lane] : MCQ_EMPTY;
@@ -329,9 +337,9 @@ __device__ __forceinline__ u32 dedup_sort(const u32 (&r)[E], u32* buf, u32* hits
     wave_sync();                                 // table dead from here: buf[] becomes the sweep's H
     return D;
 }
+// gather (or load) + insertion; the caller finishes with dedup_finish.  ~1u: stage-ablation stop after the gather.
 template <int E>
-__device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u32 len, u64 off, u32 lane, int stop,
-                                                 u32& k1, u32& incl1) {
+__device__ __forceinline__ u32 gather_dedup_insert(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos, u32 len, u64 off, u32 lane, int stop) {
     u32 r[E];
     gather_regs<u32, E>(db, r, T, pos, len, off, lane, hits);
     if (stop == 3) {                             // stage-ablation hook: keep the loads alive, skip the rest
@@ -339,18 +347,17 @@ __device__ __forceinline__ u32 gather_dedup_sort(const DbDev& db, u32* buf, u32*
 #pragma unroll
         for (int e = 0; e < E; ++e) x ^= r[e];
         buf[lane] = x;
-        k1 = MCQ_EMPTY; incl1 = 0;
         return ~1u;
     }
-    return dedup_sort<E>(r, buf, hits, T, lane, k1, incl1);
+    return dedup_insert<E>(r, buf, hits, T, lane);
 }
 // the same for a match list that already sits in global memory (staged / sharded path)
 template <int E>
-__device__ __forceinline__ u32 load_dedup_sort(const u32* __restrict__ src, u32* buf, u32* hits, u32 T, u32 lane, u32& k1, u32& incl1) {
+__device__ __forceinline__ u32 load_dedup_insert(const u32* __restrict__ src, u32* buf, u32* hits, u32 T, u32 lane) {
     u32 r[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) { const u32 t = e * 64 + lane; r[e] = t < T ? src[t] : MCQ_EMPTY; }
-    return dedup_sort<E>(r, buf, hits, T, lane, k1, incl1);
+    return dedup_insert<E>(r, buf, hits, T, lane);
 }
 
 // geometry of one read (or pair) on the wave path
@@ -435,12 +442,13 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         if constexpr (sizeof(KeyT) == 4) {
             if (T <= MCQ_DEDUP_MAX_T && !(force_block & 2)) {
-                u32 D, k1, incl1;
-                if (T <= 64)       D = gather_dedup_sort<1>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
-                else if (T <= 128) D = gather_dedup_sort<2>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
-                else if (T <= 192) D = gather_dedup_sort<3>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
-                else if (T <= 256) D = gather_dedup_sort<4>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
-                else               D = gather_dedup_sort<6>(db, buf, hits, T, pos, len, off, lane, stop, k1, incl1);
+                u32 D, k1 = MCQ_EMPTY, incl1 = 0;
+                if (T <= 64)       D = gather_dedup_insert<1>(db, buf, hits, T, pos, len, off, lane, stop);
+                else if (T <= 128) D = gather_dedup_insert<2>(db, buf, hits, T, pos, len, off, lane, stop);
+                else if (T <= 192) D = gather_dedup_insert<3>(db, buf, hits, T, pos, len, off, lane, stop);
+                else if (T <= 256) D = gather_dedup_insert<4>(db, buf, hits, T, pos, len, off, lane, stop);
+                else               D = gather_dedup_insert<6>(db, buf, hits, T, pos, len, off, lane, stop);
+                if (D != ~1u) D = dedup_finish(D, buf, hits, lane, k1, incl1);
                 if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
                     if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
@@ -793,11 +801,12 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
             if (T <= MCQ_DEDUP_MAX_T && !opt.raw_sort) {
                 const u32* src = locs + b0;
                 u32 D, k1, incl1;
-                if (T <= 64)       D = load_dedup_sort<1>(src, buf, hits, T, lane, k1, incl1);
-                else if (T <= 128) D = load_dedup_sort<2>(src, buf, hits, T, lane, k1, incl1);
-                else if (T <= 192) D = load_dedup_sort<3>(src, buf, hits, T, lane, k1, incl1);
-                else if (T <= 256) D = load_dedup_sort<4>(src, buf, hits, T, lane, k1, incl1);
-                else               D = load_dedup_sort<6>(src, buf, hits, T, lane, k1, incl1);
+                if (T <= 64)       D = load_dedup_insert<1>(src, buf, hits, T, lane);
+                else if (T <= 128) D = load_dedup_insert<2>(src, buf, hits, T, lane);
+                else if (T <= 192) D = load_dedup_insert<3>(src, buf, hits, T, lane);
+                else if (T <= 256) D = load_dedup_insert<4>(src, buf, hits, T, lane);
+                else               D = load_dedup_insert<6>(src, buf, hits, T, lane);
+                D = dedup_finish(D, reinterpret_cast<u32*>(buf), hits, lane, k1, incl1);
                 if (D != ~0u) {
                     if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
                     else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
