@@ -376,7 +376,10 @@ __device__ __forceinline__ u32 wave_sketch_chars(u32 c0, u32 c1, u32 n, u32 k, u
     const bool all_in = c <= 64;
     // 40/c of the hash range; any threshold gives the same sketch (the fallback below is exact), so a float
     // reciprocal replaces the integer division (c <= 128: the product stays below 2^32)
-    const u32 thr = all_in ? MCQ_EMPTY : (u32)(__builtin_amdgcn_rcpf((float)c) * 171798691840.0f);
+#ifndef MCQ_SKETCH_EXPECT
+#define MCQ_SKETCH_EXPECT 40          // expected number of hashes below the threshold (tuning knob)
+#endif
+    const u32 thr = all_in ? MCQ_EMPTY : (u32)(__builtin_amdgcn_rcpf((float)c) * (4294967296.0f * MCQ_SKETCH_EXPECT));
     const bool s0 = h[0] < thr, s1 = h[1] < thr;
     const u64 m0 = __ballot(s0), m1 = __ballot(s1);
     const u32 n0 = (u32)__builtin_popcountll(m0), cnt = n0 + (u32)__builtin_popcountll(m1);
