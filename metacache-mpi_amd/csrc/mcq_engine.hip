@@ -36,6 +36,23 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 extern "C" const char* mcq_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mcq_version(void) { return "mcq 0.1 (gfx950)"; }
 
+// ------------------------------------------------------------------ persistent grids
+// The wave-per-item kernels loop over their items (grid stride).  The grid is exactly what the device holds at
+// once -- occupancy x CUs -- and no more: with 3 x that many workgroups the last round leaves most of the chip
+// idle while a few waves finish (k_query_wave: 2.26 ms at 24 workgroups per CU, 2.07 ms at the resident 8).
+template <class Kernel>
+static u32 resident_blocks(Kernel kernel, int block_size, int device) {
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_size, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
+    if (const char* e = getenv("MCQ_WAVE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));       // tuning knob
+    return (u32)per_cu * (u32)prop.multiProcessorCount;
+}
+#define MCQ_GRID(kernel, block, device, want) ([&]() -> u32 { static u32 cap_ = 0; static int dev_ = -1; \
+    if (dev_ != (device)) { cap_ = resident_blocks((kernel), (block), (device)); dev_ = (device); } \
+    return (u32)std::min<u64>((want) ? (want) : 1, cap_); }())
+
 // ------------------------------------------------------------------ handles
 struct mcq_db {
     DbDev d;
@@ -1295,7 +1312,8 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     HIPCHK(hipMemsetAsync(ws->ctr, 0, sizeof(CountersDev), st));
     if (b.nq == 0) return MCQ_OK;
     u64 want = (b.nq + 3) / 4;
-    u32 grid = (u32)std::min<u64>(want, 256ull * 24);
+    const u32 grid = db->d.compact ? MCQ_GRID((k_query_wave<u32, kLcapWave>), 256, db->device, want)
+                                   : MCQ_GRID((k_query_wave<u64, kLcapWave>), 256, db->device, want);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ws->timing) {
         if (!ws->ev_free->empty()) { e0 = ws->ev_free->back().first; e1 = ws->ev_free->back().second; ws->ev_free->pop_back(); }
@@ -1436,7 +1454,7 @@ extern "C" int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t*
     if (in->n_seqs == 0) return MCQ_OK;
     // many short sequences (reads): one wave per sequence; few long ones (genomes): one wave per window
     if (in->n_seqs >= 4096) {
-        u32 grid = (u32)std::min<u64>((in->n_seqs + 3) / 4, 256ull * 32);
+        const u32 grid = MCQ_GRID(k_sketch_seqs, 256, db->device, (in->n_seqs + 3) / 4);
         hipLaunchKernelGGL(k_sketch_seqs, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, in->bases, in->seq_off,
                            (in->flags & MCQ_BATCH_RANGES) ? 1u : 0u, in->n_seqs, win_off, features, n_feat);
     } else {
@@ -1469,7 +1487,8 @@ extern "C" int mcq_lookup_gather(const mcq_db* db, const uint32_t* features, uin
     HIPCHK(hipSetDevice(db->device));
     if (n_features == 0) return MCQ_OK;
     u64 groups = (n_features + 63) / 64;
-    u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
+    const u32 grid = db->d.compact ? MCQ_GRID(k_lookup_gather<u32>, 256, db->device, (groups + 3) / 4)
+                                   : MCQ_GRID(k_lookup_gather<u64>, 256, db->device, (groups + 3) / 4);
     if (db->d.compact) hipLaunchKernelGGL(k_lookup_gather<u32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, list_len, list_src, out_off, (u32*)out_locs);
     else               hipLaunchKernelGGL(k_lookup_gather<u64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, list_len, list_src, out_off, (u64*)out_locs);
     HIPCHK(hipGetLastError());
@@ -1495,7 +1514,8 @@ extern "C" int mcq_assemble(const mcq_db* db, uint64_t n_lists, const uint32_t* 
     rc = device_exclusive_scan<u32>(list_len, src_off, n_lists, st); if (rc) return rc;
     if (n_lists) {
         u64 groups = (n_lists + 63) / 64;
-        u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
+        const u32 grid = db->d.compact ? MCQ_GRID(k_scatter_lists<u32>, 256, db->device, (groups + 3) / 4)
+                                       : MCQ_GRID(k_scatter_lists<u64>, 256, db->device, (groups + 3) / 4);
         if (db->d.compact) hipLaunchKernelGGL(k_scatter_lists<u32>, dim3(grid), dim3(256), 0, st, n_lists, (const u64*)src_off, src_slot, (const u64*)dst_off, (const u32*)src_locs, (u32*)dst_locs);
         else               hipLaunchKernelGGL(k_scatter_lists<u64>, dim3(grid), dim3(256), 0, st, n_lists, (const u64*)src_off, src_slot, (const u64*)dst_off, (const u64*)src_locs, (u64*)dst_locs);
     }
@@ -1520,7 +1540,8 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     ws->last_nq = n_queries;
     if (n_queries == 0) return MCQ_OK;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
-    u32 grid = (u32)std::min<u64>((n_queries + 3) / 4, 256ull * 24);
+    const u32 grid = db->d.compact ? MCQ_GRID((k_reduce_wave<u32, kLcapWave>), 256, db->device, (n_queries + 3) / 4)
+                                   : MCQ_GRID((k_reduce_wave<u64, kLcapWave>), 256, db->device, (n_queries + 3) / 4);
     if (db->d.compact) {
         hipLaunchKernelGGL((k_reduce_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
                            n_queries, loc_off, (const u32*)locs, query_len);
