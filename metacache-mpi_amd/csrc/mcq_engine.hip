@@ -37,9 +37,9 @@ extern "C" const char* mcq_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mcq_version(void) { return "mcq 0.1 (gfx950)"; }
 
 // ------------------------------------------------------------------ persistent grids
-// The wave-per-item kernels loop over their items (grid stride).  The grid is exactly what the device holds at
-// once -- occupancy x CUs -- and no more: with 3 x that many workgroups the last round leaves most of the chip
-// idle while a few waves finish (k_query_wave: 2.26 ms at 24 workgroups per CU, 2.07 ms at the resident 8).
+// The fused query kernel loops over its queries (grid stride).  Its grid is exactly what the device holds at
+// once -- occupancy x CUs -- and no more: 2.26 ms at 24 workgroups per CU, 2.07 ms at the resident 8 (long items,
+// all waves alive from start to end).  The staged kernels with short items keep several rounds of workgroups.
 template <class Kernel>
 static u32 resident_blocks(Kernel kernel, int block_size, int device) {
     int per_cu = 0;
@@ -1454,7 +1454,7 @@ extern "C" int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t*
     if (in->n_seqs == 0) return MCQ_OK;
     // many short sequences (reads): one wave per sequence; few long ones (genomes): one wave per window
     if (in->n_seqs >= 4096) {
-        const u32 grid = MCQ_GRID(k_sketch_seqs, 256, db->device, (in->n_seqs + 3) / 4);
+        const u32 grid = (u32)std::min<u64>((in->n_seqs + 3) / 4, 256ull * 32);    // short items: several rounds balance better
         hipLaunchKernelGGL(k_sketch_seqs, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, in->bases, in->seq_off,
                            (in->flags & MCQ_BATCH_RANGES) ? 1u : 0u, in->n_seqs, win_off, features, n_feat);
     } else {
@@ -1487,8 +1487,7 @@ extern "C" int mcq_lookup_gather(const mcq_db* db, const uint32_t* features, uin
     HIPCHK(hipSetDevice(db->device));
     if (n_features == 0) return MCQ_OK;
     u64 groups = (n_features + 63) / 64;
-    const u32 grid = db->d.compact ? MCQ_GRID(k_lookup_gather<u32>, 256, db->device, (groups + 3) / 4)
-                                   : MCQ_GRID(k_lookup_gather<u64>, 256, db->device, (groups + 3) / 4);
+    const u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
     if (db->d.compact) hipLaunchKernelGGL(k_lookup_gather<u32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, list_len, list_src, out_off, (u32*)out_locs);
     else               hipLaunchKernelGGL(k_lookup_gather<u64>, dim3(grid), dim3(256), 0, (hipStream_t)stream, db->d, features, n_features, list_len, list_src, out_off, (u64*)out_locs);
     HIPCHK(hipGetLastError());
@@ -1514,8 +1513,7 @@ extern "C" int mcq_assemble(const mcq_db* db, uint64_t n_lists, const uint32_t* 
     rc = device_exclusive_scan<u32>(list_len, src_off, n_lists, st); if (rc) return rc;
     if (n_lists) {
         u64 groups = (n_lists + 63) / 64;
-        const u32 grid = db->d.compact ? MCQ_GRID(k_scatter_lists<u32>, 256, db->device, (groups + 3) / 4)
-                                       : MCQ_GRID(k_scatter_lists<u64>, 256, db->device, (groups + 3) / 4);
+        const u32 grid = (u32)std::min<u64>((groups + 3) / 4, 256ull * 32);
         if (db->d.compact) hipLaunchKernelGGL(k_scatter_lists<u32>, dim3(grid), dim3(256), 0, st, n_lists, (const u64*)src_off, src_slot, (const u64*)dst_off, (const u32*)src_locs, (u32*)dst_locs);
         else               hipLaunchKernelGGL(k_scatter_lists<u64>, dim3(grid), dim3(256), 0, st, n_lists, (const u64*)src_off, src_slot, (const u64*)dst_off, (const u64*)src_locs, (u64*)dst_locs);
     }
@@ -1540,8 +1538,7 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     ws->last_nq = n_queries;
     if (n_queries == 0) return MCQ_OK;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
-    const u32 grid = db->d.compact ? MCQ_GRID((k_reduce_wave<u32, kLcapWave>), 256, db->device, (n_queries + 3) / 4)
-                                   : MCQ_GRID((k_reduce_wave<u64, kLcapWave>), 256, db->device, (n_queries + 3) / 4);
+    const u32 grid = (u32)std::min<u64>((n_queries + 3) / 4, 256ull * 24);     // measured: 1.07 ms vs 1.25 ms at the resident 8 per CU
     if (db->d.compact) {
         hipLaunchKernelGGL((k_reduce_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
                            n_queries, loc_off, (const u32*)locs, query_len);
