@@ -38,7 +38,13 @@ def main():
     sq = sharded.ShardedQuery(db, world, rank, dev, max_queries=nq)
     cands = torch.zeros((nq, M, 4), dtype=torch.int32, device=dev)
     ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
-    sq.query(reads, roff, n_seqs, bool(paired), cands, ncand, max_cand=M, emulate_ranks=P)
+    # window count of the batch, so that the next batch's sketch can be announced (second-stream prefetch path)
+    win_off = torch.empty(n_seqs + 1, dtype=torch.int64, device=dev)
+    db.count_windows(reads.data_ptr(), roff.data_ptr(), n_seqs, win_off.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    hint = int(win_off[-1].item())
+    sq.query(reads, roff, n_seqs, bool(paired), cands, ncand, max_cand=M, emulate_ranks=P, n_win_hint=hint,
+             next_batch=(reads, roff, n_seqs))
+    assert sq._prepared is not None                      # the same batch again: its sketch is already under way
     st = sq.last_stats()
     torch.cuda.synchronize()
     odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), off.cpu().numpy().astype(np.uint64),
@@ -52,7 +58,9 @@ def main():
         ok = bool(np.array_equal(gc[mask], oc[mask]))
     # the reduce kernel without its de-duplicating pass must agree as well
     cands2 = torch.zeros_like(cands); ncand2 = torch.zeros_like(ncand)
-    sq.query(reads, roff, n_seqs, bool(paired), cands2, ncand2, max_cand=M, emulate_ranks=P, flags=eng.MCQ_FORCE_RAW_SORT)
+    sq.query(reads, roff, n_seqs, bool(paired), cands2, ncand2, max_cand=M, emulate_ranks=P, flags=eng.MCQ_FORCE_RAW_SORT,
+             n_win_hint=hint)                            # consumes the prepared sketch + buckets
+    assert sq._prepared is None
     torch.cuda.synchronize()
     if ok:
         g2 = cands2.cpu().numpy().view(np.uint32); n2 = ncand2.cpu().numpy().view(np.uint32)
