@@ -869,7 +869,9 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
         u32 beg = 0, end = 0;
         if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, wb, beg, end);
         uint4 v; v.x = Ltax; v.y = (u32)(Lhv >> JB); v.z = beg; v.w = end;
-        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
+        u32 ln = lane;
+        asm volatile("" : "+v"(ln));               // keeps (cands + 16 * lane) from being hoisted out of the query loop and spilled
+        reinterpret_cast<uint4*>(out.cands)[q * M + ln] = v;
     }
     if (lane == 0) out.ncand[q] = n;
     return n;
@@ -925,7 +927,9 @@ __device__ __forceinline__ u32 fold_lists_write(const DbDev& db, const OptDev& o
         u32 beg = 0, end = 0;
         if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, wb, beg, end);
         uint4 v; v.x = Ltax; v.y = (u32)(Lhv >> JB); v.z = beg; v.w = end;
-        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = v;
+        u32 ln = lane;
+        asm volatile("" : "+v"(ln));               // keeps (cands + 16 * lane) from being hoisted out of the query loop and spilled
+        reinterpret_cast<uint4*>(out.cands)[q * M + ln] = v;
     }
     if (lane == 0) out.ncand[q] = n;
     return n;
