@@ -1262,7 +1262,8 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     if (lmax > (1ull << 30)) return fail(MCQ_E_UNSUPPORTED, "max_locs_per_query too large");
     ws->sc.lmax = (u32)lmax;
     ws->sc.fmax = 1u << 15;
-    ws->n_block_wgs = 512;                   // two resident workgroups per CU (32-bit keys: 64 KB of LDS, 64 VGPRs)
+    ws->n_block_wgs = 512;
+    if (const char* e = getenv("MCQ_BLOCK_WGS")) ws->n_block_wgs = std::max(1, atoi(e));      // tuning knob                   // two resident workgroups per CU (32-bit keys: 64 KB of LDS, 64 VGPRs)
     ws->ev_used = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     ws->ev_free = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     const u64 nb = (u64)ws->n_block_wgs;
