@@ -264,26 +264,33 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
     for (int e = 0; e < E; ++e) buf[e * 64 + lane] = r[e];
 }
 
-// ---- rows 8-9 on DISTINCT (tgt,win) keys (32-bit keys, T <= 384) ------------------------------
+// ---- rows 8-9 on DISTINCT (tgt,win) keys (32-bit keys, T <= 512) ------------------------------
 // A read's match list repeats the same (target, window) many times (C2: 107 locations, 33 distinct;
-// 2x150 bp pairs: 214 / 65), and everything after the gather only needs the distinct keys and how
-// often each occurs.  The wave counts them in a 512-slot open-addressing table in its LDS segment
-// (ds_cmpst claims a slot, ds_add counts in a 16-bit lane), the lanes that claimed a slot compact their
-// keys, <= 128 distinct keys are sorted in one or two registers per lane instead of 64*E raw locations,
-// and the multiplicities come back by probing the table with the sorted keys.  Output: SK[0..D) sorted
-// distinct keys, WP[0..D) inclusive prefix sums of the multiplicities (for sweep_targets_weighted).
-// Returns D, or ~0u when there are more than 128 distinct keys (the caller then sorts the raw list).
-//   LDS (u32 words): buf[0..512) table keys, later the sweep's H;  hits[0..256) table counts (16 bits per
-//   slot: any multiset of up to 384 locations is counted exactly, whatever the caller of mcq_reduce hands over),
-//   later WP in hits[0..128);  hits[256..384) compaction list;  hits[384..512) SK.
-#define MCQ_DEDUP_MAX_T 384u
+// 2x150 bp pairs: 214 / 65; on an 8 x larger table 218 / 140), and everything after the gather only needs
+// the distinct keys and how often each occurs.  The wave counts them in a 512-slot open-addressing table
+// in its LDS segment (ds_cmpst claims a slot, ds_add counts in a 16-bit lane), the lanes that claimed a
+// slot compact their keys, <= 256 distinct keys are sorted in one, two or four registers per lane instead
+// of 64*E raw locations, and the multiplicities come back by probing the table with the sorted keys.
+// Output: SK[0..D) sorted distinct keys, WP[0..D) inclusive prefix sums of the multiplicities (for
+// sweep_targets_weighted).  Returns D, or ~0u when there are more than 256 distinct keys (the caller then
+// sorts the raw list); the insertion stops at the first register that takes D past 256, so the table never
+// holds more than 320 keys.
+//   LDS (u32 words): buf[0..512) table keys, later the sweep's H in buf[0..256) and the top lists' scratch
+//   behind it;  hits[0..256) table counts (16 bits per slot: any multiset of up to 512 locations is counted
+//   exactly, whatever the caller of mcq_reduce hands over), later WP;  hits[256..512) compaction list, later SK.
+#ifndef MCQ_DEDUP_MAX_T
+#define MCQ_DEDUP_MAX_T 512u    // tuning knobs: -DMCQ_DEDUP_MAX_T=384u -DMCQ_DEDUP_MAX_D=128u is the two-register form
+#endif
+#ifndef MCQ_DEDUP_MAX_D
+#define MCQ_DEDUP_MAX_D 256u
+#endif
 #ifdef MCQ_TOPK_DPP        // tuning knob: DPP reductions per rank instead of LDS maxima for all ranks at once
 #define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write<u32, u32, 9>(db, opt, out, sk, h, D, nw, wb, q, lane)
 #else
 #define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write_lds(db, opt, out, sk, h, D, nw, wb, q, lane, (h) + 256)
 #endif
 __device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 23; }
-__device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 384; }
+__device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 256; }
 __device__ __forceinline__ u32* dedup_wp(u32* hits) { return hits; }
 __device__ __forceinline__ u32 dedup_count(const u32* tabkey, const u32* tabcnt, u32 k) {
     u32 slot = dedup_slot(k);
@@ -310,7 +317,7 @@ __device__ __forceinline__ u32 dedup_insert(const u32 (&r)[E], u32* buf, u32* hi
         bool created = false;
         if ((u32)(e * 64) + lane < T) {
             u32 slot = dedup_slot(key);
-            while (true) {                       // T <= 384 < 512 slots: an empty slot always exists
+            while (true) {                       // <= 320 keys in 512 slots: an empty slot always exists
                 const u32 old = atomicCAS(&tabkey[slot], MCQ_EMPTY, key);
                 created = old == MCQ_EMPTY;
                 if (created || old == key) { atomicAdd(&tabcnt[slot >> 1], 1u << (16 * (slot & 1))); break; }
@@ -319,19 +326,20 @@ __device__ __forceinline__ u32 dedup_insert(const u32 (&r)[E], u32* buf, u32* hi
         }
         const u64 cm = __ballot(created);
         const u32 rank = D + lane_rank(cm);
-        if (created && rank < 128) list[rank] = key;
+        if (created && rank < MCQ_DEDUP_MAX_D) list[rank] = key;
         D += (u32)__builtin_popcountll(cm);
+        if (D > MCQ_DEDUP_MAX_D) break;          // wave-uniform: the raw list gets sorted instead
     }
     wave_sync();
     return D;
 }
 // Second half, the same code for every E: sort the D distinct keys, fetch their multiplicities, prefix sums.
 // k1/incl1: the sorted keys and inclusive sums one per lane when D <= 64 (for sweep_targets_regs).
-// Returns D, or ~0u when D > 128.
+// Returns D, or ~0u when D > 256.
 __device__ __forceinline__ u32 dedup_finish(u32 D, u32* buf, u32* hits, u32 lane, u32& k1, u32& incl1) {
     u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 256; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
     k1 = MCQ_EMPTY; incl1 = 0;
-    if (D > 128) return ~0u;
+    if (D > MCQ_DEDUP_MAX_D) return ~0u;
     if (D <= 64) {
         u32 k = lane < D ? list[lane] : MCQ_EMPTY;
         k = (D <= 32) ? wave_sort32_low(k, lane) : wave_sort64(k, lane);
@@ -340,7 +348,7 @@ __device__ __forceinline__ u32 dedup_finish(u32 D, u32* buf, u32* hits, u32 lane
         wave_sync();                             // counts consumed: WP overwrites them
         SK[lane] = k; WP[lane] = incl;
         k1 = k; incl1 = incl;
-    } else {
+    } else if (D <= 128) {
         u32 k[2];
         k[0] = list[lane]; k[1] = (64 + lane < D) ? list[64 + lane] : MCQ_EMPTY;
         wave_regsort<u32, 2>(k, lane);
@@ -350,6 +358,19 @@ __device__ __forceinline__ u32 dedup_finish(u32 D, u32* buf, u32* hits, u32 lane
         const u32 i1 = wave_incl_scan_dpp(c1) + bcast(i0, 63);
         wave_sync();
         SK[lane] = k[0]; SK[64 + lane] = k[1]; WP[lane] = i0; WP[64 + lane] = i1;
+    } else {
+        u32 k[4], c[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) k[e] = ((u32)(64 * e) + lane < D) ? list[64 * e + lane] : MCQ_EMPTY;
+        wave_regsort<u32, 4>(k, lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c[e] = ((u32)(64 * e) + lane < D) ? dedup_count(tabkey, tabcnt, k[e]) : 0u;
+        u32 carry = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { c[e] = wave_incl_scan_dpp(c[e]) + carry; carry = bcast(c[e], 63); }
+        wave_sync();                             // list and counts consumed: SK and WP overwrite them
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { SK[64 * e + lane] = k[e]; WP[64 * e + lane] = c[e]; }
     }
     wave_sync();                                 // table dead from here: buf[] becomes the sweep's H
     return D;
@@ -464,7 +485,8 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                 else if (T <= 128) D = gather_dedup_insert<2>(db, buf, hits, T, pos, len, off, lane, stop);
                 else if (T <= 192) D = gather_dedup_insert<3>(db, buf, hits, T, pos, len, off, lane, stop);
                 else if (T <= 256) D = gather_dedup_insert<4>(db, buf, hits, T, pos, len, off, lane, stop);
-                else               D = gather_dedup_insert<6>(db, buf, hits, T, pos, len, off, lane, stop);
+                else if (T <= 384) D = gather_dedup_insert<6>(db, buf, hits, T, pos, len, off, lane, stop);
+                else               D = gather_dedup_insert<8>(db, buf, hits, T, pos, len, off, lane, stop);
                 if (D != ~1u) D = dedup_finish(D, buf, hits, lane, k1, incl1);
                 if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
@@ -475,7 +497,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                     wave_sync();
                     continue;
                 }
-                wave_sync();                       // more than 128 distinct keys: the raw list is sorted below
+                wave_sync();                       // more than 256 distinct keys: the raw list is sorted below
             }
         }
         if (T <= 64)       gather_sort_store<KeyT, 1>(db, buf, hits, T, pos, len, off, lane, stop);
@@ -822,7 +844,8 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
                 else if (T <= 128) D = load_dedup_insert<2>(src, buf, hits, T, lane);
                 else if (T <= 192) D = load_dedup_insert<3>(src, buf, hits, T, lane);
                 else if (T <= 256) D = load_dedup_insert<4>(src, buf, hits, T, lane);
-                else               D = load_dedup_insert<6>(src, buf, hits, T, lane);
+                else if (T <= 384) D = load_dedup_insert<6>(src, buf, hits, T, lane);
+                else               D = load_dedup_insert<8>(src, buf, hits, T, lane);
                 D = dedup_finish(D, reinterpret_cast<u32*>(buf), hits, lane, k1, incl1);
                 if (D != ~0u) {
                     if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);

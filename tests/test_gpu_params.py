@@ -88,9 +88,7 @@ def test_capacity_error_is_reported_not_hidden():
     assert (n > 0).all() and big.sync()["n_overflow"] == 4
 
 
-def test_reduce_counts_any_multiset_exactly():
-    """mcq_reduce on caller-made location lists with hundreds of copies of one (target, window): the de-duplicating
-    tail must count them exactly (16-bit table counters), like the oracle's reduce on the same multiset"""
+def _reduce_against_oracle(make_lists):
     import torch
     from golden_util import Fixture
     from oracle import dbfile
@@ -104,13 +102,7 @@ def test_reduce_counts_any_multiset_exactly():
                       tgt_winstride=p["winstride"])
     odb = orc.OracleDb(keys, off, locs, t2t, k=p["qk"], s=p["qs"], winlen=p["qwinlen"], winstride=p["qwinstride"],
                        tgt_winstride=p["winstride"])
-    rng = np.random.default_rng(9)
-    lists = []
-    for q in range(300):
-        base = rng.choice(locs, size=int(rng.integers(1, 12)))
-        reps = rng.integers(1, 330, size=len(base))
-        reps = np.minimum(reps, max(1, 380 // len(base)))
-        lists.append(np.sort(np.repeat(base, reps)))                 # up to ~380 locations, a few distinct keys
+    lists = make_lists(locs)
     loc_off = np.zeros(len(lists) + 1, np.int64); loc_off[1:] = np.cumsum([len(x) for x in lists])
     allv = np.concatenate(lists)
     wb = db.win_bits()
@@ -131,5 +123,37 @@ def test_reduce_counts_any_multiset_exactly():
             gc = cands.cpu().numpy().view(np.uint32); gn = ncand.cpu().numpy().view(np.uint32)
             for q, lst in enumerate(lists):
                 oc, on = odb.reduce_query(lst, 150, max_cand=M, emulate_ranks=P)
-                assert gn[q] == on, (q, P, M, flags)
-                assert np.array_equal(gc[q, :on], oc[:on]), (q, P, M, flags, gc[q], oc)
+                assert gn[q] == on, (q, P, M, flags, len(lst), len(np.unique(lst)))
+                assert np.array_equal(gc[q, :on], oc[:on]), (q, P, M, flags, len(lst), len(np.unique(lst)), gc[q], oc)
+
+
+def test_reduce_counts_any_multiset_exactly():
+    """mcq_reduce on caller-made location lists with hundreds of copies of one (target, window): the de-duplicating
+    tail must count them exactly (16-bit table counters), like the oracle's reduce on the same multiset"""
+    def make(locs):
+        rng = np.random.default_rng(9)
+        lists = []
+        for q in range(300):
+            base = rng.choice(locs, size=int(rng.integers(1, 12)))
+            reps = rng.integers(1, 500, size=len(base))
+            reps = np.minimum(reps, max(1, 510 // len(base)))
+            lists.append(np.sort(np.repeat(base, reps)))                 # up to ~510 locations, a few distinct keys
+        return lists
+    _reduce_against_oracle(make)
+
+
+def test_reduce_distinct_key_boundaries():
+    """location lists with exactly D distinct (target, window) keys for D on both sides of every limit of the
+    de-duplicating tail (64 / 128 / 256 keys in 1 / 2 / 4 registers per lane, more than 256: raw sort) and list
+    lengths up to the wave kernel's 512, plus a few longer ones for the workgroup kernel"""
+    def make(locs):
+        rng = np.random.default_rng(10)
+        uniq = np.unique(locs)
+        lists = []
+        for D in (1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 258, 300, 320, 321, 383, 384, 385, 511, 512):
+            for T in sorted({D, min(512, D + 1), min(512, D + 63), min(512, 2 * D), 384 if D <= 384 else 512, 512, 600}):
+                base = rng.choice(uniq, size=D, replace=False)
+                extra = rng.choice(base, size=T - D) if T > D else base[:0]
+                lists.append(np.sort(np.concatenate([base, extra])))
+        return lists
+    _reduce_against_oracle(make)
