@@ -119,6 +119,7 @@ def main():
     gen_bases, gen_off, species = synth.make_genomes(a.species, a.strains, a.genome_min, a.genome_max,
                                                      a.divergence, seed=3, device=dev)
     # table built on the GPU through the C ABI (mcq_build_table, csrc/mcq_build.hip)
+    torch.cuda.empty_cache()            # the builder allocates with hipMalloc, outside torch's cache
     t_build = time.time()
     table = eng.Table(gen_bases.data_ptr(), gen_off.data_ptr(), gen_off.numel() - 1, emulate_ranks=a.emulate_ranks,
                       device=dev.index or 0)

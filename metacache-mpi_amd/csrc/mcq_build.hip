@@ -11,10 +11,13 @@
 // mcq_db_create), plus rocPRIM's radix sort for the two global sorts -- a plain library sort of
 // ~3e8 pairs, run once per database, outside any timed region.
 #include <cstring>
+#include <chrono>
+#include <cstdio>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/mcq.h"
 
@@ -27,6 +30,43 @@ int bfail(int code, const std::string& m) { g_berr = m; return code; }
 #define BCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     return bfail(MCQ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 #define MCHK(expr) do { int r_ = (expr); if (r_ != MCQ_OK) return r_; } while (0)
+
+// Temporaries of one build come from the device's default memory pool with its release threshold lifted, so a buffer
+// freed by one phase is handed to the next without unmapping and remapping HBM (hipMalloc / hipFree of tens of GB were
+// most of the build time of a 16 Gbp input).  The destructor frees what an error path left behind, restores the
+// threshold and trims the pool, so nothing stays reserved after the call.
+struct Scratch {
+    hipMemPool_t pool = nullptr;
+    uint64_t old_threshold = 0;
+    std::vector<void*> live;
+    hipError_t init(int device) {
+        hipError_t e = hipDeviceGetDefaultMemPool(&pool, device);
+        if (e != hipSuccess) return e;
+        e = hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &old_threshold);
+        if (e != hipSuccess) return e;
+        uint64_t keep = ~0ull;
+        return hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    template <class T> hipError_t get(T** p, u64 bytes) {
+        void* q = nullptr;
+        hipError_t e = hipMallocAsync(&q, bytes ? bytes : 1, 0);
+        if (e == hipSuccess) { live.push_back(q); *p = static_cast<T*>(q); }
+        return e;
+    }
+    void put(void* p) {
+        if (!p) return;
+        for (size_t i = 0; i < live.size(); ++i) if (live[i] == p) { live[i] = live.back(); live.pop_back(); break; }
+        (void)hipFreeAsync(p, 0);
+    }
+    ~Scratch() {
+        for (void* p : live) (void)hipFreeAsync(p, 0);
+        (void)hipStreamSynchronize(0);
+        if (pool) {
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &old_threshold);
+            (void)hipMemPoolTrimTo(pool, 0);
+        }
+    }
+};
 
 const u32 TB = 256;
 inline dim3 grid_for(u64 n) { u64 g = (n + TB - 1) / TB; return dim3((u32)(g < (1u << 22) ? (g ? g : 1) : (1u << 22))); }
@@ -158,15 +198,27 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     const u32 P = d->emulate_ranks ? d->emulate_ranks : 1;
     const u32 max_locs = d->max_locs ? d->max_locs : 254;
     BCHK(hipSetDevice(d->device));
+    Scratch tmpbuf;
+    BCHK(tmpbuf.init(d->device));
     const bool dev = (d->flags & MCQ_DEVICE_PTRS) != 0;
     const u32 nt = d->n_targets;
+    // MCQ_BUILD_TRACE=1: phase times on stderr (diagnostic; adds a device synchronisation per phase)
+    const bool trace = getenv("MCQ_BUILD_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto phase = [&](const char* name) {
+        if (!trace) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mcq_build] %-28s %8.3f s\n", name, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
 
     // inputs on the device
     const char* bases = d->bases; const u64* seq_off = d->seq_off;
     char* t_bases = nullptr; u64* t_off = nullptr;
     if (!dev) {
         const u64 nb = d->seq_off[nt];
-        BCHK(hipMalloc(&t_bases, nb ? nb : 1)); BCHK(hipMalloc(&t_off, (u64)(nt + 1) * 8));
+        BCHK(tmpbuf.get(&t_bases, nb ? nb : 1)); BCHK(tmpbuf.get(&t_off, (u64)(nt + 1) * 8));
         if (nb) BCHK(hipMemcpy(t_bases, d->bases, nb, hipMemcpyHostToDevice));
         BCHK(hipMemcpy(t_off, d->seq_off, (u64)(nt + 1) * 8, hipMemcpyHostToDevice));
         bases = t_bases; seq_off = t_off;
@@ -181,6 +233,7 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     mcq_table* T = new mcq_table();
     std::memset(T, 0, sizeof(*T));
     T->device = d->device; T->n_targets = nt;
+    struct TableGuard { mcq_table*& t; ~TableGuard() { if (t) mcq_table_free(t); } } guard{T};     // error paths
     BCHK(hipMalloc(&T->win_off, (u64)(nt + 1) * 8));
     mcq_batch b; b.n_seqs = nt; b.bases = bases; b.seq_off = seq_off; b.paired = 0; b.flags = MCQ_DEVICE_PTRS;
     MCHK(mcq_count_windows(sk, &b, T->win_off, nullptr));
@@ -190,74 +243,87 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     const u32 s = d->sketch_size;
     const u64 n = n_win * s;
     u32 *feat = nullptr, *nfeat = nullptr;
-    BCHK(hipMalloc(&feat, (n ? n : 1) * 4)); BCHK(hipMalloc(&nfeat, (n_win ? n_win : 1) * 4));
+    BCHK(tmpbuf.get(&feat, (n ? n : 1) * 4)); BCHK(tmpbuf.get(&nfeat, (n_win ? n_win : 1) * 4));
     MCHK(mcq_sketch(sk, &b, T->win_off, feat, nfeat, nullptr));
     BCHK(hipDeviceSynchronize());
     mcq_db_destroy(sk);
-    (void)hipFree(nfeat);
+    tmpbuf.put(nfeat);
+    phase("windows + sketches");
 
     // (feature * P + rank, global window), stable sort: groups in (target, window) order
     u64 *key = nullptr, *key2 = nullptr; u32 *val = nullptr, *val2 = nullptr;
-    BCHK(hipMalloc(&key, (n ? n : 1) * 8)); BCHK(hipMalloc(&key2, (n ? n : 1) * 8));
-    BCHK(hipMalloc(&val, (n ? n : 1) * 4)); BCHK(hipMalloc(&val2, (n ? n : 1) * 4));
+    BCHK(tmpbuf.get(&key, (n ? n : 1) * 8)); BCHK(tmpbuf.get(&key2, (n ? n : 1) * 8));
+    BCHK(tmpbuf.get(&val, (n ? n : 1) * 4)); BCHK(tmpbuf.get(&val2, (n ? n : 1) * 4));
+    phase("  (allocations)");
     if (n) hipLaunchKernelGGL(k_make_pairs, grid_for(n), dim3(TB), 0, 0, feat, n, s, T->win_off, nt, P, key, val);
-    (void)hipFree(feat);
+    phase("  (k_make_pairs)");
+    tmpbuf.put(feat);
+    phase("pairs");
     if (n) {
+        // keys are feature * P + rank < 2^32 * P: only these bits take part in the sort
+        u32 key_bits = 32; while (key_bits < 64 && (((u64)P - 1) >> (key_bits - 32))) ++key_bits;
         size_t tmp = 0;
-        BCHK(rocprim::radix_sort_pairs(nullptr, tmp, key, key2, val, val2, n, 0, 64));
-        void* t = nullptr; BCHK(hipMalloc(&t, tmp ? tmp : 1));
-        BCHK(rocprim::radix_sort_pairs(t, tmp, key, key2, val, val2, n, 0, 64));
+        BCHK(rocprim::radix_sort_pairs(nullptr, tmp, key, key2, val, val2, n, 0, key_bits));
+        void* t = nullptr; BCHK(tmpbuf.get(&t, tmp ? tmp : 1));
+        BCHK(rocprim::radix_sort_pairs(t, tmp, key, key2, val, val2, n, 0, key_bits));
         BCHK(hipDeviceSynchronize());
-        (void)hipFree(t);
+        tmpbuf.put(t);
     }
-    (void)hipFree(key); (void)hipFree(val);
+    tmpbuf.put(key); tmpbuf.put(val);
+    phase("sort by (feature, rank)");
 
     // rank inside each group, keep the first max_locs
     u32 *head = nullptr, *keep = nullptr; u64 *gid = nullptr, *gstart = nullptr, *pos = nullptr;
-    BCHK(hipMalloc(&head, (n ? n : 1) * 4)); BCHK(hipMalloc(&keep, (n ? n : 1) * 4));
-    BCHK(hipMalloc(&gid, (n ? n : 1) * 8)); BCHK(hipMalloc(&pos, (n ? n : 1) * 8));
+    BCHK(tmpbuf.get(&head, (n ? n : 1) * 4)); BCHK(tmpbuf.get(&keep, (n ? n : 1) * 4));
+    BCHK(tmpbuf.get(&gid, (n ? n : 1) * 8)); BCHK(tmpbuf.get(&pos, (n ? n : 1) * 8));
     u64 n_groups = 0, n_kept = 0;
     if (n) hipLaunchKernelGGL(k_heads, grid_for(n), dim3(TB), 0, 0, key2, n, head);
+    phase("  (k_heads)");
     MCHK(excl_scan(head, gid, n, &n_groups));
-    BCHK(hipMalloc(&gstart, (n_groups ? n_groups : 1) * 8));
+    phase("  (scan heads)");
+    BCHK(tmpbuf.get(&gstart, (n_groups ? n_groups : 1) * 8));
     if (n) {
         hipLaunchKernelGGL(k_group_start, grid_for(n), dim3(TB), 0, 0, head, gid, n, gstart);
         hipLaunchKernelGGL(k_keep, grid_for(n), dim3(TB), 0, 0, key2, head, gid, gstart, n, max_locs, keep);
     }
+    phase("  (k_group_start, k_keep)");
     MCHK(excl_scan(keep, pos, n, &n_kept));
+    phase("  (scan keep)");
     u64* fw = nullptr;
-    BCHK(hipMalloc(&fw, (n_kept ? n_kept : 1) * 8));
+    BCHK(tmpbuf.get(&fw, (n_kept ? n_kept : 1) * 8));
     if (n) hipLaunchKernelGGL(k_compact, grid_for(n), dim3(TB), 0, 0, key2, val2, keep, pos, n, P, fw);
     BCHK(hipDeviceSynchronize());
-    (void)hipFree(key2); (void)hipFree(val2); (void)hipFree(keep); (void)hipFree(gid); (void)hipFree(gstart); (void)hipFree(pos);
+    tmpbuf.put(key2); tmpbuf.put(val2); tmpbuf.put(keep); tmpbuf.put(gid); tmpbuf.put(gstart); tmpbuf.put(pos);
+    phase("truncate to max_locs");
 
     // merge the virtual ranks' lists of a feature into (target, window) order
     if (P > 1 && n_kept) {
-        u64* fw2 = nullptr; BCHK(hipMalloc(&fw2, n_kept * 8));
+        u64* fw2 = nullptr; BCHK(tmpbuf.get(&fw2, n_kept * 8));
         size_t tmp = 0;
         BCHK(rocprim::radix_sort_keys(nullptr, tmp, fw, fw2, n_kept, 0, 64));
-        void* t = nullptr; BCHK(hipMalloc(&t, tmp ? tmp : 1));
+        void* t = nullptr; BCHK(tmpbuf.get(&t, tmp ? tmp : 1));
         BCHK(rocprim::radix_sort_keys(t, tmp, fw, fw2, n_kept, 0, 64));
         BCHK(hipDeviceSynchronize());
-        (void)hipFree(t); (void)hipFree(fw);
+        tmpbuf.put(t); tmpbuf.put(fw);
         fw = fw2;
     }
+    phase("merge ranks");
     // keys, offsets, (target, window) locations
     u64* kid = nullptr; u64 n_keys = 0;
-    (void)hipFree(head);
-    BCHK(hipMalloc(&head, (n_kept ? n_kept : 1) * 4)); BCHK(hipMalloc(&kid, (n_kept ? n_kept : 1) * 8));
+    tmpbuf.put(head);
+    BCHK(tmpbuf.get(&head, (n_kept ? n_kept : 1) * 4)); BCHK(tmpbuf.get(&kid, (n_kept ? n_kept : 1) * 8));
     if (n_kept) hipLaunchKernelGGL(k_feat_heads, grid_for(n_kept), dim3(TB), 0, 0, fw, n_kept, head);
     MCHK(excl_scan(head, kid, n_kept, &n_keys));
     if ((d->flags & MCQ_BUILD_REMOVE_OVERPOPULATED) && n_kept && max_locs > 1) {
         u64 *first = nullptr, *pos2 = nullptr, *fw2 = nullptr; u32* keep2 = nullptr; u64 n2 = 0;
-        BCHK(hipMalloc(&first, (n_keys ? n_keys : 1) * 8)); BCHK(hipMalloc(&pos2, n_kept * 8)); BCHK(hipMalloc(&keep2, n_kept * 4));
+        BCHK(tmpbuf.get(&first, (n_keys ? n_keys : 1) * 8)); BCHK(tmpbuf.get(&pos2, n_kept * 8)); BCHK(tmpbuf.get(&keep2, n_kept * 4));
         hipLaunchKernelGGL(k_first_of_key, grid_for(n_kept), dim3(TB), 0, 0, head, kid, n_kept, first);
         hipLaunchKernelGGL(k_keep_small, grid_for(n_kept), dim3(TB), 0, 0, fw, head, kid, first, n_kept, n_keys, (u64)max_locs - 1, keep2);
         MCHK(excl_scan(keep2, pos2, n_kept, &n2));
-        BCHK(hipMalloc(&fw2, (n2 ? n2 : 1) * 8));
+        BCHK(tmpbuf.get(&fw2, (n2 ? n2 : 1) * 8));
         hipLaunchKernelGGL(k_compact_u64, grid_for(n_kept), dim3(TB), 0, 0, fw, keep2, pos2, n_kept, fw2);
         BCHK(hipDeviceSynchronize());
-        (void)hipFree(first); (void)hipFree(pos2); (void)hipFree(keep2); (void)hipFree(fw);
+        tmpbuf.put(first); tmpbuf.put(pos2); tmpbuf.put(keep2); tmpbuf.put(fw);
         fw = fw2; n_kept = n2;
         if (n_kept) hipLaunchKernelGGL(k_feat_heads, grid_for(n_kept), dim3(TB), 0, 0, fw, n_kept, head);
         MCHK(excl_scan(head, kid, n_kept, &n_keys));
@@ -269,10 +335,12 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     else BCHK(hipMemset(T->list_off, 0, 8));
     BCHK(hipDeviceSynchronize());
     BCHK(hipGetLastError());
-    (void)hipFree(fw); (void)hipFree(head); (void)hipFree(kid);
-    if (t_bases) (void)hipFree(t_bases);
-    if (t_off) (void)hipFree(t_off);
+    tmpbuf.put(fw); tmpbuf.put(head); tmpbuf.put(kid);
+    phase("emit keys / offsets / locations");
+    if (t_bases) tmpbuf.put(t_bases);
+    if (t_off) tmpbuf.put(t_off);
     *out = T;
+    T = nullptr;
     return MCQ_OK;
 }
 
