@@ -448,6 +448,16 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
     const int stop = force_block >> 4;              // profiling hook: 0 = run everything
+    // The distinct-key count of a read is only known after the attempt; a failed attempt costs a gather and ~300 table
+    // inserts before the raw list is gathered again.  Reads of one batch are alike, so the wave remembers the shortest
+    // list that recently failed and sends lists at least that long straight to the raw sort (results are the same
+    // either way; only the path differs).
+    // (One word of LDS per wave, touched only by lists longer than 256: a loop-carried register costs the short reads.)
+#ifndef MCQ_NO_TFAIL                                   // tuning knob (A/B)
+    __shared__ u32 s_tfail[4];
+    if (lane == 0) s_tfail[wave] = MCQ_DEDUP_MAX_T + 1;
+    wave_sync();
+#endif
 
     for (u64 q = (u64)blockIdx.x * 4 + wave; q < b.nq; q += nwaves) {
         const ReadGeom g = read_geom(db, b, q, force_block);
@@ -481,12 +491,25 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         if constexpr (sizeof(KeyT) == 4) {
             if (T <= MCQ_DEDUP_MAX_T && !(force_block & 2)) {
                 u32 D, k1 = MCQ_EMPTY, incl1 = 0;
+                bool skipped = false;
                 if (T <= 64)       D = gather_dedup_insert<1>(db, buf, hits, T, pos, len, off, lane, stop);
                 else if (T <= 128) D = gather_dedup_insert<2>(db, buf, hits, T, pos, len, off, lane, stop);
                 else if (T <= 192) D = gather_dedup_insert<3>(db, buf, hits, T, pos, len, off, lane, stop);
                 else if (T <= 256) D = gather_dedup_insert<4>(db, buf, hits, T, pos, len, off, lane, stop);
-                else if (T <= 384) D = gather_dedup_insert<6>(db, buf, hits, T, pos, len, off, lane, stop);
-                else               D = gather_dedup_insert<8>(db, buf, hits, T, pos, len, off, lane, stop);
+                else {
+#ifndef MCQ_NO_TFAIL
+                    const u32 t_fail = s_tfail[wave];
+                    skipped = T >= t_fail;
+#endif
+                    if (skipped) {                 // creep up, so that such lists are tried again now and then
+#ifndef MCQ_NO_TFAIL
+                        if (lane == 0) s_tfail[wave] = t_fail + 2;
+#endif
+                        D = MCQ_DEDUP_MAX_D + 1;
+                    }
+                    else if (T <= 384) D = gather_dedup_insert<6>(db, buf, hits, T, pos, len, off, lane, stop);
+                    else               D = gather_dedup_insert<8>(db, buf, hits, T, pos, len, off, lane, stop);
+                }
                 if (D != ~1u) D = dedup_finish(D, buf, hits, lane, k1, incl1);
                 if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
@@ -498,6 +521,9 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                     continue;
                 }
                 wave_sync();                       // more than 256 distinct keys: the raw list is sorted below
+#ifndef MCQ_NO_TFAIL
+                if (lane == 0 && !skipped) s_tfail[wave] = T;  // (T > 256) lists this long and longer skip the attempt for a while
+#endif
             }
         }
         if (T <= 64)       gather_sort_store<KeyT, 1>(db, buf, hits, T, pos, len, off, lane, stop);

@@ -167,3 +167,48 @@ def test_many_strains_cross_every_list_size_boundary():
         T = np.diff(moff.astype(np.int64))
         assert T.max() > 512 and (T <= 384).any() and ((T > 384) & (T <= 512)).any(), np.percentile(T, [1, 25, 50, 75, 99])
         assert 0 < s["n_overflow"] < n, s         # some reads went to the workgroup kernel, most did not
+
+
+def test_crafted_lists_cross_the_distinct_key_limits():
+    """A table made by hand: the features of random reads get lists of mostly distinct random (target, window)
+    locations whose length depends on the read, so the fused kernel sees 60..512 locations with about as many
+    distinct keys -- one, two and four sort registers, more than 256 distinct keys (the attempt fails, the raw list is
+    sorted), lists the wave then sends to the raw sort without trying, and some past 512 for the workgroup kernel."""
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    rng = np.random.default_rng(21)
+    n, L, n_tgt = 6000, 150, 3000
+    seqs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(n)]
+    feat_len = {}
+    for i, sq in enumerate(seqs):
+        per = int(rng.integers(2, 19))                       # 32 features x 2..18 locations
+        for w0, w1 in orc.windows(L):
+            for f in orc.sketch(sq[w0:w1].encode()):
+                feat_len.setdefault(int(f), per)
+    keys = np.array(sorted(feat_len), np.uint32)
+    lens = np.array([feat_len[int(k)] for k in keys], np.int64)
+    off = np.zeros(len(keys) + 1, np.uint64); off[1:] = np.cumsum(lens)
+    locs = np.empty(int(off[-1]), np.uint64)
+    for j in range(len(keys)):
+        t = rng.integers(0, n_tgt, size=lens[j]).astype(np.uint64)
+        w = rng.integers(0, 40, size=lens[j]).astype(np.uint64)
+        locs[int(off[j]):int(off[j + 1])] = np.sort((t << np.uint64(32)) | w)
+    t2t = (np.arange(n_tgt) // 7).astype(np.uint32)
+    rb, ro = orc.pack_reads([s.encode() for s in seqs])
+    odb = orc.OracleDb(keys, off, locs, t2t)
+    for flags in (0, eng.MCQ_DB_LOCS_64):
+        db = eng.Database(keys, off, locs, t2t, flags=flags)
+        ws = eng.Workspace(db, n, n * L)
+        for P, M in ((2, 2), (4, 4), (1, 3)):
+            oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, threads=8)
+            for qf in (0, eng.MCQ_FORCE_RAW_SORT):
+                cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P, flags=qf)
+                _compare(cands, ncand, oc, on, "crafted lists flags=%x P=%d M=%d qf=%x" % (flags, P, M, qf))
+        s = ws.sync()
+        moff, m = ws.debug_matches(rb, ro, False)
+        T = np.diff(moff.astype(np.int64))
+        starts = moff[:-1].astype(np.int64)
+        D = np.array([len(np.unique(m[a:a + t])) for a, t in zip(starts, T)])
+        for lo, hi in ((1, 64), (65, 128), (129, 256)):
+            assert ((D >= lo) & (D <= hi) & (T <= 512)).any(), (lo, hi)
+        assert ((D > 256) & (T <= 512)).sum() > 500 and (T > 512).any(), (np.percentile(T, [1, 50, 99]), np.percentile(D, [1, 50, 99]))
+        assert 0 < s["n_overflow"] < n
