@@ -53,7 +53,9 @@ enum {
                                    FASTQ text indexed by mcq_fastq_index                          */
     MCQ_FORCE_BLOCK_PATH = 0x100u, /* test hook: every query takes the workgroup path    */
     MCQ_FORCE_RAW_SORT = 0x400u,   /* test hook: the wave path sorts the raw match list instead of
-                                      de-duplicating it first (the path of T > 384 / 64-bit keys) */
+                                      de-duplicating it first (the path of > 256 distinct keys / 64-bit keys) */
+    MCQ_NO_WAVE16 = 0x800u,        /* test hook: queries of 513..1024 locations take the workgroup path
+                                      instead of the second wave stage                     */
     MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000u, /* mcq_build_desc.flags: the build option
                                    -remove-overpopulated-features (src/mode_build.cpp:847-1074): a feature whose
                                    per-rank location counts (after the per-rank limit) sum to more than

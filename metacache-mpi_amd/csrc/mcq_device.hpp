@@ -78,6 +78,8 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     unsigned long long n_features, n_hit_features, n_locations, n_cands;
     u32 ovf_count;           // queries queued for the block-per-query path
     u32 err_count;           // queries that exceeded the block path's capacity
+    u32 ovf_mid_count;       // queued from the back of the same array: <= 64 features, 513..1024 locations (k_query_wave16)
+    u32 pad_;
 };
 
 // ------------------------------------------------------------------ scalars
@@ -631,10 +633,10 @@ __device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32
     sync();
 }
 
-// Wave version (T <= 512, packed into u32 with JB = 9): the head of an entry's run comes
+// Wave version (T <= 2^JB, packed into u32): the head of an entry's run comes
 // from a ballot of run starts in its 64-chunk (carried across chunks), and the single
 // binary search is confined to [head, j].
-template <class KeyT>
+template <class KeyT, int JB = 9>
 __device__ __forceinline__ void sweep_targets_wave(const KeyT* buf, u32* H, u32 T, u32 numWindows, u32 wb, u32 lane) {
     const KeyT winmask = (((KeyT)1) << wb) - 1;
     for (u32 j = lane; j < T; j += 64) H[j] = 0;
@@ -652,7 +654,7 @@ __device__ __forceinline__ void sweep_targets_wave(const KeyT* buf, u32* H, u32 
         const KeyT lowkey = (key & ~winmask) | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
         u32 lo = myhead, hi = valid ? j : myhead;
         while (lo < hi) { u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
-        if (valid) atomicMax(&H[myhead], ((j - lo + 1) << 9) | (511u - j));
+        if (valid) atomicMax(&H[myhead], ((j - lo + 1) << JB) | (((1u << JB) - 1) - j));
         carry_head = bcast(myhead, 63);
     }
     wave_sync();

@@ -218,6 +218,7 @@ __global__ void k_scan_add(u64* out, u64 n, const u64* tile_off) {
 }
 
 // ------------------------------------------------------------------ kernel: wave per query
+#define MCQ_LCAP_WAVE16 1024    // longest match list of the second wave stage (16 keys per lane)
 __device__ __forceinline__ u32 pow2ceil(u32 x) { return x <= 1 ? 1u : 1u << (32 - __builtin_clz(x - 1)); }
 
 template <class KeyT> __device__ __forceinline__ KeyT key_pad() { return ~(KeyT)0; }
@@ -480,7 +481,13 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
             if (T > (u32)LCAP) ovf = true;
         }
         if (ovf) {
-            if (lane == 0) { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
+            // two queues in one array: 32-bit keys and 513..1024 locations from the back (k_query_wave16: still one
+            // wave per query), everything else from the front (k_query_block)
+            if (lane == 0) {
+                if (sizeof(KeyT) == 4 && !g.ovf && T <= (u32)MCQ_LCAP_WAVE16 && !(force_block & 4)) {
+                    u32 i = atomicAdd(&ctr->ovf_mid_count, 1u); ovf_list[b.nq - 1 - i] = (u32)q;
+                } else { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
+            }
             continue;
         }
         st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
@@ -535,6 +542,61 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
         if (stop == 5) { if (hits[lane] == 0x12345u) out.ncand[q] = 1; continue; }
         st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        wave_sync();
+    }
+    if (lane == 0 && (st_feat | st_loc)) {
+        atomicAdd(&ctr->n_features, st_feat);
+        atomicAdd(&ctr->n_hit_features, st_hit);
+        atomicAdd(&ctr->n_locations, st_loc);
+        atomicAdd(&ctr->n_cands, st_cand);
+    }
+}
+
+// ------------------------------------------------------------------ kernel: wave per query, 16 keys per lane
+// Second stage of the wave path for the queries k_query_wave queued from the back of ovf_list: at most 64 features
+// and 513..1024 locations (paired reads on a large table).  Same steps, one wave per query: sketch and probe again
+// (cheap beside the rest), gather into 16 registers per lane, register sort of the raw list, sweep and top lists
+// with a 10-bit entry index.  8 KB of LDS per wave, so five waves per SIMD.  Per query this issues a fraction of
+// the instructions of a 1024-thread workgroup, whose barrier phases leave most of its waves idle at this size.
+#ifndef MCQ_WAVE16_OCC
+#define MCQ_WAVE16_OCC 5
+#endif
+__global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, BatchDev b, OptDev opt, OutDev out,
+                                                                      CountersDev* ctr, u32* ovf_list) {
+    constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
+    __shared__ u32 s_buf[4][LCAP];
+    __shared__ u32 s_hits[4][LCAP];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32* buf = s_buf[wave];
+    u32* hits = s_hits[wave];
+    u32* sk_tmp = hits;
+    u32* feat = hits + 64;
+    const u32 nwaves = gridDim.x * 4;
+    const u32 n_mid = ctr->ovf_mid_count;
+    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
+    for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
+        const u64 q = ovf_list[b.nq - 1 - it];
+        const ReadGeom g = read_geom(db, b, q, 0);
+        u32 nfeat = 0;
+        for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
+            u64 at; u32 wl;
+            window_span(db, g, w, at, wl);
+            nfeat += wave_sketch(b.bases + at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
+        }
+        const u32 myf = lane < nfeat ? feat[lane] : MCQ_EMPTY;
+        u64 off = 0; u32 len = 0;
+        probe(db, myf, off, len);
+        const u32 incl = wave_incl_scan_dpp(len);
+        const u32 pos = incl - len;
+        const u32 T = bcast(incl, 63);                 // 513..1024: the first stage saw the same table
+        st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
+        wave_sync();                                   // feat[] (aliasing hits) has been consumed
+        const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
+        gather_sort_store<u32, 16>(db, buf, hits, T, pos, len, off, lane, 0);
+        wave_sync();
+        sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
+        st_cand += topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
     }
     if (lane == 0 && (st_feat | st_loc)) {
@@ -1373,6 +1435,8 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     if (db->d.compact) hipLaunchKernelGGL((k_query_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
     else               hipLaunchKernelGGL((k_query_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
     if (ws->timing) { HIPCHK(hipEventRecord(e1, st)); ws->ev_used->emplace_back(e0, e1); }
+    if (db->d.compact)     // second wave stage (back queue); no queue for 64-bit keys
+        hipLaunchKernelGGL(k_query_wave16, dim3(MCQ_GRID(k_query_wave16, 256, db->device, want)), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list);
     if (db->d.compact) hipLaunchKernelGGL((k_query_block<u32, kLcapBlock, 1024>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
                                           (const u32*)ws->ovf_list, ws->sc, dbg);
     else               hipLaunchKernelGGL((k_query_block<u64, kLcapBlock, 1024>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
@@ -1412,7 +1476,7 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     if (!dev_out) { o.cands = ws->d_cands; o.ncand = ws->d_ncand; }
     else { o.cands = (u32*)out->cands; o.ncand = out->n_cand; }
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
-    rc = launch_query(db, ws, b, od, o, st, ((opt->flags & MCQ_FORCE_BLOCK_PATH) ? 1 : 0) | ((opt->flags & MCQ_FORCE_RAW_SORT) ? 2 : 0) | (int)((opt->flags >> 12) & 0xFu) << 4, dbg);
+    rc = launch_query(db, ws, b, od, o, st, ((opt->flags & MCQ_FORCE_BLOCK_PATH) ? 1 : 0) | ((opt->flags & MCQ_FORCE_RAW_SORT) ? 2 : 0) | ((opt->flags & MCQ_NO_WAVE16) ? 4 : 0) | (int)((opt->flags >> 12) & 0xFu) << 4, dbg);
     if (rc) return rc;
     if (!dev_out && nq) {
         HIPCHK(hipMemcpyAsync(out->cands, ws->d_cands, nq * od.max_cand * 16, hipMemcpyDeviceToHost, st));
@@ -1432,7 +1496,7 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
         stats->n_queries = ws->last_nq;
         stats->n_features = ws->ctr_host->n_features; stats->n_hit_features = ws->ctr_host->n_hit_features;
         stats->n_locations = ws->ctr_host->n_locations; stats->n_cands = ws->ctr_host->n_cands;
-        stats->n_overflow = ws->ctr_host->ovf_count;
+        stats->n_overflow = ws->ctr_host->ovf_count + ws->ctr_host->ovf_mid_count;
     }
     if (ws->ctr_host->err_count)
         return fail(MCQ_E_CAPACITY, std::to_string(ws->ctr_host->err_count) + " queries exceeded the workspace's per-query capacity");

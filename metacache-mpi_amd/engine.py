@@ -17,6 +17,7 @@ MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-qu
 MCQ_DB_LOCS_64 = 0x200           # Database(flags=...): keep 64-bit locations
 MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000   # Table / Database.build: -remove-overpopulated-features
 MCQ_FORCE_RAW_SORT = 0x400       # debug: wave path without the de-duplicating pass
+MCQ_NO_WAVE16 = 0x800            # debug: 513..1024 locations take the workgroup path, not the second wave stage
 
 MCQ_OK, MCQ_E_ARG, MCQ_E_HIP, MCQ_E_CAPACITY, MCQ_E_UNSUPPORTED = 0, -1, -2, -3, -4
 

@@ -159,7 +159,7 @@ def test_many_strains_cross_every_list_size_boundary():
     for flags in (0, eng.MCQ_DB_LOCS_64):
         db = dbbuild.make_database(keys, off, locs, species, flags=flags)
         ws = eng.Workspace(db, n, n * L)
-        for qf in (0, eng.MCQ_FORCE_RAW_SORT):
+        for qf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16):
             cands, ncand = ws.query_host(rb, ro, False, max_cand=4, emulate_ranks=2, flags=qf)
             _compare(cands, ncand, oc, on, "many strains flags=%x qf=%x" % (flags, qf))
         s = ws.sync()
@@ -173,14 +173,15 @@ def test_crafted_lists_cross_the_distinct_key_limits():
     """A table made by hand: the features of random reads get lists of mostly distinct random (target, window)
     locations whose length depends on the read, so the fused kernel sees 60..512 locations with about as many
     distinct keys -- one, two and four sort registers, more than 256 distinct keys (the attempt fails, the raw list is
-    sorted), lists the wave then sends to the raw sort without trying, and some past 512 for the workgroup kernel."""
+    sorted), lists the wave then sends to the raw sort without trying, 513..1024 locations for the second wave stage
+    (16 keys per lane; MCQ_NO_WAVE16 sends them to the workgroups instead) and longer ones for the workgroup kernel."""
     eng = importlib.import_module("metacache-mpi_amd.engine")
     rng = np.random.default_rng(21)
     n, L, n_tgt = 6000, 150, 3000
     seqs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(n)]
     feat_len = {}
     for i, sq in enumerate(seqs):
-        per = int(rng.integers(2, 19))                       # 32 features x 2..18 locations
+        per = int(rng.integers(2, 19)) if i % 40 else int(rng.integers(20, 80))    # 32 features x 2..18 locations; a few x 20..79
         for w0, w1 in orc.windows(L):
             for f in orc.sketch(sq[w0:w1].encode()):
                 feat_len.setdefault(int(f), per)
@@ -200,7 +201,7 @@ def test_crafted_lists_cross_the_distinct_key_limits():
         ws = eng.Workspace(db, n, n * L)
         for P, M in ((2, 2), (4, 4), (1, 3)):
             oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, threads=8)
-            for qf in (0, eng.MCQ_FORCE_RAW_SORT):
+            for qf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16):
                 cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P, flags=qf)
                 _compare(cands, ncand, oc, on, "crafted lists flags=%x P=%d M=%d qf=%x" % (flags, P, M, qf))
         s = ws.sync()
@@ -210,5 +211,6 @@ def test_crafted_lists_cross_the_distinct_key_limits():
         D = np.array([len(np.unique(m[a:a + t])) for a, t in zip(starts, T)])
         for lo, hi in ((1, 64), (65, 128), (129, 256)):
             assert ((D >= lo) & (D <= hi) & (T <= 512)).any(), (lo, hi)
-        assert ((D > 256) & (T <= 512)).sum() > 500 and (T > 512).any(), (np.percentile(T, [1, 50, 99]), np.percentile(D, [1, 50, 99]))
+        assert ((D > 256) & (T <= 512)).sum() > 500, (np.percentile(T, [1, 50, 99]), np.percentile(D, [1, 50, 99]))
+        assert ((T > 512) & (T <= 1024)).sum() > 50 and (T > 1024).sum() > 50, np.percentile(T, [50, 90, 99, 100])
         assert 0 < s["n_overflow"] < n
