@@ -1,19 +1,20 @@
 // mcq_engine.hip -- kernels + C ABI of the MI355X query-path engine (see include/mcq.h).
 //
-// Two kernels carry the whole per-query path (rows 1-11 of SURVEY.md 8a):
+// Three kernels carry the whole per-query path (rows 1-11 of SURVEY.md 8a):
 //
-//   k_query_wave   one wavefront per query.  Sketch (<= 4 windows), 64 parallel table
-//                  probes, list gather into the wave's LDS segment, in-LDS bitonic
-//                  sort, per-target window sweep, lane-resident top lists + tree fold.
-//                  HBM traffic = the algorithmic bytes: read bases, one 16-B slot per
-//                  probe, the location lists once, the candidates out.
-//   k_query_block  one 1024-thread workgroup per query that does not fit a wave's
-//                  budget (long reads with many windows, or > LCAP locations): same
-//                  steps with workgroup barriers, LDS up to 8192 locations, global
-//                  scratch beyond.
+//   k_query_wave    one wavefront per query.  Sketch (<= 4 windows), 64 parallel table
+//                   probes, list gather into registers, distinct-key counting in the
+//                   wave's LDS segment, register sort, per-target window sweep, top
+//                   lists + tree fold.  HBM traffic = the algorithmic bytes: read bases,
+//                   one 16-B slot per probe, the location lists once, the candidates out.
+//   k_query_wave16  second wave stage: queries of 513..1024 locations (32-bit keys),
+//                   16 keys per lane.
+//   k_query_block   one 1024-thread workgroup per query that fits neither (long reads
+//                   with many windows, longer lists): same steps with workgroup
+//                   barriers, LDS up to 8192 locations, global scratch beyond.
 //
-// Queries that overflow the wave budget are queued through a device counter; the block
-// kernel drains the queue, so no host round trip sits inside a batch.
+// Queries that overflow the first stage are queued through device counters (two queues in
+// one array); the other kernels drain them, so no host round trip sits inside a batch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
