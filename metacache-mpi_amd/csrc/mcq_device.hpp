@@ -60,7 +60,7 @@ struct OptDev {
     u32 P;                   // emulate_ranks
     u32 seg;                 // lanes per virtual-rank list = 64 / pow2ceil(P)
     u32 quirk_seq_drop;
-    u32 raw_sort;            // test hook: no de-duplicating pass (staged reduce kernel)
+    u32 hooks;               // test hooks of the staged reduce kernel: 1 = no de-duplicating pass, 2 = no second wave stage
     u64 insert_size_max;
     u32 n_fold;              // fold schedule: (snd -> rcv) in the reference's order
     u32 n_levels;            // rounds of the tree; the edges of one round touch disjoint ranks

@@ -485,7 +485,11 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
             // two queues in one array: 32-bit keys and 513..1024 locations from the back (k_query_wave16: still one
             // wave per query), everything else from the front (k_query_block)
             if (lane == 0) {
+#ifdef MCQ_NO_WAVE16_ROUTE                             // tuning knob (A/B): one queue, as before the second wave stage
+                if (false) {
+#else
                 if (sizeof(KeyT) == 4 && !g.ovf && T <= (u32)MCQ_LCAP_WAVE16 && !(force_block & 4)) {
+#endif
                     u32 i = atomicAdd(&ctr->ovf_mid_count, 1u); ovf_list[b.nq - 1 - i] = (u32)q;
                 } else { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
             }
@@ -917,8 +921,12 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
     unsigned long long st_loc = 0, st_cand = 0;
     for (u64 q = (u64)blockIdx.x * 4 + wave; q < nq; q += nwaves) {
         const u64 b0 = loc_off[q], T64 = loc_off[q + 1] - b0;
-        if (T64 > (u64)LCAP) {
-            if (lane == 0) { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
+        if (T64 > (u64)LCAP) {                  // the same two queues as in k_query_wave
+            if (lane == 0) {
+                if (sizeof(KeyT) == 4 && T64 <= (u64)MCQ_LCAP_WAVE16 && !(opt.hooks & 2)) {
+                    u32 i = atomicAdd(&ctr->ovf_mid_count, 1u); ovf_list[nq - 1 - i] = (u32)q;
+                } else { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
+            }
             continue;
         }
         const u32 T = (u32)T64;
@@ -926,7 +934,7 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         if constexpr (sizeof(KeyT) == 4) {
-            if (T <= MCQ_DEDUP_MAX_T && !opt.raw_sort) {
+            if (T <= MCQ_DEDUP_MAX_T && !(opt.hooks & 1)) {
                 const u32* src = locs + b0;
                 u32 D, k1, incl1;
                 if (T <= 64)       D = load_dedup_insert<1>(src, buf, hits, T, lane);
@@ -953,6 +961,34 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         wave_sync();
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
         st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        wave_sync();
+    }
+    if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
+}
+
+// second wave stage of the staged path (see k_query_wave16): 513..1024 locations, 16 keys per lane
+__global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
+                                                                       u64 nq, const u64* loc_off, const u32* locs, const u32* query_len) {
+    constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
+    __shared__ u32 s_buf[4][LCAP];
+    __shared__ u32 s_hits[4][LCAP];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32* buf = s_buf[wave];
+    u32* hits = s_hits[wave];
+    const u32 nwaves = gridDim.x * 4;
+    const u32 n_mid = ctr->ovf_mid_count;
+    unsigned long long st_loc = 0, st_cand = 0;
+    for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
+        const u64 q = ovf_list[nq - 1 - it];
+        const u64 b0 = loc_off[q];
+        const u32 T = (u32)(loc_off[q + 1] - b0);
+        st_loc += T;
+        const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
+        load_sort_store<u32, 16>(buf, locs + b0, T, lane);
+        wave_sync();
+        sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
+        st_cand += topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
     }
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
@@ -1230,7 +1266,7 @@ static int make_opt(const mcq_query_opts* o, OptDev& d) {
     memset(&d, 0, sizeof(d));
     d.max_cand = o->max_cand; d.P = P; d.seg = seg;
     d.quirk_seq_drop = (o->flags & MCQ_QUIRK_SEQ_DROP) ? 1 : 0;
-    d.raw_sort = (o->flags & MCQ_FORCE_RAW_SORT) ? 1 : 0;
+    d.hooks = ((o->flags & MCQ_FORCE_RAW_SORT) ? 1u : 0u) | ((o->flags & MCQ_NO_WAVE16) ? 2u : 0u);
     d.insert_size_max = o->insert_size_max;
     std::vector<std::pair<u32, u32>> sched;
     std::vector<u32> level_end;
@@ -1657,6 +1693,8 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     if (db->d.compact) {
         hipLaunchKernelGGL((k_reduce_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
                            n_queries, loc_off, (const u32*)locs, query_len);
+        hipLaunchKernelGGL(k_reduce_wave16, dim3(MCQ_GRID(k_reduce_wave16, 256, db->device, (n_queries + 3) / 4)), dim3(256), 0, st, db->d, od, o, ws->ctr,
+                           (const u32*)ws->ovf_list, n_queries, loc_off, (const u32*)locs, query_len);
         hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
                            (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len);
     } else {
