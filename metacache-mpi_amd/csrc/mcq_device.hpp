@@ -549,8 +549,8 @@ __device__ __forceinline__ void wave_regsort(KeyT (&r)[E], u32 lane) { regsort_l
 // ---- workgroup bitonic sort with the wave-local stages in registers --------------------------------
 // All stages at distance j <= 64 stay inside a 128-element chunk, so a wave takes them for its chunks in
 // registers (2 keys per lane) without workgroup barriers: levels k <= 128 are a full 128-key register sort
-// (descending chunks: complemented keys), and of every later level only the stages j >= 128 go through
-// LDS with a barrier each.  n = 4096: 21 barriers instead of 78.
+// and of every later level only the stages j >= 128 go through LDS with a barrier each.  n = 4096: 21 barriers
+// instead of 78.
 template <class KeyT, int J>
 __device__ __forceinline__ KeyT cx_dir(KeyT v, u32 lane, bool up) {
     const u64 km = up ? keepmin_mask(64, J, true) : keepmin_mask(64, J, false);
@@ -566,33 +566,47 @@ __device__ __forceinline__ void merge128(KeyT& r0, KeyT& r1, u32 lane, bool up) 
     r0 = cx_dir<KeyT, 2>(r0, lane, up);  r1 = cx_dir<KeyT, 2>(r1, lane, up);
     r0 = cx_dir<KeyT, 1>(r0, lane, up);  r1 = cx_dir<KeyT, 1>(r1, lane, up);
 }
+// "Flip" form: every comparator is ascending (the first stage of a K-block merge pairs i with its mirror
+// image in the block, the later ones i with i + j), so keys that are +infinity never move and every comparator
+// whose upper index is at or beyond the padded length can be left out: the list is padded to the next multiple
+// of 128 only (npad), not to n2p -- a 2430-entry list does 60 % of the work of the 4096 network.
 template <class KeyT, class Sync>
-__device__ __forceinline__ void bitonic_sort_block(KeyT* buf, u32 n, u32 tid, u32 G, Sync sync) {
-    if (n < 256) { bitonic_sort(buf, n, tid, G, sync); return; }
-    const u32 lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = G >> 6, nchunks = n >> 7;
+__device__ __forceinline__ void bitonic_sort_block(KeyT* buf, u32 n2p, u32 npad, u32 tid, u32 G, Sync sync) {
+    if (n2p < 256) { bitonic_sort(buf, n2p, tid, G, sync); return; }      // (then npad == n2p)
+    const u32 lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = G >> 6, nchunks = npad >> 7;
     for (u32 c = wv; c < nchunks; c += nwv) {                       // levels 2..128
         KeyT r[2] = {buf[c * 128 + lane], buf[c * 128 + 64 + lane]};
-        const bool up = (c & 1) == 0;
-        if (!up) { r[0] = ~r[0]; r[1] = ~r[1]; }
         wave_regsort<KeyT, 2>(r, lane);
-        if (!up) { r[0] = ~r[0]; r[1] = ~r[1]; }
         buf[c * 128 + lane] = r[0]; buf[c * 128 + 64 + lane] = r[1];
     }
     sync();
-    for (u32 k = 256; k <= n; k <<= 1) {
-        for (u32 j = k >> 1; j >= 128; j >>= 1) {
-            for (u32 t = tid; t < (n >> 1); t += G) {
+    for (u32 k = 256; k <= n2p; k <<= 1) {
+        {                                                           // mirror stage of the k-blocks
+            const u32 h = k >> 1, hs = (u32)__builtin_ctz(h);
+            const u32 tmax = ((npad + k - 1) >> (hs + 1)) << hs;    // blocks that hold real keys
+            for (u32 t = tid; t < tmax; t += G) {
+                const u32 blk = t >> hs, o = t & (h - 1);
+                const u32 i = (blk << (hs + 1)) + o, l = (blk << (hs + 1)) + (k - 1) - o;
+                if (l >= npad) continue;
+                const KeyT a = buf[i], b = buf[l];
+                if (a > b) { buf[i] = b; buf[l] = a; }
+            }
+            sync();
+        }
+        for (u32 j = k >> 2; j >= 128; j >>= 1) {
+            const u32 tmax = ((npad >> 1) + j - 1) & ~(j - 1);      // i >= npad from here on
+            for (u32 t = tid; t < tmax; t += G) {
                 const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const u32 l = i | j;
+                if (l >= npad) continue;
                 const KeyT a = buf[i], b = buf[l];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) { buf[i] = b; buf[l] = a; }
+                if (a > b) { buf[i] = b; buf[l] = a; }
             }
             sync();
         }
         for (u32 c = wv; c < nchunks; c += nwv) {                   // stages j = 64..1 of this level
             KeyT r0 = buf[c * 128 + lane], r1 = buf[c * 128 + 64 + lane];
-            merge128<KeyT>(r0, r1, lane, ((c * 128) & k) == 0);
+            merge128<KeyT>(r0, r1, lane, true);
             buf[c * 128 + lane] = r0; buf[c * 128 + 64 + lane] = r1;
         }
         sync();

@@ -644,10 +644,15 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
                                            KeyT* B, HT* H, u32 T, u32 numWindows, u32 wb, u64 q, u32 tid,
                                            const DebugDev& dbg, Fill fill) {
     const u32 n2p = pow2ceil(T), NTB = blockDim.x;
+#ifdef MCQ_SORT_PAD_FULL                                       // tuning knob (A/B): the whole power-of-two network
+    const u32 npad = n2p;
+#else
+    const u32 npad = n2p < 256 ? n2p : ((T + 127u) & ~127u);  // padded to whole 128-key chunks (see bitonic_sort_block)
+#endif
     fill(B);                                                   // B[0..T) = the unsorted match list
-    for (u32 t = T + tid; t < n2p; t += NTB) B[t] = key_pad<KeyT>();
+    for (u32 t = T + tid; t < npad; t += NTB) B[t] = key_pad<KeyT>();
     __syncthreads();
-    bitonic_sort_block(B, n2p, tid, NTB, [] { __syncthreads(); });
+    bitonic_sort_block(B, n2p, npad, tid, NTB, [] { __syncthreads(); });
     if (dbg.mode == 2) {
         for (u32 t = tid; t < T; t += NTB) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], wb);
     }
