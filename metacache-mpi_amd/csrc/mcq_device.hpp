@@ -619,30 +619,42 @@ __device__ __forceinline__ void bitonic_sort_block(KeyT* buf, u32 n2p, u32 npad,
 // numWindows.  Because the run is sorted, fst(lst) is simply the first entry of the run
 // with win >= win[lst]-numWindows+1, so every entry finds its own count with one binary
 // search: hits(j) = j - lower_bound(tgt, win_j - numWindows + 1) + 1.  The run's best is
-// the maximum of (hits, -j): folded with an LDS atomic max into H[first entry of the run]
-// (found by a second lower_bound that shares the loop).
+// the maximum of (hits, -j): folded with an LDS atomic max into H[first entry of the run].
 //   H[j0] = (hits << JB) | (JMASK - jbest) for run heads, 0 elsewhere.
 template <class KeyT, class HT, int JB, class Sync>
 __device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32 numWindows, u32 wb, u32 tid, u32 G,
-                                              Sync sync) {
+                                              u32* s_w /* G / 64 + 1 words of LDS */, Sync sync) {
+    // The head of an entry's run: last run start at or before it -- a ballot of run starts inside the wave, the last
+    // start of the earlier waves through s_w, of the earlier chunks through s_w[nwv] (all as index + 1, 0 = none).
+    // The lower bound is then searched inside [head, j] only: runs are a few entries long.
     const HT JMASK = ((HT)1 << JB) - 1;
     const KeyT winmask = (((KeyT)1) << wb) - 1;
+    const u32 lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = G >> 6;
     for (u32 j = tid; j < T; j += G) H[j] = 0;
+    if (tid == 0) s_w[nwv] = 0;
     sync();
-    for (u32 j = tid; j < T; j += G) {
-        const KeyT key = buf[j];
+    for (u32 base = 0; base < T; base += G) {
+        const u32 j = base + tid;
+        const bool valid = j < T;
+        const KeyT key = buf[valid ? j : T - 1];
+        const KeyT prev = buf[(valid && j > 0) ? j - 1 : 0];
+        const bool head = valid && (j == 0 || (prev >> wb) != (key >> wb));
+        const u64 hb = __ballot(head);
+        const u32 wbase = base + wv * 64;
+        const u32 mylast = hb ? wbase + (63u - (u32)__builtin_clzll(hb)) + 1 : 0u;
+        if (lane == 0) s_w[wv] = mylast;
+        sync();
+        u32 before = s_w[nwv];
+        for (u32 w = 0; w < wv; ++w) { const u32 x = s_w[w]; before = x ? x : before; }
+        const u64 le = hb & ((2ull << lane) - 1);
+        const u32 myhead = le ? wbase + (63u - (u32)__builtin_clzll(le)) : before - 1;
         const u32 win = (u32)(key & winmask);
-        const KeyT headkey = key & ~winmask;
-        const KeyT lowkey = headkey | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
-        u32 lo1 = 0, hi1 = j, lo2 = 0, hi2 = j;          // buf[j] >= both keys
-        while (lo1 < hi1 || lo2 < hi2) {
-            u32 mid1 = (lo1 + hi1) >> 1, mid2 = (lo2 + hi2) >> 1;
-            KeyT v1 = buf[mid1], v2 = buf[mid2];
-            if (lo1 < hi1) { if (v1 < lowkey) lo1 = mid1 + 1; else hi1 = mid1; }
-            if (lo2 < hi2) { if (v2 < headkey) lo2 = mid2 + 1; else hi2 = mid2; }
-        }
-        const HT packed = ((HT)(j - lo1 + 1) << JB) | (JMASK - (HT)j);
-        atomicMax(&H[lo2], packed);
+        const KeyT lowkey = (key & ~winmask) | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+        u32 lo = myhead, hi = valid ? j : myhead;
+        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
+        if (valid) atomicMax(&H[myhead], ((HT)(j - lo + 1) << JB) | (JMASK - (HT)j));
+        sync();                                                     // s_w has been read by everyone
+        if (tid == G - 1) s_w[nwv] = mylast ? mylast : before;      // last run start so far
     }
     sync();
 }

@@ -656,8 +656,8 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
     if (dbg.mode == 2) {
         for (u32 t = tid; t < T; t += NTB) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], wb);
     }
-    sweep_targets<KeyT, HT, JB>(B, H, T, numWindows, wb, tid, NTB, [] { __syncthreads(); });
     __shared__ TopkBlockScratch<HT> s_topk;
+    sweep_targets<KeyT, HT, JB>(B, H, T, numWindows, wb, tid, NTB, s_topk.fmx, [] { __syncthreads(); });
     const u32 n = topk_block<KeyT, HT, JB>(db, opt, out, B, H, T, numWindows, wb, q, tid, NTB, &s_topk, [] { __syncthreads(); });
     if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
     __syncthreads();
