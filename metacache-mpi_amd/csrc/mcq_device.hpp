@@ -968,10 +968,10 @@ __device__ __forceinline__ u32 fold_lists_write(const DbDev& db, const OptDev& o
 // round is one ds_max per candidate into the word of its rank instead of a DPP reduction per rank: all P
 // ranks advance in the same round (M rounds per 64 candidates instead of P x M), and a round costs a dozen
 // VALU instructions.  scr: 128 words of this wave's LDS segment (scr[0..64) maxima, scr[64..128) winner taxa).
+template <int JB = 9>
 __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev& opt, const OutDev& out,
                                                    const u32* buf, u32* H, u32 T, u32 numWindows, u32 wb,
                                                    u64 q, u32 lane, u32* scr) {
-    constexpr int JB = 9;
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
     const u32 JMASK = (1u << JB) - 1;

@@ -566,6 +566,19 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 #ifndef MCQ_WAVE16_OCC
 #define MCQ_WAVE16_OCC 5
 #endif
+// Top lists of the second wave stage.  The run heads are compacted to the front of the hit words; with at most 896
+// of them (distinct targets of the query) the last 128 hit words are free for the LDS maxima of
+// topk_fold_write_lds -- all virtual ranks advance in one round, which matters with several hundred heads --
+// else the DPP reductions per rank.
+__device__ __forceinline__ u32 topk16(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* buf, u32* hits,
+                                      u32 T, u32 numWindows, u64 q, u32 lane) {
+    constexpr int JB = 10;
+    u32 nheads = 0;
+    for (u32 base = 0; base < T; base += 64) nheads += (u32)__builtin_popcountll(__ballot(base + lane < T && hits[base + lane] != 0));
+    if (nheads <= (u32)MCQ_LCAP_WAVE16 - 128u)
+        return topk_fold_write_lds<JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane, hits + (MCQ_LCAP_WAVE16 - 128));
+    return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+}
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                                       CountersDev* ctr, u32* ovf_list) {
     constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
@@ -601,7 +614,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         gather_sort_store<u32, 16>(db, buf, hits, T, pos, len, off, lane, 0);
         wave_sync();
         sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
-        st_cand += topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        st_cand += topk16(db, opt, out, buf, hits, T, numWindows, q, lane);
         wave_sync();
     }
     if (lane == 0 && (st_feat | st_loc)) {
@@ -993,7 +1006,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db,
         load_sort_store<u32, 16>(buf, locs + b0, T, lane);
         wave_sync();
         sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
-        st_cand += topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        st_cand += topk16(db, opt, out, buf, hits, T, numWindows, q, lane);
         wave_sync();
     }
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
