@@ -79,8 +79,43 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     u32 ovf_count;           // queries queued for the block-per-query path
     u32 err_count;           // queries that exceeded the block path's capacity
     u32 ovf_mid_count;       // queued from the back of the same array: <= 64 features, 513..1024 locations (k_query_wave16)
-    u32 pad_;
+    u32 n_ovf;               // queries queued (the two counts above are reserved slots: a few are left empty)
 };
+
+// ---- overflow queues ---------------------------------------------------------------------------------
+// One array, two queues: the front one grows from index 0, the back one downwards from nq + MCQ_OVF_PAD - 1.  A wave
+// reserves MCQ_OVF_CHUNK slots per global atomic (with most of a batch overflowing, one atomic per query on a
+// single address cost 5 ms per 1 M reads; 8 slots: 16 would be 1 % faster there and 3 % slower with 11 % overflowing) and keeps its reservation in five words of LDS (st: next slot and slots
+// left of the front and the back queue, queries queued); when it ends it fills what is left with MCQ_EMPTY, which the
+// draining kernels skip.  The array has max_queries + MCQ_OVF_PAD entries: enough for the unused tails of 32768 waves.
+#ifndef MCQ_OVF_CHUNK
+#define MCQ_OVF_CHUNK 8u            // tuning knob: 1u = one atomic per queued query, no empty slots
+#endif
+#define MCQ_OVF_PAD (2u * MCQ_OVF_CHUNK * 32768u)
+__device__ __forceinline__ u64 ovf_slot(u64 nq, int back, u32 i) { return back ? nq + MCQ_OVF_PAD - 1 - i : (u64)i; }
+// Draining order: slot of the it-th visit.  Reservations are filled from their first slot, so the real entries sit at
+// the low positions of every chunk; a drainer striding through the slots by a multiple of its size (5120 waves, 512
+// workgroups) would see the same position every time -- some would get all the work and others only empty slots.
+// Visiting position-major (all first slots, then all second ones, ...) gives every drainer the same mix.
+__device__ __forceinline__ u32 ovf_visit(u32 it, u32 n_reserved) {
+    const u32 nch = n_reserved / MCQ_OVF_CHUNK;          // reservations
+    const u32 pos = it / nch;
+    return (it - pos * nch) * MCQ_OVF_CHUNK + pos;
+}
+__device__ __forceinline__ void ovf_init(u32* st) { st[0] = 0; st[1] = 0; st[2] = 0; st[3] = 0; st[4] = 0; }
+__device__ __forceinline__ void ovf_push(u32* st, int back, CountersDev* ctr, u32* list, u64 nq, u32 q) {   // one lane
+    u32 next = st[back], left = st[2 + back];
+    if (left == 0) { next = atomicAdd(back ? &ctr->ovf_mid_count : &ctr->ovf_count, MCQ_OVF_CHUNK); left = MCQ_OVF_CHUNK; }
+    list[ovf_slot(nq, back, next)] = q;
+    st[back] = next + 1; st[2 + back] = left - 1; st[4] += 1;
+}
+__device__ __forceinline__ void ovf_flush(u32* st, CountersDev* ctr, u32* list, u64 nq) {                    // one lane
+    for (int back = 0; back < 2; ++back) {
+        u32 next = st[back];
+        for (u32 left = st[2 + back]; left; --left, ++next) list[ovf_slot(nq, back, next)] = MCQ_EMPTY;
+    }
+    if (st[4]) atomicAdd(&ctr->n_ovf, st[4]);
+}
 
 // ------------------------------------------------------------------ scalars
 __device__ __forceinline__ u32 tmh(u32 x) {

@@ -48,7 +48,7 @@ static u32 resident_blocks(Kernel kernel, int block_size, int device) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_size, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
     if (const char* e = getenv("MCQ_WAVE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));       // tuning knob
-    return (u32)per_cu * (u32)prop.multiProcessorCount;
+    return std::min<u32>((u32)per_cu * (u32)prop.multiProcessorCount, 8192u);     // 4 x 8192 waves: what MCQ_OVF_PAD covers
 }
 #define MCQ_GRID(kernel, block, device, want) ([&]() -> u32 { static u32 cap_ = 0; static int dev_ = -1; \
     if (dev_ != (device)) { cap_ = resident_blocks((kernel), (block), (device)); dev_ = (device); } \
@@ -450,6 +450,8 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
     const int stop = force_block >> 4;              // profiling hook: 0 = run everything
+    __shared__ u32 s_ovf[4][5];                     // this wave's queue reservations (mcq_device.hpp, "overflow queues")
+    if (lane == 0) ovf_init(s_ovf[wave]);
     // The distinct-key count of a read is only known after the attempt; a failed attempt costs a gather and ~300 table
     // inserts before the raw list is gathered again.  Reads of one batch are alike, so the wave remembers the shortest
     // list that recently failed and sends lists at least that long straight to the raw sort (results are the same
@@ -490,8 +492,8 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 #else
                 if (sizeof(KeyT) == 4 && !g.ovf && T <= (u32)MCQ_LCAP_WAVE16 && !(force_block & 4)) {
 #endif
-                    u32 i = atomicAdd(&ctr->ovf_mid_count, 1u); ovf_list[b.nq - 1 - i] = (u32)q;
-                } else { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
+                    ovf_push(s_ovf[wave], 1, ctr, ovf_list, b.nq, (u32)q);
+                } else ovf_push(s_ovf[wave], 0, ctr, ovf_list, b.nq, (u32)q);
             }
             continue;
         }
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
     }
+    if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, b.nq);
     if (lane == 0 && (st_feat | st_loc)) {
         atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);
@@ -594,7 +597,9 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     const u32 n_mid = ctr->ovf_mid_count;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
-        const u64 q = ovf_list[b.nq - 1 - it];
+        const u32 q32 = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
+        if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
+        const u64 q = q32;
         const ReadGeom g = read_geom(db, b, q, 0);
         u32 nfeat = 0;
         for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
@@ -701,7 +706,9 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     u32* sk = s_hits + wave * 128;                             // per-wave sketch scratch (hit words unused yet)
 
     for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
-        const u64 q = ovf_list[it];
+        const u32 q32 = ovf_list[ovf_visit(it, n_ovf)];
+        if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation (uniform over the workgroup)
+        const u64 q = q32;
         const u64 a = b.paired ? 2 * q : q;
         u64 o0, e0, o1, e1;
         seq_bounds(b.seq_off, b.ranges, a, o0, e0);
@@ -937,13 +944,14 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
     u32* hits = s_hits[wave];
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_loc = 0, st_cand = 0;
+    __shared__ u32 s_ovf[4][5];
+    if (lane == 0) ovf_init(s_ovf[wave]);
     for (u64 q = (u64)blockIdx.x * 4 + wave; q < nq; q += nwaves) {
         const u64 b0 = loc_off[q], T64 = loc_off[q + 1] - b0;
         if (T64 > (u64)LCAP) {                  // the same two queues as in k_query_wave
             if (lane == 0) {
-                if (sizeof(KeyT) == 4 && T64 <= (u64)MCQ_LCAP_WAVE16 && !(opt.hooks & 2)) {
-                    u32 i = atomicAdd(&ctr->ovf_mid_count, 1u); ovf_list[nq - 1 - i] = (u32)q;
-                } else { u32 i = atomicAdd(&ctr->ovf_count, 1u); ovf_list[i] = (u32)q; }
+                if (sizeof(KeyT) == 4 && T64 <= (u64)MCQ_LCAP_WAVE16 && !(opt.hooks & 2)) ovf_push(s_ovf[wave], 1, ctr, ovf_list, nq, (u32)q);
+                else ovf_push(s_ovf[wave], 0, ctr, ovf_list, nq, (u32)q);
             }
             continue;
         }
@@ -981,6 +989,7 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
     }
+    if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, nq);
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
 }
 
@@ -998,7 +1007,9 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db,
     const u32 n_mid = ctr->ovf_mid_count;
     unsigned long long st_loc = 0, st_cand = 0;
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
-        const u64 q = ovf_list[nq - 1 - it];
+        const u32 q32 = ovf_list[ovf_slot(nq, 1, ovf_visit(it, n_mid))];
+        if (q32 == MCQ_EMPTY) continue;
+        const u64 q = q32;
         const u64 b0 = loc_off[q];
         const u32 T = (u32)(loc_off[q + 1] - b0);
         st_loc += T;
@@ -1023,7 +1034,9 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
     const u32 n_ovf = ctr->ovf_count;
     DebugDev dbg; dbg.mode = 0; dbg.match_cnt = nullptr; dbg.match_off = nullptr; dbg.matches = nullptr;
     for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
-        const u64 q = ovf_list[it];
+        const u32 q32 = ovf_list[ovf_visit(it, n_ovf)];
+        if (q32 == MCQ_EMPTY) continue;
+        const u64 q = q32;
         const u64 b0 = loc_off[q], T64 = loc_off[q + 1] - b0;
         if (T64 > sc.lmax) {
             if (tid == 0) { out.ncand[q] = 0; atomicAdd(&ctr->err_count, 1u); }
@@ -1435,7 +1448,7 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     const u64 nb = (u64)ws->n_block_wgs;
     HIPCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
     HIPCHK(hipHostMalloc(&ws->ctr_host, sizeof(CountersDev)));
-    HIPCHK(hipMalloc(&ws->ovf_list, std::max<u64>(1, max_queries) * 4));
+    HIPCHK(hipMalloc(&ws->ovf_list, (max_queries + (u64)MCQ_OVF_PAD) * 4));
     HIPCHK(hipMalloc(&ws->sc.feat, nb * ws->sc.fmax * 4));
     HIPCHK(hipMalloc(&ws->sc.fpos, nb * ((u64)ws->sc.fmax + 1) * 4));
     HIPCHK(hipMalloc(&ws->sc.foff, nb * ws->sc.fmax * 8));
@@ -1551,7 +1564,7 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
         stats->n_queries = ws->last_nq;
         stats->n_features = ws->ctr_host->n_features; stats->n_hit_features = ws->ctr_host->n_hit_features;
         stats->n_locations = ws->ctr_host->n_locations; stats->n_cands = ws->ctr_host->n_cands;
-        stats->n_overflow = ws->ctr_host->ovf_count + ws->ctr_host->ovf_mid_count;
+        stats->n_overflow = ws->ctr_host->n_ovf;
     }
     if (ws->ctr_host->err_count)
         return fail(MCQ_E_CAPACITY, std::to_string(ws->ctr_host->err_count) + " queries exceeded the workspace's per-query capacity");
