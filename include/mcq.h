@@ -139,7 +139,8 @@ typedef struct {
     uint64_t n_hit_features;    /* features with a non-empty list                      */
     uint64_t n_locations;       /* locations gathered                                  */
     uint64_t n_cands;           /* candidates written                                  */
-    uint64_t n_overflow;        /* queries that took the block-per-query path          */
+    uint64_t n_overflow;        /* queries that left the first wave stage (second wave
+                                   stage or block-per-query path)                      */
 } mcq_stats;
 
 /* replaces sketch_database::read -> hash_multimap::deserialize (the table build) */
