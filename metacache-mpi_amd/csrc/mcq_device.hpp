@@ -573,13 +573,51 @@ __device__ __forceinline__ void regsort_merge(KeyT (&r)[E], u32 lane) {
     regsort_stage<KeyT, E, K, J>(r, lane);
     if constexpr (J > 1) regsort_merge<KeyT, E, K, J / 2>(r, lane);
 }
+// the register-pairing stages J = J0 .. 64 of level K
+template <int E, int K, int J>
+__device__ __forceinline__ void regsort_merge_regs(u32 (&r)[E], u32 lane) {
+    regsort_stage<u32, E, K, J>(r, lane);
+    if constexpr (J > 64) regsort_merge_regs<E, K, J / 2>(r, lane);
+}
 template <class KeyT, int E, int K>
 __device__ __forceinline__ void regsort_levels(KeyT (&r)[E], u32 lane) {
     if constexpr (K > 2) regsort_levels<KeyT, E, K / 2>(r, lane);
     regsort_merge<KeyT, E, K, K / 2>(r, lane);
 }
+// 32-bit keys: levels 2..64 are wave_sort64's min/max network per register, and the lane stages of every later level
+// its ascending half-cleaners (2-3 VALU per stage instead of compare + mask + select); a register that has to come
+// out descending is complemented around them.  Stages at distance >= 64 pair registers as in the generic network.
+template <int E, int K>
+__device__ __forceinline__ void regsort_levels_u32(u32 (&r)[E], u32 lane) {
+    if constexpr (K > 128) regsort_levels_u32<E, K / 2>(r, lane);
+    if constexpr (K >= 256) regsort_merge_regs<E, K, K / 2>(r, lane);
+    else regsort_stage<u32, E, K, 64>(r, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool up = ((e * 64) & K) == 0;
+        u32 v = up ? r[e] : ~r[e];
+        v = cx_j32(v); v = cx_j16(v); v = cx_j8(v); v = cx_j4(v); v = cx_j2(v); v = cx_j1(v);
+        r[e] = up ? v : ~v;
+    }
+}
+#ifndef MCQ_REGSORT_U32_MIN_E
+#define MCQ_REGSORT_U32_MIN_E 2         // tuning knob: fewest registers per lane that take the min/max form
+#endif
 template <class KeyT, int E>
-__device__ __forceinline__ void wave_regsort(KeyT (&r)[E], u32 lane) { regsort_levels<KeyT, E, 64 * E>(r, lane); }
+__device__ __forceinline__ void wave_regsort(KeyT (&r)[E], u32 lane) {
+#ifndef MCQ_REGSORT_GENERIC     // tuning knob (A/B)
+    if constexpr (sizeof(KeyT) == 4 && E >= MCQ_REGSORT_U32_MIN_E) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            u32 v = (e & 1) ? ~r[e] : r[e];
+            v = wave_sort64(v, lane);
+            r[e] = (e & 1) ? ~v : v;
+        }
+        regsort_levels_u32<E, 64 * E>(r, lane);
+    } else
+#endif
+    regsort_levels<KeyT, E, 64 * E>(r, lane);
+}
 
 // ---- workgroup bitonic sort with the wave-local stages in registers --------------------------------
 // All stages at distance j <= 64 stay inside a 128-element chunk, so a wave takes them for its chunks in
@@ -594,6 +632,15 @@ __device__ __forceinline__ KeyT cx_dir(KeyT v, u32 lane, bool up) {
 template <class KeyT>
 __device__ __forceinline__ void merge128(KeyT& r0, KeyT& r1, u32 lane, bool up) {
     { const KeyT a = r0, b = r1; const bool sw = (a > b) == up; r0 = sw ? b : a; r1 = sw ? a : b; }
+#ifndef MCQ_REGSORT_GENERIC
+    if constexpr (sizeof(KeyT) == 4) {          // min/max half-cleaners (ascending; complemented keys for descending)
+        u32 a = up ? (u32)r0 : ~(u32)r0, b = up ? (u32)r1 : ~(u32)r1;
+        a = cx_j32(a); a = cx_j16(a); a = cx_j8(a); a = cx_j4(a); a = cx_j2(a); a = cx_j1(a);
+        b = cx_j32(b); b = cx_j16(b); b = cx_j8(b); b = cx_j4(b); b = cx_j2(b); b = cx_j1(b);
+        r0 = (KeyT)(up ? a : ~a); r1 = (KeyT)(up ? b : ~b);
+        return;
+    }
+#endif
     r0 = cx_dir<KeyT, 32>(r0, lane, up); r1 = cx_dir<KeyT, 32>(r1, lane, up);
     r0 = cx_dir<KeyT, 16>(r0, lane, up); r1 = cx_dir<KeyT, 16>(r1, lane, up);
     r0 = cx_dir<KeyT, 8>(r0, lane, up);  r1 = cx_dir<KeyT, 8>(r1, lane, up);
