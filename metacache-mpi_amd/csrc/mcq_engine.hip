@@ -432,6 +432,19 @@ __device__ __forceinline__ void window_span(const DbDev& db, const ReadGeom& g, 
     window_of32(m2 ? g.n2 : g.n1, db.winlen, db.winstride, db.magic_stride, m2 ? w - g.nw1 : w, beg, wl);
     at = (m2 ? g.o1 : g.o0) + beg;
 }
+// Top lists after a raw sort (32-bit keys).  The run heads are compacted to the front of the hit words; when they
+// leave the last 128 of the CAP hit words free, those serve the LDS maxima of topk_fold_write_lds -- all virtual ranks
+// advance in one round, which matters with several hundred heads -- else the DPP reductions per rank.
+template <int JB, int CAP>
+__device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* buf, u32* hits,
+                                          u32 T, u32 numWindows, u64 q, u32 lane) {
+    u32 nheads = 0;
+    for (u32 base = 0; base < T; base += 64) nheads += (u32)__builtin_popcountll(__ballot(base + lane < T && hits[base + lane] != 0));
+    if (nheads <= (u32)CAP - 128u)
+        return topk_fold_write_lds<JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane, hits + (CAP - 128));
+    return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+}
+
 #ifndef MCQ_WAVE_OCC
 #define MCQ_WAVE_OCC 8          // waves per SIMD the 32-bit-key kernel is compiled for (tuning knob)
 #endif
@@ -548,7 +561,8 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         if (stop == 3 || stop == 4) { if (buf[lane] == (KeyT)0x1234) out.ncand[q] = 1; continue; }
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
         if (stop == 5) { if (hits[lane] == 0x12345u) out.ncand[q] = 1; continue; }
-        st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, q, lane);
+        else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, b.nq);
@@ -569,19 +583,6 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 #ifndef MCQ_WAVE16_OCC
 #define MCQ_WAVE16_OCC 5
 #endif
-// Top lists of the second wave stage.  The run heads are compacted to the front of the hit words; with at most 896
-// of them (distinct targets of the query) the last 128 hit words are free for the LDS maxima of
-// topk_fold_write_lds -- all virtual ranks advance in one round, which matters with several hundred heads --
-// else the DPP reductions per rank.
-__device__ __forceinline__ u32 topk16(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* buf, u32* hits,
-                                      u32 T, u32 numWindows, u64 q, u32 lane) {
-    constexpr int JB = 10;
-    u32 nheads = 0;
-    for (u32 base = 0; base < T; base += 64) nheads += (u32)__builtin_popcountll(__ballot(base + lane < T && hits[base + lane] != 0));
-    if (nheads <= (u32)MCQ_LCAP_WAVE16 - 128u)
-        return topk_fold_write_lds<JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane, hits + (MCQ_LCAP_WAVE16 - 128));
-    return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
-}
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                                       CountersDev* ctr, u32* ovf_list) {
     constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         gather_sort_store<u32, 16>(db, buf, hits, T, pos, len, off, lane, 0);
         wave_sync();
         sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
-        st_cand += topk16(db, opt, out, buf, hits, T, numWindows, q, lane);
+        st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, q, lane);
         wave_sync();
     }
     if (lane == 0 && (st_feat | st_loc)) {
@@ -986,7 +987,8 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         else               load_sort_store<KeyT, 8>(buf, locs + b0, T, lane);
         wave_sync();
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
-        st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, q, lane);
+        else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
         wave_sync();
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, nq);
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db,
         load_sort_store<u32, 16>(buf, locs + b0, T, lane);
         wave_sync();
         sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
-        st_cand += topk16(db, opt, out, buf, hits, T, numWindows, q, lane);
+        st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, q, lane);
         wave_sync();
     }
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
