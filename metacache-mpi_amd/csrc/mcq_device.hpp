@@ -1107,6 +1107,56 @@ __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev
     return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, wb, q, lane, mx, wt);
 }
 
+// ---- rows 10-11, all run heads at once (raw-sort paths: several hundred heads) -------------------------
+// The compacted heads H[0..nheads), nheads <= 64 * NC, sit in registers (packed word with the virtual rank in bits 26+,
+// taxon key), so the selection needs M rounds in all instead of M per 64 heads: per round one ds_max per live candidate
+// into the word of its rank, the winners publish their taxa, every candidate of a winning taxon retires.  The
+// closed form is the same (first M distinct taxa by hits descending, position ascending); the taxon keys of all
+// heads are loaded in one go.  scr: 128 words of LDS.
+template <int JB, int NC>
+__device__ __forceinline__ u32 topk_all_lds(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* buf,
+                                            const u32* H, u32 nheads, u32 numWindows, u32 wb, u64 q, u32 lane, u32* scr) {
+    static_assert(JB <= 10, "hits << JB stays below bit 26");
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    const bool p2 = (P & (P - 1)) == 0;
+    const u32 JMASK = (1u << JB) - 1, VMASK = (1u << 26) - 1;
+    u32* mx = scr; u32* wt = scr + 64;
+    u32 cv[NC], ctax[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        cv[c] = 0; ctax[c] = MCQ_EMPTY;
+        if ((u32)(c * 64) >= nheads) continue;               // wave-uniform
+        const u32 k = c * 64 + lane;
+        const u32 v = (k < nheads) ? H[k] : 0;
+        const u32 tgt = buf[v ? JMASK - (v & JMASK) : 0] >> wb;
+        if (v != 0 && tgt < db.n_targets) ctax[c] = db.tgt2tax[tgt];
+        const u32 cr = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+        cv[c] = v | (cr << 26);
+        if (v == 0) cv[c] = 0;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) if (ctax[c] == MCQ_EMPTY) cv[c] = 0;
+    const u32 rl = lane / seg, li = lane - rl * seg;
+    const bool lslot = (li < M) && (rl < P);
+    u32 Ltax = MCQ_EMPTY, Lhv = 0;
+    for (u32 i = 0; i < M; ++i) {
+        mx[lane] = 0;
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (cv[c] != 0) atomicMax(&mx[cv[c] >> 26], cv[c]);
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (cv[c] != 0 && cv[c] == mx[cv[c] >> 26]) wt[cv[c] >> 26] = ctax[c];   // packed words are unique
+        wave_sync();
+        const u32 ml = mx[rl], wtl = wt[rl];
+        if (lslot && li == i && ml != 0) { Ltax = wtl; Lhv = ml & VMASK; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (cv[c] != 0 && ctax[c] == wt[cv[c] >> 26]) cv[c] = 0;
+        wave_sync();
+    }
+    return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, wb, q, lane, mx, wt);
+}
+
 // ---- rows 10-11 for the workgroup kernels ----------------------------------------------------------
 // After the sweep H[j] != 0 marks the head of a target's run and holds its packed best.  All threads offer
 // their heads to the list of the head's virtual rank (ds_max per rank; all ranks in the same round, M rounds,

@@ -433,16 +433,29 @@ __device__ __forceinline__ void window_span(const DbDev& db, const ReadGeom& g, 
     at = (m2 ? g.o1 : g.o0) + beg;
 }
 // Top lists after a raw sort (32-bit keys).  The run heads are compacted to the front of the hit words; when they
-// leave the last 128 of the CAP hit words free, those serve the LDS maxima of topk_fold_write_lds -- all virtual ranks
-// advance in one round, which matters with several hundred heads -- else the DPP reductions per rank.
+// leave the last 128 of the CAP hit words free, those serve the LDS maxima of topk_all_lds (up to CAP / 2 heads at
+// once, all virtual ranks in the same round) or topk_fold_write_lds (64 heads at a time), else the DPP reductions per
+// rank and 64 heads.
 template <int JB, int CAP>
 __device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* buf, u32* hits,
                                           u32 T, u32 numWindows, u64 q, u32 lane) {
     u32 nheads = 0;
-    for (u32 base = 0; base < T; base += 64) nheads += (u32)__builtin_popcountll(__ballot(base + lane < T && hits[base + lane] != 0));
+    for (u32 base = 0; base < T; base += 64) {                      // in place: writes trail reads
+        const u32 j = base + lane;
+        const u32 hv = (j < T) ? hits[j] : 0;
+        const u64 hm = __ballot(hv != 0);
+        if (hv != 0) hits[nheads + lane_rank(hm)] = hv;
+        nheads += (u32)__builtin_popcountll(hm);
+    }
+    wave_sync();
+#ifndef MCQ_TOPK_CHUNKED                                            // tuning knob (A/B): M rounds per 64 heads only
+    constexpr int NC = CAP / 128;                                   // register budget: 2 words per 64 heads
+    if (nheads <= 64u * NC)
+        return topk_all_lds<JB, NC>(db, opt, out, buf, hits, nheads, numWindows, db.wb, q, lane, hits + (CAP - 128));
+#endif
     if (nheads <= (u32)CAP - 128u)
-        return topk_fold_write_lds<JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane, hits + (CAP - 128));
-    return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        return topk_fold_write_lds<JB>(db, opt, out, buf, hits, nheads, numWindows, db.wb, q, lane, hits + (CAP - 128));
+    return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, nheads, numWindows, db.wb, q, lane);
 }
 
 #ifndef MCQ_WAVE_OCC
