@@ -289,8 +289,27 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 #ifdef MCQ_TOPK_DPP        // tuning knob: DPP reductions per rank instead of LDS maxima for all ranks at once
 #define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write<u32, u32, 9>(db, opt, out, sk, h, D, nw, wb, q, lane)
 #else
-#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write_lds(db, opt, out, sk, h, D, nw, wb, q, lane, (h) + 256)
+#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_dedup(db, opt, out, sk, h, D, nw, wb, q, lane)
 #endif
+// top lists of the dedup path: more than 64 distinct keys (two to four rounds of 64 run heads) take all heads at once
+__device__ __forceinline__ u32 topk_dedup(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* sk, u32* H, u32 D,
+                                          u32 numWindows, u32 wb, u64 q, u32 lane) {
+#ifndef MCQ_TOPK_DEDUP_CHUNKED                                      // tuning knob (A/B)
+    if (D > 64) {
+        u32 nheads = 0;
+        for (u32 base = 0; base < D; base += 64) {                  // in place: writes trail reads
+            const u32 j = base + lane;
+            const u32 hv = (j < D) ? H[j] : 0;
+            const u64 hm = __ballot(hv != 0);
+            if (hv != 0) H[nheads + lane_rank(hm)] = hv;
+            nheads += (u32)__builtin_popcountll(hm);
+        }
+        wave_sync();
+        return topk_all_lds<9, 4>(db, opt, out, sk, H, nheads, numWindows, wb, q, lane, H + 256);
+    }
+#endif
+    return topk_fold_write_lds(db, opt, out, sk, H, D, numWindows, wb, q, lane, H + 256);
+}
 __device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 23; }
 __device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 256; }
 __device__ __forceinline__ u32* dedup_wp(u32* hits) { return hits; }
