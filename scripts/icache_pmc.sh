@@ -1,7 +1,7 @@
 #!/bin/bash
-# instruction-cache and issue-stall counters of the fused kernel (pipelined and serial variants)
+# instruction-cache and issue-stall counters of the fused kernel (values per read, summed over SEs)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for v in 0 0x800; do
+for v in 0; do
  for set in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_IFETCH SQ_IFETCH_LEVEL"; do
   rm -rf gpurun_out/ic_tmp
   rocprofv3 --kernel-trace --pmc $set --kernel-include-regex "k_query_wave" --output-format csv -d gpurun_out/ic_tmp -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --query-flags $v > gpurun_out/ic.log 2>&1
