@@ -256,6 +256,39 @@ __device__ __forceinline__ void gather_regs(const DbDev& db, KeyT (&r)[E], u32 T
     }
     wave_sync();                                         // mark[] is the caller's again
 }
+// The same for up to 128 lists, two per lane (list l of the lane's first feature, list 64 + l of its second):
+// the marks run to 128, and the list's start comes out of the first or the second register set.
+template <int E>
+__device__ __forceinline__ void gather_regs2(const DbDev& db, u32 (&r)[E], u32 T, u32 pos0, u32 len0, u64 off0,
+                                             u32 pos1, u32 len1, u64 off1, bool two, u32 lane, u32* mark) {
+    const u32* __restrict__ locs = static_cast<const u32*>(db.locs);
+#pragma unroll
+    for (int e = 0; e < E; ++e) mark[e * 64 + lane] = 0;
+    wave_sync();
+    if (len0 > 0) mark[pos0] = lane + 1;
+    if (len1 > 0) mark[pos1] = lane + 65;
+    wave_sync();
+    u32 carry = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 t = e * 64 + lane;
+        if (e > 0 && (u32)(e * 64) >= T) { r[e] = MCQ_EMPTY; continue; }      // wave-uniform: nothing up here
+        u32 v = wave_incl_max_dpp(mark[t]);
+        v = v > carry ? v : carry;
+        carry = bcast(v, 63);
+        const u32 j = v - 1;                             // v >= 1: the first list starts at slot 0
+        u32 pj = __shfl(pos0, (int)(j & 63), 64);
+        u32 olo = __shfl((u32)off0, (int)(j & 63), 64), ohi = __shfl((u32)(off0 >> 32), (int)(j & 63), 64);
+        if (two) {                                       // wave-uniform
+            const u32 pj1 = __shfl(pos1, (int)(j & 63), 64);
+            const u32 olo1 = __shfl((u32)off1, (int)(j & 63), 64), ohi1 = __shfl((u32)(off1 >> 32), (int)(j & 63), 64);
+            if (j >= 64) { pj = pj1; olo = olo1; ohi = ohi1; }
+        }
+        r[e] = MCQ_EMPTY;
+        if (t < T) r[e] = locs[(((u64)ohi << 32) | olo) + (t - pj)];
+    }
+    wave_sync();                                         // mark[] is the caller's again
+}
 // ... sort them there and leave the sorted keys in the wave's LDS segment for the sweep.
 template <class KeyT, int E>
 __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u32* hits, u32 T, u32 pos, u32 len, u64 off, u32 lane, int stop) {
@@ -410,6 +443,14 @@ __device__ __forceinline__ u32 gather_dedup_insert(const DbDev& db, u32* buf, u3
     }
     return dedup_insert<E>(r, buf, hits, T, lane);
 }
+// the same with two lists per lane (second wave stage, reads of 65..128 features)
+template <int E>
+__device__ __forceinline__ u32 gather2_dedup_insert(const DbDev& db, u32* buf, u32* hits, u32 T, u32 pos0, u32 len0, u64 off0,
+                                                    u32 pos1, u32 len1, u64 off1, bool two, u32 lane) {
+    u32 r[E];
+    gather_regs2<E>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, hits);
+    return dedup_insert<E>(r, buf, hits, T, lane);
+}
 // the same for a match list that already sits in global memory (staged / sharded path)
 template <int E>
 __device__ __forceinline__ u32 load_dedup_insert(const u32* __restrict__ src, u32* buf, u32* hits, u32 T, u32 lane) {
@@ -425,7 +466,8 @@ struct ReadGeom {
     u32 n1, n2;          // their lengths
     u32 nw1, nw2;        // their window counts
     u64 qlen;            // l1 + l2
-    bool ovf;            // not for the wave path
+    bool ovf;            // not for the first wave stage
+    bool wide;           // 65..128 features (5..8 windows, e.g. 2 x 250 bp): second wave stage, two features per lane
 };
 __device__ __forceinline__ ReadGeom read_geom(const DbDev& db, const BatchDev& b, u64 q, int force_block) {
     ReadGeom g;
@@ -436,11 +478,12 @@ __device__ __forceinline__ ReadGeom read_geom(const DbDev& db, const BatchDev& b
     const u64 l1 = e0 - g.o0, l2 = e1 - g.o1;
     g.qlen = l1 + l2;
     g.ovf = (force_block & 1) || ((l1 | l2) >> 20) != 0;
-    g.n1 = (u32)l1; g.n2 = (u32)l2; g.nw1 = 0; g.nw2 = 0;
+    g.n1 = (u32)l1; g.n2 = (u32)l2; g.nw1 = 0; g.nw2 = 0; g.wide = false;
     if (!g.ovf) {
         g.nw1 = num_windows32(g.n1, db.winlen, db.winstride, db.magic_stride);
         g.nw2 = b.paired ? num_windows32(g.n2, db.winlen, db.winstride, db.magic_stride) : 0;
         g.ovf = (g.nw1 + g.nw2) * db.s > 64;
+        g.wide = g.ovf && (g.nw1 + g.nw2) * db.s <= 128;
     }
     return g;
 }
@@ -529,13 +572,13 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
             if (T > (u32)LCAP) ovf = true;
         }
         if (ovf) {
-            // two queues in one array: 32-bit keys and 513..1024 locations from the back (k_query_wave16: still one
-            // wave per query), everything else from the front (k_query_block)
+            // two queues in one array: 32-bit keys and either 513..1024 locations or 65..128 features from the back
+            // (k_query_wave16: still one wave per query), everything else from the front (k_query_block)
             if (lane == 0) {
 #ifdef MCQ_NO_WAVE16_ROUTE                             // tuning knob (A/B): one queue, as before the second wave stage
                 if (false) {
 #else
-                if (sizeof(KeyT) == 4 && !g.ovf && T <= (u32)MCQ_LCAP_WAVE16 && !(force_block & 4)) {
+                if (sizeof(KeyT) == 4 && ((!g.ovf && T <= (u32)MCQ_LCAP_WAVE16) || g.wide) && !(force_block & 4)) {
 #endif
                     ovf_push(s_ovf[wave], 1, ctr, ovf_list, b.nq, (u32)q);
                 } else ovf_push(s_ovf[wave], 0, ctr, ovf_list, b.nq, (u32)q);
@@ -610,10 +653,10 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 // Second stage of the wave path for the queries k_query_wave queued from the back of ovf_list: at most 64 features
 // and 513..1024 locations (paired reads on a large table).  Same steps, one wave per query: sketch and probe again
 // (cheap beside the rest), gather into 16 registers per lane, register sort of the raw list, sweep and top lists
-// with a 10-bit entry index.  8 KB of LDS per wave, so five waves per SIMD.  Per query this issues a fraction of
+// with a 10-bit entry index.  8 KB of LDS per wave; four waves per SIMD (128 VGPRs).  Per query this issues a fraction of
 // the instructions of a 1024-thread workgroup, whose barrier phases leave most of its waves idle at this size.
 #ifndef MCQ_WAVE16_OCC
-#define MCQ_WAVE16_OCC 5
+#define MCQ_WAVE16_OCC 4        // waves per SIMD it is compiled for: 5 fit the LDS, but then 10 VGPRs spill (+30 % time)
 #endif
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                                       CountersDev* ctr, u32* ovf_list) {
@@ -629,32 +672,72 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     const u32 nwaves = gridDim.x * 4;
     const u32 n_mid = ctr->ovf_mid_count;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
+    u32 fq_next = 0, fq_left = 0;                      // this wave's reservation in the front queue (wide reads with > 1024 locations)
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
         const u32 q32 = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
         if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
         const u64 q = q32;
         const ReadGeom g = read_geom(db, b, q, 0);
-        u32 nfeat = 0;
+        u32 nfeat = 0;                                 // <= 128: the first stage queued nothing wider
         for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
             u64 at; u32 wl;
             window_span(db, g, w, at, wl);
             nfeat += wave_sketch(b.bases + at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
         }
-        const u32 myf = lane < nfeat ? feat[lane] : MCQ_EMPTY;
-        u64 off = 0; u32 len = 0;
-        probe(db, myf, off, len);
-        const u32 incl = wave_incl_scan_dpp(len);
-        const u32 pos = incl - len;
-        const u32 T = bcast(incl, 63);                 // 513..1024: the first stage saw the same table
-        st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
+        const bool two = nfeat > 64;                   // wave-uniform
+        const u32 myf0 = lane < nfeat ? feat[lane] : MCQ_EMPTY;
+        const u32 myf1 = (two && 64 + lane < nfeat) ? feat[64 + lane] : MCQ_EMPTY;
+        u64 off0 = 0, off1 = 0; u32 len0 = 0, len1 = 0;
+        probe(db, myf0, off0, len0);
+        if (two) probe(db, myf1, off1, len1);
+        const u32 incl0 = wave_incl_scan_dpp(len0);
+        const u32 T0 = bcast(incl0, 63);
+        const u32 incl1 = wave_incl_scan_dpp(len1) + T0;
+        const u32 pos0 = incl0 - len0, pos1 = incl1 - len1;
+        const u32 T = bcast(incl1, 63);                // <= 1024 for the queries queued by their length
+        if (T > (u32)LCAP) {                           // a wide read with a longer list: on to the workgroup kernel
+            if (fq_left == 0) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&ctr->ovf_count, MCQ_OVF_CHUNK);
+                fq_next = bcast(base, 0); fq_left = MCQ_OVF_CHUNK;
+            }
+            if (lane == 0) ovf_list[fq_next] = q32;
+            ++fq_next; --fq_left;
+            continue;
+        }
+        st_feat += nfeat; st_loc += T;
+        st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
+        if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        gather_sort_store<u32, 16>(db, buf, hits, T, pos, len, off, lane, 0);
+        if (T <= MCQ_DEDUP_MAX_T) {                    // a wide read with a short list: the distinct-key tail of the first stage
+            u32 D, k1 = MCQ_EMPTY, incl1 = 0;
+            if (T <= 128)      D = gather2_dedup_insert<2>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
+            else if (T <= 256) D = gather2_dedup_insert<4>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
+            else               D = gather2_dedup_insert<8>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
+            D = dedup_finish(D, buf, hits, lane, k1, incl1);
+            if (D != ~0u) {
+                if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, buf, D, numWindows, db.wb, lane);
+                else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
+                st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), buf, D, numWindows, db.wb, q, lane);
+                wave_sync();
+                continue;
+            }
+            wave_sync();                               // more than 256 distinct keys: the raw list below
+        }
+        {
+            u32 r[16];
+            gather_regs2<16>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, hits);
+            wave_regsort<u32, 16>(r, lane);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) buf[e * 64 + lane] = r[e];
+        }
         wave_sync();
         sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
         st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, q, lane);
         wave_sync();
     }
+    if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
     if (lane == 0 && (st_feat | st_loc)) {
         atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);

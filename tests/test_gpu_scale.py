@@ -214,3 +214,27 @@ def test_crafted_lists_cross_the_distinct_key_limits():
         assert ((D > 256) & (T <= 512)).sum() > 500, (np.percentile(T, [1, 50, 99]), np.percentile(D, [1, 50, 99]))
         assert ((T > 512) & (T <= 1024)).sum() > 50 and (T > 1024).sum() > 50, np.percentile(T, [50, 90, 99, 100])
         assert 0 < s["n_overflow"] < n
+
+
+@pytest.mark.parametrize("P,M", [(1, 4), (2, 2), (4, 4)])
+def test_wide_reads_take_the_second_wave_stage(world, P, M):
+    """500 bp single-end reads (5 windows, 80 features) and 2 x 250 bp pairs (6 windows, 96 features): more than one
+    feature per lane, so the first wave stage hands them to the second one (two features per lane) -- or, with 64-bit
+    locations (P = 4 here) or MCQ_NO_WAVE16, to the workgroup kernel.  Same results as the oracle either way."""
+    eng, synth, gb, goff, dbs = world
+    db, odb = dbs[P]
+    n = 20000
+    for paired in (False, True):
+        if paired:
+            reads, off, _ = synth.sample_pairs(gb, goff, n // 2, 250, 500, 700, 0.01, 0.002, seed=31 + P)
+            nq = n // 2
+        else:
+            reads, off, _ = synth.sample_reads(gb, goff, n, 500, 0.01, 0.002, seed=41 + P)
+            nq = n
+        rb = reads.cpu().numpy().tobytes(); ro = off.cpu().numpy().astype(np.uint64)
+        oc, on = odb.query(rb, ro, paired, max_cand=M, emulate_ranks=P, threads=8)
+        ws = eng.Workspace(db, nq, len(rb))
+        for qf in (0, eng.MCQ_NO_WAVE16, eng.MCQ_FORCE_RAW_SORT):
+            cands, ncand = ws.query_host(rb, ro, paired, max_cand=M, emulate_ranks=P, flags=qf)
+            _compare(cands, ncand, oc, on, "wide reads paired=%d P=%d M=%d qf=%x" % (paired, P, M, qf))
+            assert ws.sync()["n_overflow"] == nq          # every query left the first stage
