@@ -238,3 +238,38 @@ def test_wide_reads_take_the_second_wave_stage(world, P, M):
             cands, ncand = ws.query_host(rb, ro, paired, max_cand=M, emulate_ranks=P, flags=qf)
             _compare(cands, ncand, oc, on, "wide reads paired=%d P=%d M=%d qf=%x" % (paired, P, M, qf))
             assert ws.sync()["n_overflow"] == nq          # every query left the first stage
+
+
+def test_ragged_lengths_cross_every_window_count(world):
+    """One batch with reads of 15..1100 bases, every window-count boundary included (128/129, 241/242, ... 919/920):
+    1..4 windows stay in the first wave stage, 5..8 take the second, more the workgroup kernel; single-end and as
+    pairs of unequal mates."""
+    eng, synth, gb, goff, dbs = world
+    rng = np.random.default_rng(5)
+    host = gb.cpu().numpy()
+    offs = goff.cpu().numpy()
+    lens = [15, 16, 17, 100, 127, 128, 129, 150, 240, 241, 242, 353, 354, 355, 466, 467, 468, 500, 579, 580, 581,
+            692, 693, 694, 805, 806, 807, 918, 919, 920, 921, 1000, 1100]
+    seqs = []
+    for rep in range(40):
+        for L in lens:
+            t = int(rng.integers(0, len(offs) - 1))
+            a = int(rng.integers(offs[t], offs[t + 1] - L))
+            sq = host[a:a + L].copy()
+            if rep % 7 == 3 and L > 20:
+                sq[int(rng.integers(0, L))] = ord("N")
+            seqs.append(sq.tobytes())
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    if len(seqs) % 2:
+        seqs.append(seqs[0])
+    rb, ro = orc.pack_reads(seqs)
+    for P, M in ((2, 2), (1, 4), (4, 4)):
+        db, odb = dbs[P]
+        for paired in (False, True):
+            nq = len(seqs) // 2 if paired else len(seqs)
+            oc, on = odb.query(rb, ro, paired, max_cand=M, emulate_ranks=P, threads=8)
+            ws = eng.Workspace(db, nq, len(rb))
+            for qf in (0, eng.MCQ_NO_WAVE16):
+                cands, ncand = ws.query_host(rb, ro, paired, max_cand=M, emulate_ranks=P, flags=qf)
+                _compare(cands, ncand, oc, on, "ragged lengths paired=%d P=%d M=%d qf=%x" % (paired, P, M, qf))
