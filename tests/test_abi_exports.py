@@ -43,3 +43,21 @@ def test_error_paths_without_gpu():
     L = eng.lib()
     assert L.mcq_db_create(None, None) == eng.MCQ_E_ARG
     assert b"null" in L.mcq_last_error()
+
+
+def test_flag_constants_match_the_header():
+    """the Python mirror of the flags (engine.py) must not drift from include/mcq.h"""
+    import importlib
+    import re
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "include", "mcq.h")).read()
+    vals = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"\b(MCQ_[A-Z0-9_]+)\s*=\s*(0x[0-9a-fA-F]+|-?\d+)u?", text)}
+    checked = 0
+    for name, v in vals.items():
+        if hasattr(eng, name):
+            assert getattr(eng, name) == v, (name, getattr(eng, name), v)
+            checked += 1
+    assert checked >= 8, checked
+    for name in ("MCQ_DEVICE_PTRS", "MCQ_FORCE_RAW_SORT", "MCQ_NO_WAVE16", "MCQ_DB_LOCS_64", "MCQ_BUILD_REMOVE_OVERPOPULATED"):
+        assert name in vals and hasattr(eng, name), name
