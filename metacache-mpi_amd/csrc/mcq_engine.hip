@@ -922,7 +922,8 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
                 }
             }
         };
-        if (pow2ceil(T) <= (u32)LCAPB) block_tail<KeyT, u32, 13>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, fill);
+        // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
+        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, fill);
         else                           block_tail<KeyT, u64, 32>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, fill);
     }
 }
@@ -1163,7 +1164,8 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
         if (tid == 0) atomicAdd(&ctr->n_locations, (unsigned long long)T);
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         auto fill = [&](KeyT* B) { for (u32 t = tid; t < T; t += 1024) B[t] = locs[b0 + t]; };
-        if (pow2ceil(T) <= (u32)LCAPB) block_tail<KeyT, u32, 13>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, fill);
+        // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
+        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, fill);
         else                           block_tail<KeyT, u64, 32>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, fill);
     }
 }
@@ -1545,6 +1547,11 @@ extern "C" int mcq_db_destroy(mcq_db* db) {
 
 extern "C" uint64_t mcq_db_bytes(const mcq_db* db) { return db ? db->bytes : 0; }
 
+#ifndef MCQ_BLOCK_NT            // tuning knobs: shape of the 32-bit workgroup kernel (threads, keys of LDS, workgroups)
+#define MCQ_BLOCK_NT 1024
+#define MCQ_BLOCK_LCAP 8192
+#define MCQ_BLOCK_WGS_DEFAULT 512
+#endif
 // ------------------------------------------------------------------ workspace
 extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t max_bases,
                              uint64_t max_locs_per_query, mcq_ws** out) {
@@ -1558,7 +1565,7 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     if (lmax > (1ull << 30)) return fail(MCQ_E_UNSUPPORTED, "max_locs_per_query too large");
     ws->sc.lmax = (u32)lmax;
     ws->sc.fmax = 1u << 15;
-    ws->n_block_wgs = 512;
+    ws->n_block_wgs = MCQ_BLOCK_WGS_DEFAULT;
     if (const char* e = getenv("MCQ_BLOCK_WGS")) ws->n_block_wgs = std::max(1, atoi(e));      // tuning knob                   // two resident workgroups per CU (32-bit keys: 64 KB of LDS, 64 VGPRs)
     ws->ev_used = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
     ws->ev_free = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
@@ -1622,7 +1629,7 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     if (ws->timing) { HIPCHK(hipEventRecord(e1, st)); ws->ev_used->emplace_back(e0, e1); }
     if (db->d.compact)     // second wave stage (back queue); no queue for 64-bit keys
         hipLaunchKernelGGL(k_query_wave16, dim3(MCQ_GRID(k_query_wave16, 256, db->device, want)), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list);
-    if (db->d.compact) hipLaunchKernelGGL((k_query_block<u32, kLcapBlock, 1024>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
+    if (db->d.compact) hipLaunchKernelGGL((k_query_block<u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT>), dim3(ws->n_block_wgs), dim3(MCQ_BLOCK_NT), 0, st, db->d, b, od, o, ws->ctr,
                                           (const u32*)ws->ovf_list, ws->sc, dbg);
     else               hipLaunchKernelGGL((k_query_block<u64, kLcapBlock, 1024>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
                                           (const u32*)ws->ovf_list, ws->sc, dbg);
