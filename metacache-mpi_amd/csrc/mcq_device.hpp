@@ -17,6 +17,7 @@
 //   bounded top list insert          src/candidates.h:236-285
 //   P-rank tree fold                 src/querying.h:867-1073
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -80,7 +81,15 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     u32 err_count;           // queries that exceeded the block path's capacity
     u32 ovf_mid_count;       // queued from the back of the same array: <= 64 features, 513..1024 locations (k_query_wave16)
     u32 n_ovf;               // queries queued (the two counts above are reserved slots: a few are left empty)
+    // not zeroed per call (set once per workspace): the first wave stage leaves the probe results of the queries it
+    // queues by their length here -- 64 words per back-queue slot: list offset << 16 | list length of the
+    // lane's feature -- so the second stage neither sketches nor probes them again.  (In a cache line of its own: the
+    // counters above are hammered by atomics, and a load from their line queues behind them.)
+    unsigned long long pad_[26];
+    unsigned long long* probe_buf;
 };
+static_assert(offsetof(CountersDev, probe_buf) == 256, "probe_buf sits 256 bytes into the block");
+#define MCQ_CTR_ZEROED offsetof(CountersDev, probe_buf)
 
 // ---- overflow queues ---------------------------------------------------------------------------------
 // One array, two queues: the front one grows from index 0, the back one downwards from nq + MCQ_OVF_PAD - 1.  A wave

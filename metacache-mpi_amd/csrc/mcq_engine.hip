@@ -84,7 +84,8 @@ struct mcq_ws {
     u64 max_queries, max_bases;
     CountersDev* ctr;         // device
     CountersDev* ctr_host;    // pinned
-    u32* ovf_list;            // [max_queries]
+    u32* ovf_list;            // [max_queries + MCQ_OVF_PAD]
+    unsigned long long* probe_buf;   // [(max_queries + MCQ_OVF_PAD / 2) x 64], see CountersDev
     ScratchDev sc;
     int n_block_wgs;
     // staging for host-pointer calls
@@ -583,6 +584,14 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                     ovf_push(s_ovf[wave], 1, ctr, ovf_list, b.nq, (u32)q);
                 } else ovf_push(s_ovf[wave], 0, ctr, ovf_list, b.nq, (u32)q);
             }
+#if !defined(MCQ_NO_PROBE_HANDOVER) && !defined(MCQ_NO_WAVE16_ROUTE)     // tuning knob (A/B)
+            if (sizeof(KeyT) == 4 && !g.ovf && T <= (u32)MCQ_LCAP_WAVE16 && !(force_block & 4)) {
+                wave_sync();                           // the slot lane 0 just took: next - 1 of the back queue
+                const u32 slot = s_ovf[wave][1] - 1;
+                ctr->probe_buf[(u64)slot * 64 + lane] = (off << 16) | len;
+                st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0));     // counted here, not in the second stage
+            }
+#endif
             continue;
         }
         st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
@@ -679,17 +688,26 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         const u64 q = q32;
         const ReadGeom g = read_geom(db, b, q, 0);
         u32 nfeat = 0;                                 // <= 128: the first stage queued nothing wider
-        for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
-            u64 at; u32 wl;
-            window_span(db, g, w, at, wl);
-            nfeat += wave_sketch(b.bases + at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
-        }
-        const bool two = nfeat > 64;                   // wave-uniform
-        const u32 myf0 = lane < nfeat ? feat[lane] : MCQ_EMPTY;
-        const u32 myf1 = (two && 64 + lane < nfeat) ? feat[64 + lane] : MCQ_EMPTY;
+        bool two = false;
         u64 off0 = 0, off1 = 0; u32 len0 = 0, len1 = 0;
-        probe(db, myf0, off0, len0);
-        if (two) probe(db, myf1, off1, len1);
+#ifndef MCQ_NO_PROBE_HANDOVER
+        if (!g.wide) {                                 // queued by its length: the first stage left its probe results
+            const u64 pw = ctr->probe_buf[(u64)ovf_visit(it, n_mid) * 64 + lane];
+            off0 = pw >> 16; len0 = (u32)(pw & 0xFFFFu);
+        } else
+#endif
+        {
+            for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
+                u64 at; u32 wl;
+                window_span(db, g, w, at, wl);
+                nfeat += wave_sketch(b.bases + at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
+            }
+            two = nfeat > 64;                          // wave-uniform
+            const u32 myf0 = lane < nfeat ? feat[lane] : MCQ_EMPTY;
+            const u32 myf1 = (two && 64 + lane < nfeat) ? feat[64 + lane] : MCQ_EMPTY;
+            probe(db, myf0, off0, len0);
+            if (two) probe(db, myf1, off1, len1);
+        }
         const u32 incl0 = wave_incl_scan_dpp(len0);
         const u32 T0 = bcast(incl0, 63);
         const u32 incl1 = wave_incl_scan_dpp(len1) + T0;
@@ -705,8 +723,15 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             ++fq_next; --fq_left;
             continue;
         }
-        st_feat += nfeat; st_loc += T;
-        st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
+        st_loc += T;
+#ifdef MCQ_NO_PROBE_HANDOVER
+        {
+#else
+        if (g.wide) {                                  // (the first stage counted the features of the others)
+#endif
+            st_feat += nfeat;
+            st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
+        }
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
@@ -1573,6 +1598,9 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     HIPCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
     HIPCHK(hipHostMalloc(&ws->ctr_host, sizeof(CountersDev)));
     HIPCHK(hipMalloc(&ws->ovf_list, (max_queries + (u64)MCQ_OVF_PAD) * 4));
+    HIPCHK(hipMalloc(&ws->probe_buf, (max_queries + (u64)MCQ_OVF_PAD / 2) * 64 * 8));
+    HIPCHK(hipMemset(ws->ctr, 0, sizeof(CountersDev)));
+    HIPCHK(hipMemcpy(&ws->ctr->probe_buf, &ws->probe_buf, sizeof(ws->probe_buf), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc(&ws->sc.feat, nb * ws->sc.fmax * 4));
     HIPCHK(hipMalloc(&ws->sc.fpos, nb * ((u64)ws->sc.fmax + 1) * 4));
     HIPCHK(hipMalloc(&ws->sc.foff, nb * ws->sc.fmax * 8));
@@ -1585,7 +1613,7 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
 extern "C" int mcq_ws_destroy(mcq_ws* ws) {
     if (!ws) return MCQ_OK;
     (void)hipSetDevice(ws->device);
-    (void)hipFree(ws->ctr); (void)hipHostFree(ws->ctr_host); (void)hipFree(ws->ovf_list);
+    (void)hipFree(ws->ctr); (void)hipHostFree(ws->ctr_host); (void)hipFree(ws->ovf_list); (void)hipFree(ws->probe_buf);
     (void)hipFree(ws->sc.feat); (void)hipFree(ws->sc.fpos); (void)hipFree(ws->sc.foff); (void)hipFree(ws->sc.gbuf); (void)hipFree(ws->sc.ghits);
     if (ws->d_bases) (void)hipFree(ws->d_bases);
     if (ws->d_seq_off) (void)hipFree(ws->d_seq_off);
@@ -1613,7 +1641,7 @@ static const int kLcapBlock = 8192;
 
 static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const OptDev& od, const OutDev& o,
                         hipStream_t st, int force_block, const DebugDev& dbg) {
-    HIPCHK(hipMemsetAsync(ws->ctr, 0, sizeof(CountersDev), st));
+    HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
     if (b.nq == 0) return MCQ_OK;
     u64 want = (b.nq + 3) / 4;
     const u32 grid = db->d.compact ? MCQ_GRID((k_query_wave<u32, kLcapWave>), 256, db->device, want)
@@ -1840,7 +1868,7 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     if (rc) return rc;
     HIPCHK(hipSetDevice(db->device));
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(hipMemsetAsync(ws->ctr, 0, sizeof(CountersDev), st));
+    HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
     ws->last_nq = n_queries;
     if (n_queries == 0) return MCQ_OK;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
