@@ -2,27 +2,38 @@
 """bench.py -- query reads/sec of the MI355X query-path engine on BASELINE.json's configs.
 
 One step = one pass of the hot path (sketch -> probe -> gather -> sort -> candidates ->
-fold) over one batch of synthetic reads already resident in HBM.  N=1 runs config[1]
-("1xMI355X: DB from ~500 bacterial-size genomes in HBM, 50 M synthetic 150 bp reads,
-k=16 s=16"): the default --steps x --batch covers 50 M reads.  Prints ONE JSON line.
+fold) over one batch of synthetic reads already resident in HBM.  Prints ONE JSON line.
 
-  python bench.py --gpus 1 --steps 48 --warmup 2
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  N = 1   BASELINE configs[1]: 500 synthetic genomes in HBM, 150 bp reads, fused kernel
+          (the default --steps x --batch covers the config's 50 M reads).
+  N > 1   BASELINE configs[2] shape: the feature table is hash-range-sharded over the N
+          GPUs (one process per GPU), features go to their owners and hits come back by
+          RCCL all-to-all -- that is `value`; the same reads on a replicated table
+          ("replicas only", no collective) are reported beside it as the second curve.
+          The database grows with N (--species x N species) unless --db-fixed.
+
+  python bench.py --gpus N --steps K --warmup W      (starts the N ranks itself)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (or is started as one of them)
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+KERNELS = {"fused": ("k_query_wave", "k_query_wave16", "k_query_block"),
+           "staged": ("k_reduce_wave", "k_reduce_wave16", "k_reduce_block")}
+EXIT_SHARDED_FAILED = 3        # the line is printed (replicas leg), the exit status says the sharded leg failed
+EXIT_PARITY_FAILED = 4         # GPU result differs from the CPU oracle / the fused kernel
 
 
 def parse():
@@ -32,17 +43,19 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="reads per step per GPU")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--species", type=int, default=50)
+    ap.add_argument("--species", type=int, default=50, help="species of the database (x strains genomes); at N > 1 per GPU unless --db-fixed")
     ap.add_argument("--strains", type=int, default=10)
     ap.add_argument("--genome-min", type=int, default=2_000_000)
     ap.add_argument("--genome-max", type=int, default=6_000_000)
     ap.add_argument("--divergence", type=float, default=0.02)
+    ap.add_argument("--db-fixed", action="store_true", help="N > 1: keep the N = 1 database instead of --species x N")
     ap.add_argument("--emulate-ranks", type=int, default=2, help="reference rank count whose results are reproduced")
     ap.add_argument("--max-cand", type=int, default=2)
-    ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "replicas", "sharded"],
+                    help="auto = fused kernel at N = 1, sharded (+ replicas beside it) at N > 1")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo only to rehearse N>1 on a box with one GPU")
-    ap.add_argument("--no-sharded-leg", action="store_true", help="N>1: skip the extra sharded (all-to-all) measurement")
-    ap.add_argument("--sharded-timeout", type=int, default=150, help="seconds the sharded leg may take before the run ends without it")
+    ap.add_argument("--no-replicas-leg", action="store_true", help="N>1: skip the replicated-table measurement")
+    ap.add_argument("--sharded-timeout", type=int, default=240, help="seconds the sharded leg may take before the run ends without it")
     ap.add_argument("--small", action="store_true", help="tiny DB / few reads (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -51,12 +64,26 @@ def parse():
     ap.add_argument("--long-mean", type=int, default=8000)
     ap.add_argument("--workload", default="c2", choices=["c2", "paired", "long"],
                     help="c2 = BASELINE configs[1] (150 bp single-end); paired = 2x150 bp pairs (configs[3] shape); "
-                         "long = ONT-like reads, mean 8 kb (configs[4] shape) -- the last two on the 1-GPU database")
-    ap.add_argument("--stop-stage", type=int, default=0, help="profiling: stop the fused kernel after stage 1..5 (results invalid)")
+                         "long = ONT-like reads, mean 8 kb (configs[4] shape)")
+    ap.add_argument("--stop-stage", type=int, default=0, help="profiling builds (-DMCQ_PROFILE_HOOKS): stop the fused kernel after stage 1..5 (results invalid)")
     ap.add_argument("--query-flags", type=lambda x: int(x, 0), default=0,
                     help="experiments: extra mcq_query_opts.flags (0x400 raw sort); results stay exact")
     ap.add_argument("--distinct-batches", type=int, default=0, help="0 = one per step (capped by memory)")
+    ap.add_argument("--no-pcie-leg", action="store_true")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """--gpus N without a launcher: start the N ranks as fresh child processes (torch.distributed.run) BEFORE this
+    process touches the GPU -- nothing that initialised HIP is ever replaced or re-executed.  Rank 0 prints the line
+    on the inherited stdout; the exit status is the launcher's."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def algorithmic_bytes(n_bases, st):
@@ -66,6 +93,9 @@ def algorithmic_bytes(n_bases, st):
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
+    import torch
     if a.small:
         a.species, a.strains, a.genome_min, a.genome_max = 6, 4, 150_000, 300_000
         a.batch = min(a.batch, 1 << 16)
@@ -73,6 +103,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.stderr.write("[bench] --gpus %d but WORLD_SIZE=%d: the launcher decides, n_gpus = %d\n" % (a.gpus, world, world))
     # stdout carries exactly one JSON line: libraries that print to fd 1 (RCCL's version banner at communicator
     # creation does) are sent to stderr; emit() below writes the line to the real stdout
     sys.stdout.flush()
@@ -83,6 +115,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(obj) + "\n").encode())
 
+    dist = None
     if world > 1 or a.mode == "sharded":
         import datetime
         import torch.distributed as dist
@@ -103,20 +136,21 @@ def main():
     eng = importlib.import_module("metacache-mpi_amd.engine")
     synth = importlib.import_module("metacache-mpi_amd.synth")
 
-    # N > 1: the table of this workload fits one MI355X many times over (288 GB HBM), so the reads are split and the
-    # table replicated ("replicas only", no data-path collective) -- that is the primary number.  The hash-range-sharded
-    # path with RCCL all-to-all (what a table larger than one GPU needs) is measured in the same run as a second leg
-    # (auto), or made the primary with --mode sharded.
+    # N = 1: the fused kernel on the whole table.  N > 1: the hash-range-sharded table with the all-to-all exchange is
+    # the primary number (north_star / configs[2]); "replicas only" (table replicated, reads split, no collective: what
+    # one would deploy while the table fits one 288 GB GPU) is measured in the same run as the second curve.
     mode = a.mode
     if mode == "auto":
-        mode = "single" if world == 1 else "replicas"
+        mode = "single" if world == 1 else "sharded"
     if world == 1 and mode == "replicas":
         mode = "single"
-    with_sharded_leg = (mode == "sharded") or (world > 1 and not a.no_sharded_leg)
+    with_sharded = mode == "sharded"
+    with_fused = mode != "sharded" or not a.no_replicas_leg
+    n_species = a.species * (world if (world > 1 and not a.db_fixed) else 1)
 
     # ---- database: same seeded genomes on every rank; each rank keeps its hash-range shard
     t_setup = time.time()
-    gen_bases, gen_off, species = synth.make_genomes(a.species, a.strains, a.genome_min, a.genome_max,
+    gen_bases, gen_off, species = synth.make_genomes(n_species, a.strains, a.genome_min, a.genome_max,
                                                      a.divergence, seed=3, device=dev)
     # table built on the GPU through the C ABI (mcq_build_table, csrc/mcq_build.hip)
     torch.cuda.empty_cache()            # the builder allocates with hipMalloc, outside torch's cache
@@ -132,12 +166,13 @@ def main():
                             device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr,
                                              tgt2tax=sp32.data_ptr(), n_keys=table.n_keys, n_locs=table.n_locs,
                                              n_targets=sp32.numel()))
-    # full table on every rank (fused single-GPU path / replicas); plus this rank's hash-range shard when sharding
-    db = make_db()
-    db_shard = make_db(world, rank) if with_sharded_leg else None
+    # full table (fused single-GPU path / replicas) and/or this rank's hash-range shard
+    db = make_db() if with_fused else None
+    db_shard = make_db(world, rank) if with_sharded else None
     n_keys, n_locs, n_targets = table.n_keys, table.n_locs, species.numel()
     keys, list_off, locs = (None, None, None)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stop_stage:
+    want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and (world == 1 or n_locs <= 600_000_000)
+    if want_cpu:
         keys, list_off, locs, _ = table.to_host()       # only the CPU baseline (the checker) reads these
     table.close()
     db_bp = int(gen_off[-1].item())
@@ -161,38 +196,39 @@ def main():
         else:
             r, off, _ = synth.sample_long_reads(gen_bases, gen_off, B, a.long_mean, 0.08, seed=sd)
         batches.append(r); offsets.append(off)
-    read_off = offsets[0]
+    del gen_bases
     max_bases = max(int(o[-1].item()) for o in offsets)
     nq = B // 2 if paired else B
     sharded = None
     n_win_per_batch = None
     if a.workload != "long":
         n_win_per_batch = B * (1 if L <= 128 else ((L - 128) // 113 + 1 + (1 if ((L - 128) // 113 + 1) * 113 < L else 0)))
-    if with_sharded_leg:
+    if with_sharded:
         sh = importlib.import_module("metacache-mpi_amd.sharded")
         sharded = sh.ShardedQuery(db_shard, world, rank, dev, max_queries=nq, max_bases=max_bases, read_len_hint=L)
-    ws = eng.Workspace(db, nq, max_bases)
+    ws = eng.Workspace(db, nq, max_bases) if with_fused else None
     cands = torch.zeros((nq, a.max_cand, 4), dtype=torch.int32, device=dev)
     ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
+    cands_s, ncand_s = torch.zeros_like(cands), torch.zeros_like(ncand)       # results of the sharded leg
     stream = torch.cuda.current_stream(dev).cuda_stream
     torch.cuda.synchronize(dev)
     t_setup = time.time() - t_setup
+    qflags = (((a.stop_stage & 15) << 12) if a.stop_stage else 0) | a.query_flags
 
     def step_sharded(i):
         # the next step's batch is announced so that its sketching runs on the second stream under this step's exchange
         nxt = (batches[(i + 1) % nb], offsets[(i + 1) % nb], B) if i + 1 < a.warmup + a.steps else None
-        sharded.query(batches[i % nb], offsets[i % nb], B, paired, cands, ncand, max_cand=a.max_cand,
+        sharded.query(batches[i % nb], offsets[i % nb], B, paired, cands_s, ncand_s, max_cand=a.max_cand,
                       emulate_ranks=a.emulate_ranks, n_win_hint=n_win_per_batch, next_batch=nxt)
 
     def step_fused(i):
         r, ro = batches[i % nb], offsets[i % nb]
         ws.query_device(r.data_ptr(), ro.data_ptr(), B, paired, cands.data_ptr(), ncand.data_ptr(),
-                        max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=((a.stop_stage & 15) << 12) | a.query_flags, stream=stream)
+                        max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=qflags, stream=stream)
 
     def barrier():
         torch.cuda.synchronize(dev)
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -207,23 +243,98 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            import torch.distributed as dist
             t = torch.tensor([el], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
 
-    # fused kernel on the full table: THE path at N=1; "replicas only" (reads split, no collective) at N>1
-    ws.timing(True)
-    fused_elapsed = timed(step_fused)
-    st = ws.sync()
-    kms, kn = ws.kernel_time()
-    ws.timing(False)
-    def make_line(mode, sharded_elapsed, sharded_error, sh_stats):
+    # ---- leg 1: fused kernel on the full table: THE path at N=1; "replicas only" (reads split, no collective) at N>1
+    fused_elapsed, st, kms, kn = None, None, None, 0
+    if with_fused:
+        ws.timing(True)
+        fused_elapsed = timed(step_fused)
+        st = ws.sync()
+        kms, kn = ws.kernel_times()
+        ws.timing(False)
+
+    # ---- leg 2: sharded table + all-to-all exchange
+    sharded_elapsed, sharded_error, sh_stats, sh_kms, sh_kn, sharded_ok = None, None, None, None, 0, None
+    if sharded is not None:
+        # The exchange runs on real xGMI only in the driver's multi-GPU runs.  Should a rank fail inside it and leave the
+        # others waiting in a collective, the watchdog prints the line of the leg already measured and ends every rank
+        # with a non-zero status.
+        import threading
+
+        def give_up():
+            if rank == 0 and fused_elapsed is not None:
+                emit(make_line("replicas" if world > 1 else "single", None,
+                               "watchdog: sharded leg did not finish within %d s" % a.sharded_timeout))
+            sys.stderr.write("[bench rank %d] sharded leg timed out; exiting\n" % rank); sys.stderr.flush()
+            os._exit(EXIT_SHARDED_FAILED)
+        dog = threading.Timer(a.sharded_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            sharded.be.ws.timing(True)
+            sharded_elapsed = timed(step_sharded)
+            sh_stats = sharded.last_stats()
+            sh_kms, sh_kn = sharded.be.ws.kernel_times()
+            sharded.be.ws.timing(False)
+            if with_fused:
+                # same batch through the fused kernel on the replicated table: bit-identical results expected on every rank
+                last = a.warmup + a.steps - 1
+                step_fused(last)
+                torch.cuda.synchronize(dev)
+                okn = bool(torch.equal(ncand, ncand_s))
+                m = torch.arange(a.max_cand, device=dev)[None, :] < ncand[:, None]
+                okc = bool(torch.equal(cands[m], cands_s[m]))
+                flag = torch.tensor([1 if (okn and okc) else 0], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+                if world > 1:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                sharded_ok = bool(flag.item())
+        except Exception as e:          # keep the line; the replicas leg stands
+            sharded_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+        dog.cancel()
+
+    def roofline(kind, ms3, n_batches, stats, elapsed):
+        names = KERNELS[kind]
+        algo = algorithmic_bytes(max_bases, stats)
+        per = [m / n_batches for m in ms3]
+        tot = sum(per)
+        dom = int(np.argmax(per))
+        ach = algo / (tot * 1e-3) / 1e9
+        rf = {"bound": "hbm", "kernel": names[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+              "traffic": None,
+              "kernel_ms": {names[i]: per[i] for i in range(3)}, "kernel_ms_sum": tot,
+              "kernel_note": "HIP events between the path's kernels on their stream (mcq_ws_timing), averaged over %d batches; "
+                             "achieved = algorithmic bytes per batch / SUM of the three kernels' times; `kernel` = the one with the largest share" % n_batches,
+              "algorithmic_bytes_per_launch": algo, "bytes_per_read": algo / B, "launches_timed": n_batches,
+              "per_launch": {k: stats[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow") if k in stats}}
+        if kind == "staged":
+            rf["kernel_note"] += "; the sketch / lookup / gather kernels of the sharded path are not in this sum -- see whole_step"
+            rf["whole_step"] = {"achieved": algo / (elapsed / a.steps) / 1e9, "frac": algo / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
+                                "note": "algorithmic bytes / ms_per_step (exchange included): the conservative figure for the sharded path"}
+        # HBM traffic per launch from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
+        if kind == "fused" and not a.small and n_species == 50:
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.workload)))
+                rf["traffic"] = tj["hbm_bytes_per_launch"] * B / tj["reads_per_launch"]
+                rf["traffic_source"] = "profiles/pmc_traffic_%s.json: %s" % (a.workload, tj.get("source", ""))
+                if tj.get("valu_insts_per_launch"):
+                    # second roofline: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) over the live kernel
+                    # time, against 1 instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz
+                    valu = tj["valu_insts_per_launch"] * B / tj["reads_per_launch"]
+                    peak = 1024 * 2.4e9 / 4
+                    rf["valu_issue"] = {"achieved": valu / (tot * 1e-3), "peak": peak, "unit": "wave64 VALU inst/s",
+                                        "frac": valu / (tot * 1e-3) / peak, "insts_per_read": valu / B}
+            except Exception:
+                pass
+        return rf
+
+    def make_line(mode, sharded_elapsed, sharded_error):
         if mode == "sharded" and sharded_elapsed is None:
             mode = "replicas" if world > 1 else "single"
         elapsed = sharded_elapsed if mode == "sharded" else fused_elapsed
-
         total_reads = a.steps * B * world          # paired-end: each mate counts (src/printing.cpp:626-627)
         value = total_reads / elapsed
         out = {
@@ -233,82 +344,41 @@ def main():
             "config": {
                 "workload": "%s: %d synthetic genomes (%d species x %d strains, %.1f%% divergence, %.2f Gbp) in HBM, %s per step per GPU, "
                             "k=16 s=16 w=128/113" %
-                            ({"c2": "BASELINE configs[1]", "paired": "BASELINE configs[3] shape on the 1-GPU DB",
-                              "long": "BASELINE configs[4] shape on the 1-GPU DB"}[a.workload],
-                             n_targets, a.species, a.strains, 100 * a.divergence, db_bp / 1e9,
+                            ({"c2": "BASELINE configs[1]" if world == 1 else "BASELINE configs[2] shape",
+                              "paired": "BASELINE configs[3] shape", "long": "BASELINE configs[4] shape"}[a.workload],
+                             n_targets, n_species, a.strains, 100 * a.divergence, db_bp / 1e9,
                              {"c2": "%d x %d bp single-end reads" % (B, L), "paired": "%d reads = %d pairs of 2x%d bp" % (B, B // 2, L),
                               "long": "%d ONT-like reads, mean %d bp, 8%% substitutions" % (B, a.long_mean)}[a.workload]),
-                "reads_total": total_reads, "db_keys": n_keys, "db_locations": n_locs, "db_hbm_bytes": db.bytes(),
+                "reads_total": total_reads, "db_keys": n_keys, "db_locations": n_locs,
+                "db_hbm_bytes": (db_shard if mode == "sharded" else db).bytes(),
+                "db_scaling": "fixed" if (world == 1 or a.db_fixed) else "%d species per GPU: the table grows with N, and with it the locations per read" % a.species,
                 "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "distinct_batches": nb,
                 "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
-                                "sharded": "feature table hash-range-sharded over %d GPUs, all-to-all of features and hits" % world}[mode],
+                                "sharded": "feature table hash-range-sharded over %d GPU(s), all-to-all of features and hits (RCCL)" % world}[mode],
                 "setup_s": round(t_setup, 1), "db_build_s": round(t_build, 3),
             },
         }
         if sharded_elapsed is not None:
             out["sharded_all_to_all"] = {"value": total_reads / sharded_elapsed, "unit": "reads/s", "ms_per_step": 1e3 * sharded_elapsed / a.steps,
-                                         "per_step_per_gpu": sh_stats,
-                                         "note": "same reads; feature table hash-range-sharded over %d GPU(s), features and hits exchanged by RCCL all-to-all" % world}
-        if mode == "sharded":
+                                         "per_step_per_gpu": sh_stats, "matches_fused_kernel_on_every_rank": sharded_ok,
+                                         "note": "feature table hash-range-sharded over %d GPU(s), features and hits exchanged by all-to-all" % world}
+        if fused_elapsed is not None and world > 1:
             out["replicas_only"] = {"value": total_reads / fused_elapsed, "unit": "reads/s", "ms_per_step": 1e3 * fused_elapsed / a.steps,
-                                    "note": "same reads, table replicated on every GPU, fused kernel, no collective (the table fits one GPU)"}
+                                    "note": "same reads, table replicated on every GPU, fused kernel, no collective"}
         if sharded_error:
             out["sharded_error"] = sharded_error
-        if kn > 0:
-            traffic, valu = None, None      # per launch, from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-                if a.workload == "c2" and not a.small:
-                    traffic = tj["hbm_bytes_per_launch"] * B / tj["reads_per_launch"]
-                    valu = tj["valu_insts_per_launch"] * B / tj["reads_per_launch"]
-            except Exception:
-                traffic, valu = None, None
-            algo = algorithmic_bytes(max_bases, st)
-            avg_ms = kms / kn
-            ach = algo / (avg_ms * 1e-3) / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "k_query_wave", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                               "traffic_source": "profiles/pmc_traffic.json (FETCH_SIZE+WRITE_SIZE of the committed rocprofv3 --pmc passes, uncorrected, see profiles/r01_fetch_calibration.txt)" if traffic else None,
-                               "binding_resource": "integer VALU issue (1 wave64 instr / 4 cycles / SIMD, scripts/valu_rate.hip): see valu_issue; HBM random-sector traffic is ~19% of peak",
-                               "kernel_note": "k_query_wave timed by HIP events on its stream (mcq_ws_timing); for --workload long the work is in k_query_block, timed by ms_per_step",
-                               "algorithmic_bytes_per_launch": algo, "avg_kernel_ms": avg_ms, "launches_timed": kn,
-                               "bytes_per_read": algo / B,
-                               "per_launch": {k: st[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow")}}
-            if valu:
-                # second, binding roofline: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) over the live
-                # kernel time, against 1 instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz
-                peak = 1024 * 2.4e9 / 4
-                out["roofline"]["valu_issue"] = {"achieved": valu / (avg_ms * 1e-3), "peak": peak, "unit": "wave64 VALU inst/s",
-                                                 "frac": valu / (avg_ms * 1e-3) / peak, "insts_per_read": valu / B,
-                                                 "source": "profiles/pmc_traffic.json (SQ_INSTS_VALU), kernel time live"}
-
+        if mode == "sharded" and sh_kn:
+            out["roofline"] = roofline("staged", sh_kms, sh_kn, sh_stats, sharded_elapsed)
+            if kn:
+                out["roofline"]["fused_kernel_on_replica"] = roofline("fused", kms, kn, st, fused_elapsed)
+        elif kn:
+            out["roofline"] = roofline("fused", kms, kn, st, fused_elapsed)
         return out
 
-    sharded_elapsed, sharded_error, sh_stats = None, None, None
-    if sharded is not None:
-        # The exchange runs on real xGMI only in the driver's multi-GPU runs.  Should a rank fail inside it and leave the
-        # others waiting in a collective, the watchdog prints the line of the leg already measured and ends every rank.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                emit(make_line("replicas" if world > 1 else "single", None,
-                               "watchdog: sharded leg did not finish within %d s" % a.sharded_timeout, None))
-            sys.stderr.write("[bench rank %d] sharded leg timed out; exiting\n" % rank); sys.stderr.flush()
-            os._exit(0)
-        dog = threading.Timer(a.sharded_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            sharded_elapsed = timed(step_sharded)
-            sh_stats = sharded.last_stats()
-        except Exception as e:          # keep the line; the replicas leg stands
-            sharded_error = "%s: %s" % (type(e).__name__, str(e)[:300])
-        dog.cancel()
-    out = make_line(mode, sharded_elapsed, sharded_error, sh_stats)
+    out = make_line(mode, sharded_elapsed, sharded_error)
     if a.stop_stage:
         out["INVALID_profiling_stop_stage"] = a.stop_stage
-    if world == 1 and a.workload == "c2" and not a.stop_stage and not a.small:
+    if world == 1 and mode == "single" and a.workload == "c2" and not a.stop_stage and not a.small and not a.no_pcie_leg:
         # the boundary may hand over HOST buffers: same steps with the batch copied in from pinned memory and the
         # result copied back (PCIe Gen5 x16); reported for DESIGN.md, never as `value`
         hb = [b.cpu().pin_memory() for b in batches[:4]]
@@ -326,20 +396,29 @@ def main():
         torch.cuda.synchronize(dev)
         out["pcie_inclusive"] = {"value": nsteps * B / (time.perf_counter() - t0), "unit": "reads/s",
                                  "note": "bases in from pinned host memory + candidates out per step, single stream, no overlap"}
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not a.stop_stage:
+    parity_ok = True
+    if want_cpu:
+        # the GPU buffers still hold the last timed batch's result (fused leg if it ran, else the sharded leg)
+        gc, gn = (cands, ncand) if with_fused else (cands_s, ncand_s)
         out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches, offsets, (a.warmup + a.steps - 1) % nb,
-                                           cands, ncand, B, paired)
+                                           gc, gn, B, paired, bounded=world > 1)
+        parity_ok = out["cpu_baseline"]["gpu_matches_cpu_on_first_batch"] is not False
     if rank == 0:
         emit(out)
-    if world > 1 or a.mode == "sharded":
-        import torch.distributed as dist
-        if sharded_error:            # a rank that failed inside the exchange may have left its peers in a collective
+    rc = 0
+    if sharded_error or (with_sharded and sharded_elapsed is None):
+        rc = EXIT_SHARDED_FAILED
+    elif not parity_ok or sharded_ok is False:
+        rc = EXIT_PARITY_FAILED
+    if dist is not None:
+        if rc == EXIT_SHARDED_FAILED:    # a rank that failed inside the exchange may have left its peers in a collective
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(rc)
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
-def cpu_baseline(a, keys, list_off, locs, species, batches, offsets, first, cands, ncand, B, paired):
+def cpu_baseline(a, keys, list_off, locs, species, batches, offsets, first, cands, ncand, B, paired, bounded=False):
     """The oracle (bit-exact CPU restatement of the reference path) timed on this box's
     host cores on a bounded sample of the same workload (whole batches, starting with the
     last timed one, until ~cpu_seconds), and checked against the GPU result of that batch."""
@@ -364,6 +443,8 @@ def cpu_baseline(a, keys, list_off, locs, species, batches, offsets, first, cand
                 mask = np.arange(a.max_cand)[None, :] < on[:, None]
                 ok = bool(np.array_equal(gc[mask], oc[mask]))
         i += 1
+        if bounded:
+            break
     return {"value": total_n / total_t, "unit": "reads/s", "cores": cores, "kind": "port",
             "sample": "%d reads (%d whole batches of the timed workload), %d threads, DB build excluded" % (total_n, total_n // B, cores),
             "seconds": total_t, "gpu_matches_cpu_on_first_batch": ok}

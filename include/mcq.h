@@ -114,7 +114,8 @@ typedef struct {
     uint32_t emulate_ranks;     /* P of the reference run to match (fold order of
                                    src/querying.h:867-1073); 1 = single list, no fold    */
     uint64_t insert_size_max;   /* insertSizeMax                                         */
-    uint32_t flags;             /* MCQ_QUIRK_SEQ_DROP                                    */
+    uint32_t flags;             /* MCQ_QUIRK_SEQ_DROP and the MCQ_FORCE_* / MCQ_NO_WAVE16 test hooks; any other
+                                   bit is rejected with MCQ_E_ARG                         */
 } mcq_query_opts;
 
 /* match_candidate (src/candidates.h:66-81) with the taxon as its key.  After a fold
@@ -210,11 +211,15 @@ int mcq_bucket_features(const uint32_t* features, uint64_t n, uint32_t n_shards,
  * (src/hash_int.h:39-45), never of f itself                          */
 uint32_t mcq_owner(uint32_t feature, uint32_t n_shards);
 
-/* Per-kernel timing of the fused query kernel (HIP events on the call's stream), for the
- * roofline line of bench.py.  enable != 0 starts recording; mcq_ws_kernel_time returns the
- * summed duration and launch count since enabling (synchronises the recorded events).   */
+/* Per-kernel timing of the path's kernels (HIP events between them on the call's stream), for the
+ * roofline line of bench.py.  enable != 0 starts recording.  mcq_ws_kernel_times returns, summed over
+ * the batches since enabling, the milliseconds of ms[0] the first wave stage (k_query_wave / k_reduce_wave),
+ * ms[1] the second wave stage (k_query_wave16 / k_reduce_wave16), ms[2] the workgroup kernel
+ * (k_query_block / k_reduce_block), and the number of batches; mcq_ws_kernel_time their total.
+ * Both synchronise the recorded events.                                                   */
 int mcq_ws_timing(mcq_ws* ws, int enable);
-int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_launches);
+int mcq_ws_kernel_times(mcq_ws* ws, double* ms /* [3] */, uint64_t* n_batches);
+int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_batches);
 
 /* ---- row f4: FASTQ ingest on the GPU ------------------------------------------------
  * text: raw FASTQ bytes in DEVICE memory (4 lines per record, as fastq_reader::read_next reads
@@ -257,9 +262,14 @@ int mcq_table_free(mcq_table* t);
 int mcq_db_build(const mcq_build_desc* desc, mcq_db** out);
 const char* mcq_build_last_error(void);
 
-/* ---- debug / parity taps (rows 5 and 8 in isolation) ----------------------------- */
-/* sorted match list of every query: match_off[q..q+1) into matches (capacity cap)   */
-int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* in,
+/* ---- debug / parity taps ------------------------------------------------------------
+ * Row 5 in isolation is mcq_count_windows + mcq_sketch above (the sketches of every window).
+ * Rows 7-8 in isolation: the sorted match list of every query (what merge_sort returns,
+ * src/querying.h:88-106): match_off[q..q+1) into matches (capacity cap; pass matches = NULL first to
+ * learn the sizes).  path_flags = 0 taps every query on the path it takes in mcq_query (first or second
+ * wave stage, workgroup kernel); MCQ_FORCE_BLOCK_PATH / MCQ_FORCE_RAW_SORT / MCQ_NO_WAVE16 tap the path
+ * those hooks select.  The taps live in separate instantiations of the kernels.                     */
+int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, uint32_t path_flags,
                       uint64_t* match_off /* host [n_queries+1] */, uint64_t* matches /* host */, uint64_t cap);
 
 const char* mcq_last_error(void);

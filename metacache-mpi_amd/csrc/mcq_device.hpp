@@ -92,16 +92,21 @@ static_assert(offsetof(CountersDev, probe_buf) == 256, "probe_buf sits 256 bytes
 #define MCQ_CTR_ZEROED offsetof(CountersDev, probe_buf)
 
 // ---- overflow queues ---------------------------------------------------------------------------------
-// One array, two queues: the front one grows from index 0, the back one downwards from nq + MCQ_OVF_PAD - 1.  A wave
+// One array, two queues: the front one grows from index 0, the back one downwards from the array's last entry.  A wave
 // reserves MCQ_OVF_CHUNK slots per global atomic (with most of a batch overflowing, one atomic per query on a
 // single address cost 5 ms per 1 M reads; 8 slots: 16 would be 1 % faster there and 3 % slower with 11 % overflowing) and keeps its reservation in five words of LDS (st: next slot and slots
 // left of the front and the back queue, queries queued); when it ends it fills what is left with MCQ_EMPTY, which the
-// draining kernels skip.  The array has max_queries + MCQ_OVF_PAD entries: enough for the unused tails of 32768 waves.
+// draining kernels skip.
+// Capacity: every query can sit in the back queue AND be passed on to the front queue by the second wave stage while
+// other waves still drain the back queue, so the array has 2 x nq entries plus the unused reservation tails of three
+// sets of at most 32768 waves (first stage front, first stage back, second stage front): the two queues never meet.
 #ifndef MCQ_OVF_CHUNK
 #define MCQ_OVF_CHUNK 8u            // tuning knob: 1u = one atomic per queued query, no empty slots
 #endif
-#define MCQ_OVF_PAD (2u * MCQ_OVF_CHUNK * 32768u)
-__device__ __forceinline__ u64 ovf_slot(u64 nq, int back, u32 i) { return back ? nq + MCQ_OVF_PAD - 1 - i : (u64)i; }
+#define MCQ_OVF_TAIL (MCQ_OVF_CHUNK * 32768u)      // unused reservation tails of one set of waves
+#define MCQ_OVF_PAD (3u * MCQ_OVF_TAIL)
+__device__ __host__ __forceinline__ u64 ovf_capacity(u64 nq) { return 2 * nq + MCQ_OVF_PAD; }
+__device__ __forceinline__ u64 ovf_slot(u64 nq, int back, u32 i) { return back ? ovf_capacity(nq) - 1 - i : (u64)i; }
 // Draining order: slot of the it-th visit.  Reservations are filled from their first slot, so the real entries sit at
 // the low positions of every chunk; a drainer striding through the slots by a multiple of its size (5120 waves, 512
 // workgroups) would see the same position every time -- some would get all the work and others only empty slots.

@@ -5,8 +5,9 @@
 //   k_query_wave    one wavefront per query.  Sketch (<= 4 windows), 64 parallel table
 //                   probes, list gather into registers, distinct-key counting in the
 //                   wave's LDS segment, register sort, per-target window sweep, top
-//                   lists + tree fold.  HBM traffic = the algorithmic bytes: read bases,
-//                   one 16-B slot per probe, the location lists once, the candidates out.
+//                   lists + tree fold.  Per read it touches the bases, one 16-B slot per probe, the
+//                   location lists once and the candidates out (the algorithmic bytes); the HBM traffic
+//                   is 2.3 x that, because slots and short lists come in 64-B sectors.
 //   k_query_wave16  second wave stage: queries of 513..1024 locations (32-bit keys),
 //                   16 keys per lane.
 //   k_query_block   one 1024-thread workgroup per query that fits neither (long reads
@@ -34,6 +35,10 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     return fail(MCQ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
+// like HIPCHK inside a constructor-like function: releases what the half-built object already holds before returning
+#define HIPCHK_OR(expr, cleanup) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cleanup; \
+    return fail(MCQ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+
 extern "C" const char* mcq_last_error(void) { return g_err.c_str(); }
 extern "C" const char* mcq_version(void) { return "mcq 0.1 (gfx950)"; }
 
@@ -48,11 +53,11 @@ static u32 resident_blocks(Kernel kernel, int block_size, int device) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_size, 0) != hipSuccess || per_cu < 1) per_cu = 4;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
     if (const char* e = getenv("MCQ_WAVE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));       // tuning knob
-    return std::min<u32>((u32)per_cu * (u32)prop.multiProcessorCount, 8192u);     // 4 x 8192 waves: what MCQ_OVF_PAD covers
+    return std::min<u32>((u32)per_cu * (u32)prop.multiProcessorCount, 8192u);     // 4 x 8192 waves: what MCQ_OVF_TAIL covers
 }
-#define MCQ_GRID(kernel, block, device, want) ([&]() -> u32 { static u32 cap_ = 0; static int dev_ = -1; \
-    if (dev_ != (device)) { cap_ = resident_blocks((kernel), (block), (device)); dev_ = (device); } \
-    return (u32)std::min<u64>((want) ? (want) : 1, cap_); }())
+// (computed once per workspace for its device and kept in the handle: nothing static, so two devices or two
+// threads in one process do not disturb each other)
+static u32 grid_for(u32 cap, u64 want) { return (u32)std::min<u64>(want ? want : 1, cap ? cap : 1); }
 
 // ------------------------------------------------------------------ handles
 struct mcq_db {
@@ -79,23 +84,26 @@ struct DebugDev {
     u64* matches;
 };
 
+#define MCQ_N_TIMED 3           // kernels of one batch that are timed separately: first wave stage, second wave stage, workgroup kernel
+struct TimedLaunch { hipEvent_t ev[MCQ_N_TIMED + 1]; };
 struct mcq_ws {
     int device;
     u64 max_queries, max_bases;
     CountersDev* ctr;         // device
     CountersDev* ctr_host;    // pinned
-    u32* ovf_list;            // [max_queries + MCQ_OVF_PAD]
-    unsigned long long* probe_buf;   // [(max_queries + MCQ_OVF_PAD / 2) x 64], see CountersDev
+    u32* ovf_list;            // [ovf_capacity(max_queries)]
+    unsigned long long* probe_buf;   // [(max_queries + MCQ_OVF_TAIL) x 64], see CountersDev
     ScratchDev sc;
     int n_block_wgs;
+    u32 cap_wave, cap_wave16, cap_reduce16;   // resident workgroups of the wave-per-query kernels on this device
     // staging for host-pointer calls
     char* d_bases; u64* d_seq_off; u32* d_cands; u32* d_ncand;
     u64 last_nq;
-    // optional per-launch timing of the wave kernel
+    // optional per-launch timing of the path's kernels (events between them on the call's stream)
     int timing;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev_used;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>>* ev_free;
-    double timed_ms; u64 timed_launches;
+    std::vector<TimedLaunch>* ev_used;
+    std::vector<TimedLaunch>* ev_free;
+    double timed_ms[MCQ_N_TIMED]; u64 timed_launches;
 };
 
 // ------------------------------------------------------------------ kernels: table build
@@ -524,9 +532,23 @@ __device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, co
 #ifndef MCQ_WAVE_OCC
 #define MCQ_WAVE_OCC 8          // waves per SIMD the 32-bit-key kernel is compiled for (tuning knob)
 #endif
-template <class KeyT, int LCAP>
+// match-list tap of the wave kernels (TAP instantiations only: mcq_debug_matches): the sorted match list of a query
+// as rows 7-8 define it, written out from whichever form the path holds it in
+template <class KeyT>
+__device__ __forceinline__ void tap_sorted(const DebugDev& dbg, const KeyT* buf, u32 T, u32 wb, u64 q, u32 lane) {
+    for (u32 t = lane; t < T; t += 64) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(buf[t], wb);
+}
+// ... from the distinct sorted keys SK[0..D) and the inclusive sums WP of their multiplicities
+__device__ __forceinline__ void tap_distinct(const DebugDev& dbg, const u32* SK, const u32* WP, u32 D, u32 wb, u64 q, u32 lane) {
+    for (u32 j = lane; j < D; j += 64) {
+        const u64 v = key_expand<u32>(SK[j], wb);
+        for (u32 c = j ? WP[j - 1] : 0u; c < WP[j]; ++c) dbg.matches[dbg.match_off[q] + c] = v;
+    }
+}
+
+template <class KeyT, int LCAP, bool TAP = false>
 __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
-                                                    CountersDev* ctr, u32* ovf_list, int force_block) {
+                                                    CountersDev* ctr, u32* ovf_list, int force_block, DebugDev dbg) {
     static_assert(LCAP == 512, "wave path: 8 keys per lane at most, entry index packed into 9 bits");
     __shared__ KeyT s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
@@ -538,7 +560,11 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
     u32* feat = hits + 64;
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
-    const int stop = force_block >> 4;              // profiling hook: 0 = run everything
+#ifdef MCQ_PROFILE_HOOKS
+    const int stop = force_block >> 4;              // profiling builds: stop after stage 1..5 (results invalid); 0 = run everything
+#else
+    constexpr int stop = 0;
+#endif
     __shared__ u32 s_ovf[4][5];                     // this wave's queue reservations (mcq_device.hpp, "overflow queues")
     if (lane == 0) ovf_init(s_ovf[wave]);
     // The distinct-key count of a read is only known after the attempt; a failed attempt costs a gather and ~300 table
@@ -595,6 +621,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
             continue;
         }
         st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
+        if constexpr (TAP) { if (dbg.mode == 1 && lane == 0) dbg.match_cnt[q] = T; }
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
 
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
@@ -624,6 +651,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                 if (D != ~1u) D = dedup_finish(D, buf, hits, lane, k1, incl1);
                 if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
+                    if constexpr (TAP) { if (dbg.mode == 2) tap_distinct(dbg, dedup_sk(hits), dedup_wp(hits), D, db.wb, q, lane); }
                     if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
                     else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
                     if (stop == 5) { if (buf[lane] == 0x12345u) out.ncand[q] = 1; wave_sync(); continue; }
@@ -643,6 +671,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         else               gather_sort_store<KeyT, 8>(db, buf, hits, T, pos, len, off, lane, stop);
         wave_sync();
         if (stop == 3 || stop == 4) { if (buf[lane] == (KeyT)0x1234) out.ncand[q] = 1; continue; }
+        if constexpr (TAP) { if (dbg.mode == 2) tap_sorted<KeyT>(dbg, buf, T, db.wb, q, lane); }
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
         if (stop == 5) { if (hits[lane] == 0x12345u) out.ncand[q] = 1; continue; }
         if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, q, lane);
@@ -667,8 +696,9 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 #ifndef MCQ_WAVE16_OCC
 #define MCQ_WAVE16_OCC 4        // waves per SIMD it is compiled for: 5 fit the LDS, but then 10 VGPRs spill (+30 % time)
 #endif
+template <bool TAP = false>
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, BatchDev b, OptDev opt, OutDev out,
-                                                                      CountersDev* ctr, u32* ovf_list) {
+                                                                      CountersDev* ctr, u32* ovf_list, DebugDev dbg) {
     constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
     __shared__ u32 s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
@@ -724,6 +754,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             continue;
         }
         st_loc += T;
+        if constexpr (TAP) { if (dbg.mode == 1 && lane == 0) dbg.match_cnt[q] = T; }
 #ifdef MCQ_NO_PROBE_HANDOVER
         {
 #else
@@ -742,6 +773,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             else               D = gather2_dedup_insert<8>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
             D = dedup_finish(D, buf, hits, lane, k1, incl1);
             if (D != ~0u) {
+                if constexpr (TAP) { if (dbg.mode == 2) tap_distinct(dbg, dedup_sk(hits), dedup_wp(hits), D, db.wb, q, lane); }
                 if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, buf, D, numWindows, db.wb, lane);
                 else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
                 st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), buf, D, numWindows, db.wb, q, lane);
@@ -758,6 +790,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             for (int e = 0; e < 16; ++e) buf[e * 64 + lane] = r[e];
         }
         wave_sync();
+        if constexpr (TAP) { if (dbg.mode == 2) tap_sorted<u32>(dbg, buf, T, db.wb, q, lane); }
         sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
         st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, q, lane);
         wave_sync();
@@ -1430,8 +1463,23 @@ static void fold_schedule(u32 P, std::vector<std::pair<u32, u32>>& sched, std::v
     }
 }
 
+// flags of mcq_query_opts a caller may set (anything else is rejected: a stray bit must not change results silently)
+#ifdef MCQ_PROFILE_HOOKS        // profiling builds only: bits 12..15 = stop the fused kernel after stage 1..5 (results invalid)
+#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16 | 0xF000u)
+#else
+#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16)
+#endif
+static int force_bits(u32 flags) {
+    int f = ((flags & MCQ_FORCE_BLOCK_PATH) ? 1 : 0) | ((flags & MCQ_FORCE_RAW_SORT) ? 2 : 0) | ((flags & MCQ_NO_WAVE16) ? 4 : 0);
+#ifdef MCQ_PROFILE_HOOKS
+    f |= (int)((flags >> 12) & 0xFu) << 4;
+#endif
+    return f;
+}
+
 static int make_opt(const mcq_query_opts* o, OptDev& d) {
     if (!o) return fail(MCQ_E_ARG, "opts is null");
+    if (o->flags & ~(u32)MCQ_OPT_FLAGS_KNOWN) return fail(MCQ_E_ARG, "unknown bits in mcq_query_opts.flags");
     u32 P = o->emulate_ranks ? o->emulate_ranks : 1;
     if (P > 64) return fail(MCQ_E_UNSUPPORTED, "emulate_ranks > 64");
     u32 p2 = (u32)pow2ceil64(P);
@@ -1474,25 +1522,24 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     const bool dev = (desc->flags & MCQ_DEVICE_PTRS) != 0;
     const u64 nk = desc->n_keys, nl = desc->n_locs;
     const u32* d_keys = desc->keys; const u64* d_off = desc->list_off; const u64* d_locs = desc->locs;
+    // temporaries are released on every way out; the handle itself by mcq_db_destroy on failure
+    struct Temps { std::vector<void*> p; ~Temps() { for (void* x : p) (void)hipFree(x); }
+                   hipError_t alloc(void** out, u64 bytes) { hipError_t e = hipMalloc(out, bytes); if (e == hipSuccess) p.push_back(*out); return e; } } tmp;
     u32* t_keys = nullptr; u64* t_off = nullptr; u64* t_locs = nullptr;
     if (!dev) {
-        HIPCHK(hipMalloc(&t_keys, std::max<u64>(1, nk) * 4));
-        HIPCHK(hipMalloc(&t_off, (nk + 1) * 8));
-        HIPCHK(hipMalloc(&t_locs, std::max<u64>(1, nl) * 8));
+        HIPCHK(tmp.alloc((void**)&t_keys, std::max<u64>(1, nk) * 4));
+        HIPCHK(tmp.alloc((void**)&t_off, (nk + 1) * 8));
+        HIPCHK(tmp.alloc((void**)&t_locs, std::max<u64>(1, nl) * 8));
         if (nk) HIPCHK(hipMemcpy(t_keys, desc->keys, nk * 4, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(t_off, desc->list_off, (nk + 1) * 8, hipMemcpyHostToDevice));
         if (nl) HIPCHK(hipMemcpy(t_locs, desc->locs, nl * 8, hipMemcpyHostToDevice));
         d_keys = t_keys; d_off = t_off; d_locs = t_locs;
     }
 
-    mcq_db* db = new mcq_db();
-    memset(db, 0, sizeof(*db));
-    db->device = desc->device; db->n_shards = n_shards; db->shard_id = desc->shard_id;
-
     // owned list lengths -> compacted offsets
     u64 *d_len = nullptr, *d_new = nullptr;
-    HIPCHK(hipMalloc(&d_len, std::max<u64>(1, nk) * 8));
-    HIPCHK(hipMalloc(&d_new, (nk + 1) * 8));
+    HIPCHK(tmp.alloc((void**)&d_len, std::max<u64>(1, nk) * 8));
+    HIPCHK(tmp.alloc((void**)&d_new, (nk + 1) * 8));
     const u32 TB = 256;
     if (nk) hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id, d_len);
     { int rcs = device_exclusive_scan<u64>(d_len, d_new, nk, 0); if (rcs) return rcs; }
@@ -1505,22 +1552,20 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
         if (nk) HIPCHK(hipMemcpy(h_len.data(), d_len, nk * 8, hipMemcpyDeviceToHost));
         for (u64 i = 0; i < nk; ++i) nk_local += h_len[i] > 0;
     }
-    db->n_keys_local = nk_local; db->n_locs_local = nl_local;
     // load factor <= 0.25: 43 % of a read's features are not in the table and an unsuccessful linear probe
     // walks 2.5 slots at load 0.5 but 1.4 at 0.25 -- fewer 64-B sectors per read for 16 B per key more
     u64 slots_per_key = 4;
     if (const char* e = getenv("MCQ_SLOTS_PER_KEY")) slots_per_key = std::max<u64>(1, strtoull(e, nullptr, 10));   // tuning knob
-    db->nslots = std::max<u64>(1024, pow2ceil64(nk_local * slots_per_key));
-    if (db->nslots > (1ull << 32)) { return fail(MCQ_E_UNSUPPORTED, "table too large"); }
+    const u64 nslots = std::max<u64>(1024, pow2ceil64(nk_local * slots_per_key));
+    if (nslots > (1ull << 32)) { return fail(MCQ_E_UNSUPPORTED, "table too large"); }
     // compact locations: (tgt << wb) | win in 32 bits when target and window ids fit
     u32 wb = 32, compact = 0;
     if (!(desc->flags & MCQ_DB_LOCS_64)) {
         u32* d_mw = nullptr; u32 maxwin = 0;
-        HIPCHK(hipMalloc(&d_mw, 4));
+        HIPCHK(tmp.alloc((void**)&d_mw, 4));
         HIPCHK(hipMemset(d_mw, 0, 4));
         if (nl) hipLaunchKernelGGL(k_max_win, dim3(1024), dim3(256), 0, 0, d_locs, nl, d_mw);
         HIPCHK(hipMemcpy(&maxwin, d_mw, 4, hipMemcpyDeviceToHost));
-        (void)hipFree(d_mw);
         u32 winbits = 1; while (winbits < 32 && (maxwin >> winbits)) ++winbits;
         u32 maxtgt = desc->n_targets ? desc->n_targets - 1 : 0;
         u32 tgtbits = 1; while (tgtbits < 32 && (maxtgt >> tgtbits)) ++tgtbits;
@@ -1529,26 +1574,29 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
             ((((u64)maxtgt << winbits) | maxwin) < 0xFFFFFFFFull)) { compact = 1; wb = winbits; }
     }
     const u64 locsz = compact ? 4 : 8;
-    HIPCHK(hipMalloc(&db->slots, db->nslots * sizeof(uint4)));
-    HIPCHK(hipMalloc(&db->locs, std::max<u64>(1, nl_local) * locsz));
-    HIPCHK(hipMalloc(&db->tgt2tax, std::max<u32>(1, desc->n_targets) * 4));
+
+    mcq_db* db = new mcq_db();
+    memset(db, 0, sizeof(*db));
+    db->device = desc->device; db->n_shards = n_shards; db->shard_id = desc->shard_id;
+    db->n_keys_local = nk_local; db->n_locs_local = nl_local; db->nslots = nslots;
+#define DBCHK(expr) HIPCHK_OR(expr, (void)mcq_db_destroy(db))
+    DBCHK(hipMalloc(&db->slots, db->nslots * sizeof(uint4)));
+    DBCHK(hipMalloc(&db->locs, std::max<u64>(1, nl_local) * locsz));
+    DBCHK(hipMalloc(&db->tgt2tax, std::max<u32>(1, desc->n_targets) * 4));
     if (desc->n_targets)
-        HIPCHK(hipMemcpy(db->tgt2tax, desc->tgt2tax, (u64)desc->n_targets * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        DBCHK(hipMemcpy(db->tgt2tax, desc->tgt2tax, (u64)desc->n_targets * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_fill_slots, dim3((u32)std::min<u64>((db->nslots + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, db->slots, db->nslots);
     if (nk) {
         hipLaunchKernelGGL(k_insert_keys, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, db->slots, (u32)(db->nslots - 1),
                            d_keys, d_new, nk, n_shards, desc->shard_id);
-        HIPCHK(hipGetLastError());
+        DBCHK(hipGetLastError());
         const dim3 cg((u32)std::min<u64>((nk * 64 + TB - 1) / TB, 1u << 20));
         if (compact) hipLaunchKernelGGL(k_copy_lists<u32>, cg, dim3(TB), 0, 0, d_off, d_new, d_locs, (u32*)db->locs, nk, wb);
         else         hipLaunchKernelGGL(k_copy_lists<u64>, cg, dim3(TB), 0, 0, d_off, d_new, d_locs, (u64*)db->locs, nk, 32u);
-        HIPCHK(hipGetLastError());
+        DBCHK(hipGetLastError());
     }
-    HIPCHK(hipDeviceSynchronize());
-    (void)hipFree(d_len); (void)hipFree(d_new);
-    if (t_keys) (void)hipFree(t_keys);
-    if (t_off) (void)hipFree(t_off);
-    if (t_locs) (void)hipFree(t_locs);
+    DBCHK(hipDeviceSynchronize());
+#undef DBCHK
 
     db->d.slots = db->slots; db->d.slot_mask = (u32)(db->nslots - 1); db->d.locs = db->locs;
     db->d.wb = wb; db->d.compact = compact;
@@ -1581,31 +1629,37 @@ extern "C" uint64_t mcq_db_bytes(const mcq_db* db) { return db ? db->bytes : 0; 
 extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t max_bases,
                              uint64_t max_locs_per_query, mcq_ws** out) {
     if (!db || !out) return fail(MCQ_E_ARG, "null argument");
-    if (max_queries >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "max_queries must be < 2^32 per batch");
+    if (max_queries >= (1ull << 31)) return fail(MCQ_E_UNSUPPORTED, "max_queries must be < 2^31 per batch");
+    u64 lmax = max_locs_per_query ? pow2ceil64(max_locs_per_query) : (1ull << 18);
+    if (lmax > (1ull << 30)) return fail(MCQ_E_UNSUPPORTED, "max_locs_per_query too large");
     HIPCHK(hipSetDevice(db->device));
     mcq_ws* ws = new mcq_ws();
     memset(ws, 0, sizeof(*ws));
     ws->device = db->device; ws->max_queries = max_queries; ws->max_bases = max_bases;
-    u64 lmax = max_locs_per_query ? pow2ceil64(max_locs_per_query) : (1ull << 18);
-    if (lmax > (1ull << 30)) return fail(MCQ_E_UNSUPPORTED, "max_locs_per_query too large");
     ws->sc.lmax = (u32)lmax;
     ws->sc.fmax = 1u << 15;
-    ws->n_block_wgs = MCQ_BLOCK_WGS_DEFAULT;
-    if (const char* e = getenv("MCQ_BLOCK_WGS")) ws->n_block_wgs = std::max(1, atoi(e));      // tuning knob                   // two resident workgroups per CU (32-bit keys: 64 KB of LDS, 64 VGPRs)
-    ws->ev_used = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
-    ws->ev_free = new std::vector<std::pair<hipEvent_t, hipEvent_t>>();
+    ws->n_block_wgs = MCQ_BLOCK_WGS_DEFAULT;   // two resident workgroups per CU (32-bit keys: 64 KB of LDS, 64 VGPRs)
+    if (const char* e = getenv("MCQ_BLOCK_WGS")) ws->n_block_wgs = std::max(1, atoi(e));      // tuning knob
+    ws->ev_used = new std::vector<TimedLaunch>();
+    ws->ev_free = new std::vector<TimedLaunch>();
+    ws->cap_wave = db->d.compact ? resident_blocks(k_query_wave<u32, 512>, 256, db->device)
+                                 : resident_blocks(k_query_wave<u64, 512>, 256, db->device);
+    ws->cap_wave16 = resident_blocks(k_query_wave16<false>, 256, db->device);
+    ws->cap_reduce16 = resident_blocks(k_reduce_wave16, 256, db->device);
     const u64 nb = (u64)ws->n_block_wgs;
-    HIPCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
-    HIPCHK(hipHostMalloc(&ws->ctr_host, sizeof(CountersDev)));
-    HIPCHK(hipMalloc(&ws->ovf_list, (max_queries + (u64)MCQ_OVF_PAD) * 4));
-    HIPCHK(hipMalloc(&ws->probe_buf, (max_queries + (u64)MCQ_OVF_PAD / 2) * 64 * 8));
-    HIPCHK(hipMemset(ws->ctr, 0, sizeof(CountersDev)));
-    HIPCHK(hipMemcpy(&ws->ctr->probe_buf, &ws->probe_buf, sizeof(ws->probe_buf), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc(&ws->sc.feat, nb * ws->sc.fmax * 4));
-    HIPCHK(hipMalloc(&ws->sc.fpos, nb * ((u64)ws->sc.fmax + 1) * 4));
-    HIPCHK(hipMalloc(&ws->sc.foff, nb * ws->sc.fmax * 8));
-    HIPCHK(hipMalloc(&ws->sc.gbuf, nb * lmax * 8));
-    HIPCHK(hipMalloc(&ws->sc.ghits, nb * lmax * 8));
+#define WSCHK(expr) HIPCHK_OR(expr, (void)mcq_ws_destroy(ws))
+    WSCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
+    WSCHK(hipHostMalloc(&ws->ctr_host, sizeof(CountersDev)));
+    WSCHK(hipMalloc(&ws->ovf_list, ovf_capacity(max_queries) * 4));
+    WSCHK(hipMalloc(&ws->probe_buf, (max_queries + (u64)MCQ_OVF_TAIL) * 64 * 8));
+    WSCHK(hipMemset(ws->ctr, 0, sizeof(CountersDev)));
+    WSCHK(hipMemcpy(&ws->ctr->probe_buf, &ws->probe_buf, sizeof(ws->probe_buf), hipMemcpyHostToDevice));
+    WSCHK(hipMalloc(&ws->sc.feat, nb * ws->sc.fmax * 4));
+    WSCHK(hipMalloc(&ws->sc.fpos, nb * ((u64)ws->sc.fmax + 1) * 4));
+    WSCHK(hipMalloc(&ws->sc.foff, nb * ws->sc.fmax * 8));
+    WSCHK(hipMalloc(&ws->sc.gbuf, nb * lmax * 8));
+    WSCHK(hipMalloc(&ws->sc.ghits, nb * lmax * 8));
+#undef WSCHK
     *out = ws;
     return MCQ_OK;
 }
@@ -1620,7 +1674,8 @@ extern "C" int mcq_ws_destroy(mcq_ws* ws) {
     if (ws->d_cands) (void)hipFree(ws->d_cands);
     if (ws->d_ncand) (void)hipFree(ws->d_ncand);
     for (auto* v : {ws->ev_used, ws->ev_free}) {
-        for (auto& e : *v) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+        if (!v) continue;
+        for (auto& t : *v) for (auto e : t.ev) (void)hipEventDestroy(e);
         delete v;
     }
     delete ws;
@@ -1639,28 +1694,50 @@ static int ensure_staging(mcq_ws* ws) {
 static const int kLcapWave = 512;
 static const int kLcapBlock = 8192;
 
+// events between the kernels of one batch (timing enabled only): begin(), then mark() after each kernel
+struct LaunchTimer {
+    mcq_ws* ws; hipStream_t st; TimedLaunch t; int n; bool on;
+    LaunchTimer(mcq_ws* w, hipStream_t s) : ws(w), st(s), n(0), on(w->timing != 0) {}
+    int begin() {
+        if (!on) return MCQ_OK;
+        if (!ws->ev_free->empty()) { t = ws->ev_free->back(); ws->ev_free->pop_back(); }
+        else for (auto& e : t.ev) HIPCHK(hipEventCreate(&e));
+        return mark();
+    }
+    int mark() { if (on && n <= MCQ_N_TIMED) HIPCHK(hipEventRecord(t.ev[n++], st)); return MCQ_OK; }
+    int end() {                                 // kernels that were not launched take no time: repeat the last event
+        if (!on) return MCQ_OK;
+        while (n <= MCQ_N_TIMED) { int rc = mark(); if (rc) return rc; }
+        ws->ev_used->push_back(t);
+        return MCQ_OK;
+    }
+};
+
 static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const OptDev& od, const OutDev& o,
                         hipStream_t st, int force_block, const DebugDev& dbg) {
     HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
     if (b.nq == 0) return MCQ_OK;
-    u64 want = (b.nq + 3) / 4;
-    const u32 grid = db->d.compact ? MCQ_GRID((k_query_wave<u32, kLcapWave>), 256, db->device, want)
-                                   : MCQ_GRID((k_query_wave<u64, kLcapWave>), 256, db->device, want);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ws->timing) {
-        if (!ws->ev_free->empty()) { e0 = ws->ev_free->back().first; e1 = ws->ev_free->back().second; ws->ev_free->pop_back(); }
-        else { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); }
-        HIPCHK(hipEventRecord(e0, st));
+    const u64 want = (b.nq + 3) / 4;
+    const u32 grid = grid_for(ws->cap_wave, want);
+    LaunchTimer tm(ws, st);
+    int rc = tm.begin(); if (rc) return rc;
+    const bool tap = dbg.mode != 0;     // mcq_debug_matches: the instantiations that also write the sorted match lists
+#define MCQ_LAUNCH_WAVE(KT, TAPV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg)
+    if (db->d.compact) { if (tap) MCQ_LAUNCH_WAVE(u32, true); else MCQ_LAUNCH_WAVE(u32, false); }
+    else               { if (tap) MCQ_LAUNCH_WAVE(u64, true); else MCQ_LAUNCH_WAVE(u64, false); }
+#undef MCQ_LAUNCH_WAVE
+    rc = tm.mark(); if (rc) return rc;
+    if (db->d.compact) {   // second wave stage (back queue); no queue for 64-bit keys
+        const dim3 g16(grid_for(ws->cap_wave16, want));
+        if (tap) hipLaunchKernelGGL(k_query_wave16<true>, g16, dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, dbg);
+        else     hipLaunchKernelGGL(k_query_wave16<false>, g16, dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, dbg);
     }
-    if (db->d.compact) hipLaunchKernelGGL((k_query_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
-    else               hipLaunchKernelGGL((k_query_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block);
-    if (ws->timing) { HIPCHK(hipEventRecord(e1, st)); ws->ev_used->emplace_back(e0, e1); }
-    if (db->d.compact)     // second wave stage (back queue); no queue for 64-bit keys
-        hipLaunchKernelGGL(k_query_wave16, dim3(MCQ_GRID(k_query_wave16, 256, db->device, want)), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list);
+    rc = tm.mark(); if (rc) return rc;
     if (db->d.compact) hipLaunchKernelGGL((k_query_block<u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT>), dim3(ws->n_block_wgs), dim3(MCQ_BLOCK_NT), 0, st, db->d, b, od, o, ws->ctr,
                                           (const u32*)ws->ovf_list, ws->sc, dbg);
     else               hipLaunchKernelGGL((k_query_block<u64, kLcapBlock, 1024>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
                                           (const u32*)ws->ovf_list, ws->sc, dbg);
+    rc = tm.end(); if (rc) return rc;
     HIPCHK(hipGetLastError());
     ws->last_nq = b.nq;
     return MCQ_OK;
@@ -1696,7 +1773,7 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     if (!dev_out) { o.cands = ws->d_cands; o.ncand = ws->d_ncand; }
     else { o.cands = (u32*)out->cands; o.ncand = out->n_cand; }
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
-    rc = launch_query(db, ws, b, od, o, st, ((opt->flags & MCQ_FORCE_BLOCK_PATH) ? 1 : 0) | ((opt->flags & MCQ_FORCE_RAW_SORT) ? 2 : 0) | ((opt->flags & MCQ_NO_WAVE16) ? 4 : 0) | (int)((opt->flags >> 12) & 0xFu) << 4, dbg);
+    rc = launch_query(db, ws, b, od, o, st, force_bits(opt->flags), dbg);
     if (rc) return rc;
     if (!dev_out && nq) {
         HIPCHK(hipMemcpyAsync(out->cands, ws->d_cands, nq * od.max_cand * 16, hipMemcpyDeviceToHost, st));
@@ -1724,9 +1801,10 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
 }
 
 // ------------------------------------------------------------------ debug tap: sorted match lists
-extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* in,
+extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, uint32_t path_flags,
                                  uint64_t* match_off, uint64_t* matches, uint64_t cap) {
     if (!db || !ws || !in || !match_off) return fail(MCQ_E_ARG, "null argument");
+    if (path_flags & ~(u32)(MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16)) return fail(MCQ_E_ARG, "path_flags: test hooks only");
     if (in->flags & MCQ_DEVICE_PTRS) return fail(MCQ_E_ARG, "debug tap takes host batches");
     HIPCHK(hipSetDevice(db->device));
     const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
@@ -1742,10 +1820,11 @@ extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* 
     OutDev o; o.cands = ws->d_cands; o.ncand = ws->d_ncand;
     u64 *d_cnt = nullptr, *d_off = nullptr, *d_m = nullptr;
     HIPCHK(hipMalloc(&d_cnt, std::max<u64>(1, nq) * 8));
+    HIPCHK(hipMemset(d_cnt, 0, std::max<u64>(1, nq) * 8));
     HIPCHK(hipMalloc(&d_off, (nq + 1) * 8));
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
     dbg.mode = 1; dbg.match_cnt = d_cnt;
-    rc = launch_query(db, ws, b, od, o, 0, 1, dbg); if (rc) return rc;
+    rc = launch_query(db, ws, b, od, o, 0, force_bits(path_flags), dbg); if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());
     std::vector<u64> cnt(nq);
     if (nq) HIPCHK(hipMemcpy(cnt.data(), d_cnt, nq * 8, hipMemcpyDeviceToHost));
@@ -1755,7 +1834,7 @@ extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* 
         HIPCHK(hipMalloc(&d_m, match_off[nq] * 8));
         HIPCHK(hipMemcpy(d_off, match_off, (nq + 1) * 8, hipMemcpyHostToDevice));
         dbg.mode = 2; dbg.match_off = d_off; dbg.matches = d_m;
-        rc = launch_query(db, ws, b, od, o, 0, 1, dbg); if (rc) return rc;
+        rc = launch_query(db, ws, b, od, o, 0, force_bits(path_flags), dbg); if (rc) return rc;
         HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipMemcpy(matches, d_m, match_off[nq] * 8, hipMemcpyDeviceToHost));
         (void)hipFree(d_m);
@@ -1873,31 +1952,41 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     if (n_queries == 0) return MCQ_OK;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
     const u32 grid = (u32)std::min<u64>((n_queries + 3) / 4, 256ull * 24);     // measured: 1.07 ms vs 1.25 ms at the resident 8 per CU
+    LaunchTimer tm(ws, st);
+    rc = tm.begin(); if (rc) return rc;
     if (db->d.compact) {
         hipLaunchKernelGGL((k_reduce_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
                            n_queries, loc_off, (const u32*)locs, query_len);
-        hipLaunchKernelGGL(k_reduce_wave16, dim3(MCQ_GRID(k_reduce_wave16, 256, db->device, (n_queries + 3) / 4)), dim3(256), 0, st, db->d, od, o, ws->ctr,
+        rc = tm.mark(); if (rc) return rc;
+        hipLaunchKernelGGL(k_reduce_wave16, dim3(grid_for(ws->cap_reduce16, (n_queries + 3) / 4)), dim3(256), 0, st, db->d, od, o, ws->ctr,
                            (const u32*)ws->ovf_list, n_queries, loc_off, (const u32*)locs, query_len);
+        rc = tm.mark(); if (rc) return rc;
         hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
                            (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len);
     } else {
         hipLaunchKernelGGL((k_reduce_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
                            n_queries, loc_off, (const u64*)locs, query_len);
+        rc = tm.mark(); if (rc) return rc;
+        rc = tm.mark(); if (rc) return rc;
         hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
                            (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
     }
+    rc = tm.end(); if (rc) return rc;
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }
 
 // ------------------------------------------------------------------ per-kernel timing
 static int drain_events(mcq_ws* ws) {
-    for (auto& e : *ws->ev_used) {
-        HIPCHK(hipEventSynchronize(e.second));
-        float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
-        ws->timed_ms += ms; ws->timed_launches += 1;
-        ws->ev_free->push_back(e);
+    for (auto& t : *ws->ev_used) {
+        HIPCHK(hipEventSynchronize(t.ev[MCQ_N_TIMED]));
+        for (int i = 0; i < MCQ_N_TIMED; ++i) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+            ws->timed_ms[i] += ms;
+        }
+        ws->timed_launches += 1;
+        ws->ev_free->push_back(t);
     }
     ws->ev_used->clear();
     return MCQ_OK;
@@ -1908,16 +1997,23 @@ extern "C" int mcq_ws_timing(mcq_ws* ws, int enable) {
     HIPCHK(hipSetDevice(ws->device));
     int rc = drain_events(ws); if (rc) return rc;
     ws->timing = enable ? 1 : 0;
-    if (enable) { ws->timed_ms = 0; ws->timed_launches = 0; }
+    if (enable) { for (auto& m : ws->timed_ms) m = 0; ws->timed_launches = 0; }
     return MCQ_OK;
 }
 
-extern "C" int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_launches) {
+extern "C" int mcq_ws_kernel_times(mcq_ws* ws, double* ms, uint64_t* n_batches) {
     if (!ws) return fail(MCQ_E_ARG, "null argument");
     HIPCHK(hipSetDevice(ws->device));
     int rc = drain_events(ws); if (rc) return rc;
-    if (total_ms) *total_ms = ws->timed_ms;
-    if (n_launches) *n_launches = ws->timed_launches;
+    if (ms) for (int i = 0; i < MCQ_N_TIMED; ++i) ms[i] = ws->timed_ms[i];
+    if (n_batches) *n_batches = ws->timed_launches;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_batches) {
+    double ms[MCQ_N_TIMED];
+    int rc = mcq_ws_kernel_times(ws, ms, n_batches); if (rc) return rc;
+    if (total_ms) { *total_ms = 0; for (double m : ms) *total_ms += m; }
     return MCQ_OK;
 }
 

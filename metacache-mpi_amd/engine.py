@@ -86,9 +86,10 @@ def lib():
         L.mcq_query.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         L.mcq_ws_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.mcq_owner.restype = C.c_uint32; L.mcq_owner.argtypes = [C.c_uint32, C.c_uint32]
-        L.mcq_debug_matches.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mcq_debug_matches.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
         L.mcq_ws_timing.argtypes = [C.c_void_p, C.c_int]
         L.mcq_ws_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mcq_ws_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         L.mcq_count_windows.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p]
         L.mcq_sketch.argtypes = [C.c_void_p, C.POINTER(Batch), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_lookup_count.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -261,22 +262,30 @@ class Workspace:
         _chk(lib().mcq_ws_kernel_time(self.h, C.byref(ms), C.byref(n)))
         return ms.value, int(n.value)
 
+    def kernel_times(self):
+        """(ms of first wave stage, second wave stage, workgroup kernel summed over the timed batches; n batches)"""
+        ms, n = (C.c_double * 3)(), C.c_uint64(0)
+        _chk(lib().mcq_ws_kernel_times(self.h, ms, C.byref(n)))
+        return [float(x) for x in ms], int(n.value)
+
     def reduce_device(self, n_queries, loc_off_ptr, locs_ptr, query_len_ptr, cands_ptr, ncand_ptr, max_cand=2,
                       emulate_ranks=1, insert_size_max=0, flags=0, stream=None):
         o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
         r = Result(cands_ptr, ncand_ptr, MCQ_DEVICE_PTRS)
         _chk(lib().mcq_reduce(self.db.h, self.h, n_queries, loc_off_ptr, locs_ptr, query_len_ptr, C.byref(o), C.byref(r), stream))
 
-    def debug_matches(self, bases, seq_off, paired):
+    def debug_matches(self, bases, seq_off, paired, path_flags=0):
+        """sorted match list of every query, tapped on the path the query takes (path_flags = 0) or the one a
+        test hook (MCQ_FORCE_BLOCK_PATH, MCQ_FORCE_RAW_SORT, MCQ_NO_WAVE16) selects"""
         seq_off = np.ascontiguousarray(seq_off, np.uint64)
         n_seqs = len(seq_off) - 1
         nq = n_seqs // 2 if paired else n_seqs
         bases_arr = np.ascontiguousarray(np.frombuffer(bases, dtype=np.uint8))
         b = Batch(n_seqs, _np_ptr(bases_arr) if len(bases_arr) else None, _np_ptr(seq_off), 1 if paired else 0, 0)
         moff = np.zeros(nq + 1, np.uint64)
-        _chk(lib().mcq_debug_matches(self.db.h, self.h, C.byref(b), _np_ptr(moff), None, 0))
+        _chk(lib().mcq_debug_matches(self.db.h, self.h, C.byref(b), path_flags, _np_ptr(moff), None, 0))
         m = np.zeros(max(1, int(moff[nq])), np.uint64)
-        _chk(lib().mcq_debug_matches(self.db.h, self.h, C.byref(b), _np_ptr(moff), _np_ptr(m), len(m)))
+        _chk(lib().mcq_debug_matches(self.db.h, self.h, C.byref(b), path_flags, _np_ptr(moff), _np_ptr(m), len(m)))
         return moff, m[:int(moff[nq])]
 
 

@@ -43,9 +43,14 @@ class HipBackend:
     def sketch(self, bases, seq_off, n_seqs, n_win_hint=None):
         win_off = torch.empty(n_seqs + 1, dtype=torch.int64, device=self.dev)
         self.db.count_windows(bases.data_ptr(), seq_off.data_ptr(), n_seqs, win_off.data_ptr(), self._st())
+        # n_win_hint (no host wait) is only right for fixed-length reads: the buffers are sized by a bound that holds
+        # for any batch (a sequence of n bases has at most n // stride + 2 windows), the hint only trims the view
+        bound = bases.numel() // self.db.winstride + 2 * n_seqs
         n_win = int(win_off[-1].item()) if n_win_hint is None else n_win_hint
-        feats = torch.empty((max(n_win, 1), self.s), dtype=torch.int32, device=self.dev)
-        nfeat = torch.empty(max(n_win, 1), dtype=torch.int32, device=self.dev)
+        if n_win > bound:
+            raise ValueError("n_win_hint %d exceeds what %d bases in %d sequences can have" % (n_win, bases.numel(), n_seqs))
+        feats = torch.empty((max(bound, 1), self.s), dtype=torch.int32, device=self.dev)
+        nfeat = torch.empty(max(bound, 1), dtype=torch.int32, device=self.dev)
         self.db.sketch(bases.data_ptr(), seq_off.data_ptr(), n_seqs, win_off.data_ptr(), feats.data_ptr(),
                        nfeat.data_ptr(), self._st())
         return win_off, feats[:n_win]

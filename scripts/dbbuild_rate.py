@@ -1,6 +1,7 @@
 """Times mcq_build_table (csrc/mcq_build.hip) against the torch-plumbing build of dbbuild.py on the
 bench's C2 genomes and checks the two tables are identical."""
-import importlib
+import importlib, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import sys
 import time
 
@@ -9,7 +10,7 @@ import torch
 sys.path.insert(0, ".")
 pkg = importlib.import_module("metacache-mpi_amd"); pkg.build_hip()
 eng = importlib.import_module("metacache-mpi_amd.engine")
-dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+dbbuild = importlib.import_module("dbbuild_torch")
 synth = importlib.import_module("metacache-mpi_amd.synth")
 dev = torch.device("cuda", 0)
 species, strains = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1024, 4)

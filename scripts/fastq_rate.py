@@ -1,9 +1,10 @@
 """throughput of mcq_fastq_index and of the query reading bases in place from raw FASTQ text"""
 import importlib, os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 eng = importlib.import_module("metacache-mpi_amd.engine")
-dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+dbbuild = importlib.import_module("dbbuild_torch")
 synth = importlib.import_module("metacache-mpi_amd.synth")
 dev = torch.device("cuda", 0)
 gb, goff, species = synth.make_genomes(50, 10, 2_000_000, 6_000_000, 0.02, seed=3, device=dev)

@@ -1,4 +1,7 @@
-"""GPU construction of the feature -> locations table from reference sequences.
+"""TEST INFRASTRUCTURE (not product): torch-op second implementation of the table build, kept as an
+independent check of csrc/mcq_build.hip.
+
+GPU construction of the feature -> locations table from reference sequences.
 
 Restates the reference's build-side insertion (add_all_window_sketches,
 src/sketch_database.h:1079-1097, with the target -> rank assignment tgt % P of
@@ -10,9 +13,11 @@ path uses; per (feature, virtual rank) only the first maxLocs=254 locations in
 Sorting / compaction here is torch plumbing around the HIP sketch kernel; it runs
 once per database, outside any timed region.
 """
+import importlib
+
 import torch
 
-from . import engine
+engine = importlib.import_module("metacache-mpi_amd.engine")      # TEST INFRASTRUCTURE: a second, torch-plumbing table build
 
 MAXLOCS = 254
 

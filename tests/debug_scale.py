@@ -4,7 +4,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from oracle import mc_oracle as orc
 eng = importlib.import_module("metacache-mpi_amd.engine")
-dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+dbbuild = importlib.import_module("dbbuild_torch")
 synth = importlib.import_module("metacache-mpi_amd.synth")
 dev = torch.device("cuda", 0)
 nsp = int(sys.argv[1]) if len(sys.argv) > 1 else 50

@@ -10,6 +10,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import mc_oracle as orc        # noqa: E402
 
 
@@ -21,7 +22,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     eng = importlib.import_module("metacache-mpi_amd.engine")
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     synth = importlib.import_module("metacache-mpi_amd.synth")
     sharded = importlib.import_module("metacache-mpi_amd.sharded")
     P, M = 4, 4

@@ -28,7 +28,7 @@ def _load_genomes(tag, dev):
 
 @pytest.mark.parametrize("tag,P", [("mini", 2), ("mini", 4), ("mini", 8), ("tie", 4), ("noanc", 2)])
 def test_table_equals_reference_shards(tag, P):
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     dev = torch.device("cuda", 0)
     fx = Fixture(tag, P)
     bases, off = _load_genomes(tag, dev)
@@ -46,7 +46,7 @@ def test_table_equals_reference_shards(tag, P):
 
 def test_truncation_to_254_per_virtual_rank():
     # one 128-base window repeated 700 times: every feature has 700 locations in one target set
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(3)
     unit = rng.choice(list(b"ACGT"), 113).astype(np.uint8)
@@ -85,7 +85,7 @@ def test_abi_table_equals_reference_shards(tag, P):
 
 def test_abi_table_host_pointers_and_truncation():
     engine = importlib.import_module("metacache-mpi_amd.engine")
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(3)
     unit = rng.choice(list(b"ACGT"), 113).astype(np.uint8)
@@ -141,7 +141,7 @@ def test_abi_build_rejects_bad_arguments():
 def test_remove_overpopulated_features_like_the_reference(P):
     """fixture built by the reference with -remove-overpopulated-features: counts are summed over the ranks"""
     engine = importlib.import_module("metacache-mpi_amd.engine")
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     dev = torch.device("cuda", 0)
     fx = Fixture("overpop", P)
     bases, off = _load_genomes("overpop", dev)

@@ -25,7 +25,7 @@ PARAMS = [
 @pytest.mark.parametrize("k,s,W,S,qS", PARAMS)
 def test_parameters(k, s, W, S, qS):
     eng = importlib.import_module("metacache-mpi_amd.engine")
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     synth = importlib.import_module("metacache-mpi_amd.synth")
     dev = torch.device("cuda", 0)
     gb, goff, species = synth.make_genomes(4, 5, 30_000, 60_000, 0.03, seed=17, device=dev)
@@ -71,7 +71,7 @@ def test_capacity_error_is_reported_not_hidden():
     """a query whose match list exceeds the workspace's per-query capacity gets no result and
     mcq_ws_sync returns MCQ_E_CAPACITY (the reference's analogue: a FAIL log line, src/querying.h:833-847)"""
     eng = importlib.import_module("metacache-mpi_amd.engine")
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     synth = importlib.import_module("metacache-mpi_amd.synth")
     dev = torch.device("cuda", 0)
     gb, goff, species = synth.make_genomes(2, 12, 60_000, 80_000, 0.01, seed=23, device=dev)

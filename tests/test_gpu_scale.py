@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def world():
     eng = importlib.import_module("metacache-mpi_amd.engine")
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     synth = importlib.import_module("metacache-mpi_amd.synth")
     dev = torch.device("cuda", 0)
     gb, goff, species = synth.make_genomes(6, 12, 200_000, 400_000, 0.02, seed=5, device=dev)
@@ -81,7 +81,7 @@ def test_long_reads_take_the_block_path(world):
 def test_db_roundtrip_lookup(world):
     """every key's list comes back from the GPU table exactly (mcq_lookup_count/_gather)"""
     eng, synth, gb, goff, dbs = world
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     dev = torch.device("cuda", 0)
     keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=2)
     species = torch.zeros(goff.numel() - 1, dtype=torch.int64, device=dev)
@@ -145,7 +145,7 @@ def test_many_strains_cross_every_list_size_boundary():
     reads cross the dedup limits (384 locations, 128 distinct keys), the wave kernel's raw-sort sizes and its
     512-location limit into the workgroup kernel -- all in one batch, against the oracle"""
     eng = importlib.import_module("metacache-mpi_amd.engine")
-    dbbuild = importlib.import_module("metacache-mpi_amd.dbbuild")
+    dbbuild = importlib.import_module("dbbuild_torch")
     synth = importlib.import_module("metacache-mpi_amd.synth")
     dev = torch.device("cuda", 0)
     gb, goff, species = synth.make_genomes(3, 36, 100_000, 140_000, 0.012, seed=77, device=dev)
@@ -273,3 +273,43 @@ def test_ragged_lengths_cross_every_window_count(world):
             for qf in (0, eng.MCQ_NO_WAVE16):
                 cands, ncand = ws.query_host(rb, ro, paired, max_cand=M, emulate_ranks=P, flags=qf)
                 _compare(cands, ncand, oc, on, "ragged lengths paired=%d P=%d M=%d qf=%x" % (paired, P, M, qf))
+
+
+def test_more_wide_queries_than_the_old_queue_held():
+    """540 000 pairs of 2 x 250 bp (96 features: back queue of the first stage) whose lists exceed 1024 locations
+    (so the second stage passes every one of them on to the front queue while other waves still drain the back
+    queue).  The two queues of the overflow array must never meet (with max_queries + 2^19 entries the
+    front writes landed on unread back-queue slots and queries were lost or ran twice without any error)."""
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    rng = np.random.default_rng(33)
+    n_tmpl, L, n_tgt, per = 8, 250, 900, 16
+    tmpl = [("".join(rng.choice(list("ACGT"), size=L)), "".join(rng.choice(list("ACGT"), size=L))) for _ in range(n_tmpl)]
+    feats = set()
+    for a, b in tmpl:
+        for sq in (a, b):
+            for w0, w1 in orc.windows(L):
+                feats.update(int(f) for f in orc.sketch(sq[w0:w1].encode()))
+    keys = np.array(sorted(feats), np.uint32)
+    off = (np.arange(len(keys) + 1) * per).astype(np.uint64)
+    t = rng.integers(0, n_tgt, size=len(keys) * per).astype(np.uint64)
+    w = rng.integers(0, 30, size=len(keys) * per).astype(np.uint64)
+    locs = np.sort(((t << np.uint64(32)) | w).reshape(len(keys), per), axis=1).reshape(-1)
+    t2t = (np.arange(n_tgt) // 5).astype(np.uint32)
+    odb = orc.OracleDb(keys, off, locs, t2t)
+    tb, to = orc.pack_reads([s.encode() for pr in tmpl for s in pr])
+    oc, on = odb.query(tb, to, True, max_cand=4, emulate_ranks=2)
+    assert min(len(odb.matches(a, b)) for a, b in tmpl) > 1024
+    nq = 540_000
+    reps = nq // n_tmpl
+    rb = np.tile(np.frombuffer(tb, np.uint8), reps)
+    ro = (np.arange(2 * nq + 1) * L).astype(np.uint64)
+    db = eng.Database(keys, off, locs, t2t)
+    ws = eng.Workspace(db, nq, len(rb))
+    cands, ncand = ws.query_host(rb, ro, True, max_cand=4, emulate_ranks=2)
+    st = ws.sync()
+    assert st["n_overflow"] == nq and st["n_queries"] == nq
+    want_n = np.tile(on, reps)
+    assert np.array_equal(ncand, want_n)
+    want_c = np.tile(oc, (reps, 1, 1))
+    mask = np.arange(4)[None, :] < want_n[:, None]
+    assert np.array_equal(cands[mask], want_c[mask])
