@@ -74,9 +74,13 @@ enum {
  * n_shards/shard_id: this handle stores only keys with mcq_owner(key, n_shards) ==
  * shard_id (the caller may pass all keys; foreign ones are skipped).               */
 typedef struct {
+    /* Limits narrower than the reference's, by construction of the kernels (MCQ_E_UNSUPPORTED beyond them):
+     * k <= 16 is the reference's own limit for 32-bit k-mers (src/config.h:47); winlen <= 128 (`-winlen` is free in
+     * the reference, src/mode_build.cpp:67; one wave holds a window as 2 bases per lane) and sketch_size <= 32 (the
+     * selection network sorts 64 candidates) cover its defaults (128 / 16) and every shipped script.              */
     uint32_t k;               /* k-mer length, 1..16 (src/hash_dna.h:75)              */
     uint32_t sketch_size;     /* s, 1..32 (src/mode_build.cpp:66)                     */
-    uint32_t winlen;          /* query window length, <= 128 (src/sketch_database.h:256) */
+    uint32_t winlen;          /* query window length, k..128 (src/sketch_database.h:256) */
     uint32_t winstride;       /* query window stride                                  */
     uint32_t tgt_winstride;   /* target window stride (range width, classification.cpp:217) */
     uint32_t n_targets;
@@ -110,9 +114,14 @@ typedef struct {
 /* classification_options / candidate_generation_rules subset that the path uses
  * (src/query_options.h:123-135, src/candidates.h:89-101).                            */
 typedef struct {
-    uint32_t max_cand;          /* maxNumCandidatesPerQuery, 1..16 and <= 64/emulate_ranks */
-    uint32_t emulate_ranks;     /* P of the reference run to match (fold order of
-                                   src/querying.h:867-1073); 1 = single list, no fold    */
+    uint32_t max_cand;          /* maxNumCandidatesPerQuery, 1..16.  (The reference's `-maxcand 0` = unbounded list,
+                                   src/query_options.cpp:176-178, is not offered: past 16 entries its std::sort
+                                   is an unstable introsort, so results stop being defined by the inputs.)   */
+    uint32_t emulate_ranks;     /* P of the reference run to match (fold order of src/querying.h:867-1073),
+                                   1..64; 1 = single list, no fold.  While pow2ceil(P) x max_cand <= 64 the P lists
+                                   live in the lanes of one wave; beyond that (the reference's scripted -n 32 / -n 64
+                                   with -maxcand 4, script/ft/QueryGeneric_FT.sh:115) they live in the LDS of the
+                                   workgroup kernel, which then takes every query: same results, ~5x slower    */
     uint64_t insert_size_max;   /* insertSizeMax                                         */
     uint32_t flags;             /* MCQ_QUIRK_SEQ_DROP and the MCQ_FORCE_* / MCQ_NO_WAVE16 test hooks; any other
                                    bit is rejected with MCQ_E_ARG                         */

@@ -26,6 +26,7 @@ typedef uint64_t u64;
 
 #define MCQ_EMPTY 0xFFFFFFFFu
 #define MCQ_MAX_FOLD 64
+#define MCQ_BIGLIST_MAX 1024u        // 64 virtual ranks x 16 candidates
 
 namespace mcq {
 
@@ -59,9 +60,11 @@ __device__ __forceinline__ void seq_bounds(const u64* seq_off, u32 ranges, u64 a
 struct OptDev {
     u32 max_cand;            // M
     u32 P;                   // emulate_ranks
-    u32 seg;                 // lanes per virtual-rank list = 64 / pow2ceil(P)
+    u32 seg;                 // lanes per virtual-rank list = 64 / pow2ceil(P); with `big`: entries per list = M
+    u32 big;                 // pow2ceil(P) x M > 64: the P lists do not fit one wave's lanes -- every query takes the
+                             // workgroup kernel, which keeps them in LDS (MCQ_BIGLIST_MAX entries)
     u32 quirk_seq_drop;
-    u32 hooks;               // test hooks of the staged reduce kernel: 1 = no de-duplicating pass, 2 = no second wave stage
+    u32 hooks;               // staged reduce kernel: 1 = no de-duplicating pass, 2 = no second wave stage, 4 = workgroup kernel only
     u64 insert_size_max;
     u32 n_fold;              // fold schedule: (snd -> rcv) in the reference's order
     u32 n_levels;            // rounds of the tree; the edges of one round touch disjoint ranks
@@ -1178,13 +1181,62 @@ __device__ __forceinline__ u32 topk_all_lds(const DbDev& db, const OptDev& opt, 
 // (64 taxa + 64 HT words) in lane layout -- LDS of the workgroup.
 template <class HT> struct TopkBlockScratch { HT mx[64]; HT lhv[64]; u32 wt[64]; u32 ltax[64]; u32 fmx[64]; u32 fwt[64]; };
 
-template <class KeyT, class HT, int JB, class Sync>
+// Tree fold of P lists of M entries that live in LDS (bl[0..P*M) hits, bl[MCQ_BIGLIST_MAX ..) taxa; hits == 0 marks an
+// unused entry): the emulation of the reference's larger rank counts (mpiexec -n 32 / -n 64 with -maxcand 4,
+// script/ft/QueryGeneric_FT.sh:115) where P x M exceeds the 64 lanes of a wave.  One wave per edge of a tree level
+// (the edges of a level touch disjoint ranks), lanes [0,M) the receiver's entries, [M,2M) the sender's; the same closed
+// form as fold_lists_write: M rounds of "largest (hits, earliest position), record it, retire its taxon".  Then list 0
+// is written; window positions are (0,0) after a fold.  Returns the number of candidates (in every thread of wave 0).
+template <class Sync>
+__device__ __forceinline__ u32 fold_lists_block(const OptDev& opt, const OutDev& out, u32* bl, u64 q, u32 tid, u32 NTB, Sync sync) {
+    const u32 M = opt.max_cand, lane = tid & 63, wv = tid >> 6, nwv = NTB >> 6;
+    u32* hits = bl; u32* tax = bl + MCQ_BIGLIST_MAX;
+    u32 lb = 0;
+    for (u32 L = 0; L < opt.n_levels; ++L) {
+        const u32 le = opt.level_end[L];
+        for (u32 e = lb + wv; e < le; e += nwv) {                 // wave-uniform
+            const u32 snd = opt.fold_snd[e], rcv = opt.fold_rcv[e];
+            const bool is_snd = lane >= M;
+            const u32 src_i = (is_snd ? snd : rcv) * M + (is_snd ? lane - M : lane);
+            u32 h = 0, t = MCQ_EMPTY;
+            if (lane < 2 * M) { h = hits[src_i]; t = tax[src_i]; }
+            if (opt.quirk_seq_drop && is_snd && (t & 0x80000000u)) h = 0;
+            u64 key = h ? (((u64)h << 32) | (u64)(0xFFFFFFFFu - lane)) : 0ull;
+            u32 Nh = 0, Nt = MCQ_EMPTY;
+            for (u32 i = 0; i < M; ++i) {
+                const u64 m = wave_max(key);
+                if (m == 0) break;
+                const u32 src = (u32)__builtin_ctzll(__ballot(key == m));
+                const u32 wtax = bcast(t, src);
+                if (lane == i) { Nh = (u32)(m >> 32); Nt = wtax; }
+                if (key != 0 && t == wtax) key = 0;
+            }
+            wave_sync();                                          // everyone has read the two lists
+            if (lane < M) { hits[rcv * M + lane] = Nh; tax[rcv * M + lane] = Nt; }
+        }
+        lb = le;
+        sync();
+    }
+    u32 n = 0;
+    if (tid < 64) {
+        const u32 h = lane < M ? hits[lane] : 0u;
+        n = (u32)__builtin_popcountll(__ballot(h != 0));
+        if (lane < n) reinterpret_cast<uint4*>(out.cands)[q * M + lane] = make_uint4(tax[lane], h, 0u, 0u);
+        if (lane == 0) out.ncand[q] = n;
+    }
+    return n;
+}
+
+// BIG (a separate instantiation of the workgroup kernels, so that the usual one carries none of it): OptDev::big
+template <class KeyT, class HT, int JB, bool BIG, class Sync>
 __device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* B, HT* H,
                                           u32 T, u32 numWindows, u32 wb, u64 q, u32 tid, u32 NTB,
-                                          TopkBlockScratch<HT>* scr, Sync sync) {
+                                          TopkBlockScratch<HT>* scr, u32* bl, Sync sync) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
+    constexpr bool big = BIG;
     if (tid < 64) { scr->ltax[tid] = MCQ_EMPTY; scr->lhv[tid] = 0; }
+    if constexpr (big) for (u32 i = tid; i < P * M; i += NTB) { bl[i] = 0; bl[MCQ_BIGLIST_MAX + i] = MCQ_EMPTY; }
     for (u32 i = 0; i < M; ++i) {
         if (tid < 64) scr->mx[tid] = 0;
         sync();
@@ -1213,9 +1265,13 @@ __device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, co
             const u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
             if (db.tgt2tax[tgt] == scr->wt[r]) H[j] = 0;            // every head of the winner's taxon retires
         }
-        if (tid < P && scr->mx[tid] != 0) { scr->ltax[tid * seg + i] = scr->wt[tid]; scr->lhv[tid * seg + i] = scr->mx[tid]; }
+        if (tid < P && scr->mx[tid] != 0) {
+            if constexpr (big) { bl[tid * M + i] = (u32)(scr->mx[tid] >> JB); bl[MCQ_BIGLIST_MAX + tid * M + i] = scr->wt[tid]; }
+            else { scr->ltax[tid * seg + i] = scr->wt[tid]; scr->lhv[tid * seg + i] = scr->mx[tid]; }
+        }
         sync();
     }
+    if constexpr (big) return fold_lists_block(opt, out, bl, q, tid, NTB, sync);
     u32 n = 0;
     if (tid < 64) n = fold_lists_write<KeyT, HT, JB>(db, opt, out, B, scr->ltax[tid], scr->lhv[tid], numWindows, wb, q, tid, scr->fmx, scr->fwt);
     return n;

@@ -831,10 +831,10 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
 // Tail of the workgroup path: fill B[0..n2p) through `load(t)`, sort, sweep, top lists.
 // HT/JB: packed (hits << JB | index) word of the sweep: u32 with JB = 13 when the list fits the workgroup's LDS
 // (<= 8192 entries, hits <= 8192), u64 with JB = 32 in global scratch
-template <class KeyT, class HT, int JB, class Fill>
+template <class KeyT, class HT, int JB, bool BIG, class Fill>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
                                            KeyT* B, HT* H, u32 T, u32 numWindows, u32 wb, u64 q, u32 tid,
-                                           const DebugDev& dbg, Fill fill) {
+                                           const DebugDev& dbg, u32* biglist, Fill fill) {
     const u32 n2p = pow2ceil(T), NTB = blockDim.x;
 #ifdef MCQ_SORT_PAD_FULL                                       // tuning knob (A/B): the whole power-of-two network
     const u32 npad = n2p;
@@ -850,7 +850,7 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
     }
     __shared__ TopkBlockScratch<HT> s_topk;
     sweep_targets<KeyT, HT, JB>(B, H, T, numWindows, wb, tid, NTB, s_topk.fmx, [] { __syncthreads(); });
-    const u32 n = topk_block<KeyT, HT, JB>(db, opt, out, B, H, T, numWindows, wb, q, tid, NTB, &s_topk, [] { __syncthreads(); });
+    const u32 n = topk_block<KeyT, HT, JB, BIG>(db, opt, out, B, H, T, numWindows, wb, q, tid, NTB, &s_topk, biglist, [] { __syncthreads(); });
     if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
     __syncthreads();
 }
@@ -859,7 +859,7 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
 // 32-bit keys: 8192 x (4 + 4) B = 64 KB of LDS and 64 VGPRs, so two 1024-thread workgroups share a CU -- the phases
 // of a query are serialised by workgroup barriers, and the second workgroup fills the gaps (+45 % on 8 kb reads;
 // <4096, 512> with four per CU is slower: 15 % of those reads then sort in global scratch).
-template <class KeyT, int LCAPB, int NT>
+template <class KeyT, int LCAPB, int NT, bool BIG = false>
 __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                       CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg) {
     static_assert(LCAPB <= 8192, "packed sweep word: 13 index bits");
@@ -867,6 +867,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     __shared__ KeyT s_buf[LCAPB];
     __shared__ u32 s_hits[LCAPB];
     __shared__ u32 s_w[20];
+    __shared__ u32 s_biglist[BIG ? 2 * MCQ_BIGLIST_MAX : 1];       // P lists of M entries when they do not fit a wave (OptDev::big)
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 W = db.winlen, S = db.winstride;
@@ -981,8 +982,8 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             }
         };
         // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
-        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, fill);
-        else                           block_tail<KeyT, u64, 32>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, fill);
+        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, s_biglist, fill);
+        else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, s_biglist, fill);
     }
 }
 
@@ -1123,9 +1124,9 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
     if (lane == 0) ovf_init(s_ovf[wave]);
     for (u64 q = (u64)blockIdx.x * 4 + wave; q < nq; q += nwaves) {
         const u64 b0 = loc_off[q], T64 = loc_off[q + 1] - b0;
-        if (T64 > (u64)LCAP) {                  // the same two queues as in k_query_wave
+        if (T64 > (u64)LCAP || (opt.hooks & 4)) {   // the same two queues as in k_query_wave
             if (lane == 0) {
-                if (sizeof(KeyT) == 4 && T64 <= (u64)MCQ_LCAP_WAVE16 && !(opt.hooks & 2)) ovf_push(s_ovf[wave], 1, ctr, ovf_list, nq, (u32)q);
+                if (sizeof(KeyT) == 4 && T64 > (u64)LCAP && T64 <= (u64)MCQ_LCAP_WAVE16 && !(opt.hooks & 6)) ovf_push(s_ovf[wave], 1, ctr, ovf_list, nq, (u32)q);
                 else ovf_push(s_ovf[wave], 0, ctr, ovf_list, nq, (u32)q);
             }
             continue;
@@ -1199,11 +1200,12 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db,
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
 }
 
-template <class KeyT, int LCAPB>
+template <class KeyT, int LCAPB, bool BIG = false>
 __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
                                                        ScratchDev sc, const u64* loc_off, const KeyT* locs, const u32* query_len) {
     __shared__ KeyT s_buf[LCAPB];
     __shared__ u32 s_hits[LCAPB];
+    __shared__ u32 s_biglist[BIG ? 2 * MCQ_BIGLIST_MAX : 1];
     const u32 tid = threadIdx.x;
     KeyT* gbuf = reinterpret_cast<KeyT*>(sc.gbuf + (u64)blockIdx.x * sc.lmax);
     u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
@@ -1219,12 +1221,13 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
             continue;
         }
         const u32 T = (u32)T64;
+        if (T == 0) { if (tid == 0) out.ncand[q] = 0; continue; }
         if (tid == 0) atomicAdd(&ctr->n_locations, (unsigned long long)T);
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         auto fill = [&](KeyT* B) { for (u32 t = tid; t < T; t += 1024) B[t] = locs[b0 + t]; };
         // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
-        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, fill);
-        else                           block_tail<KeyT, u64, 32>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, fill);
+        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, s_biglist, fill);
+        else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, s_biglist, fill);
     }
 }
 
@@ -1483,13 +1486,15 @@ static int make_opt(const mcq_query_opts* o, OptDev& d) {
     u32 P = o->emulate_ranks ? o->emulate_ranks : 1;
     if (P > 64) return fail(MCQ_E_UNSUPPORTED, "emulate_ranks > 64");
     u32 p2 = (u32)pow2ceil64(P);
-    u32 seg = 64 / p2;
-    if (o->max_cand < 1 || o->max_cand > 16 || o->max_cand > seg)
-        return fail(MCQ_E_UNSUPPORTED, "max_cand must be in 1..16 and <= 64/pow2ceil(emulate_ranks)");
+    if (o->max_cand < 1 || o->max_cand > 16) return fail(MCQ_E_UNSUPPORTED, "max_cand must be in 1..16");
     memset(&d, 0, sizeof(d));
-    d.max_cand = o->max_cand; d.P = P; d.seg = seg;
+    // P lists of M entries side by side in the 64 lanes of a wave when they fit; else (the reference's -n 32 / -n 64
+    // runs with -maxcand 4) in the LDS of the workgroup kernel, which then takes every query
+    d.big = p2 * o->max_cand > 64 ? 1 : 0;
+    d.max_cand = o->max_cand; d.P = P; d.seg = d.big ? o->max_cand : 64 / p2;
     d.quirk_seq_drop = (o->flags & MCQ_QUIRK_SEQ_DROP) ? 1 : 0;
-    d.hooks = ((o->flags & MCQ_FORCE_RAW_SORT) ? 1u : 0u) | ((o->flags & MCQ_NO_WAVE16) ? 2u : 0u);
+    d.hooks = ((o->flags & MCQ_FORCE_RAW_SORT) ? 1u : 0u) | ((o->flags & MCQ_NO_WAVE16) ? 2u : 0u) |
+              (((o->flags & MCQ_FORCE_BLOCK_PATH) || d.big) ? 4u : 0u);
     d.insert_size_max = o->insert_size_max;
     std::vector<std::pair<u32, u32>> sched;
     std::vector<u32> level_end;
@@ -1733,10 +1738,11 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
         else     hipLaunchKernelGGL(k_query_wave16<false>, g16, dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, dbg);
     }
     rc = tm.mark(); if (rc) return rc;
-    if (db->d.compact) hipLaunchKernelGGL((k_query_block<u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT>), dim3(ws->n_block_wgs), dim3(MCQ_BLOCK_NT), 0, st, db->d, b, od, o, ws->ctr,
-                                          (const u32*)ws->ovf_list, ws->sc, dbg);
-    else               hipLaunchKernelGGL((k_query_block<u64, kLcapBlock, 1024>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, b, od, o, ws->ctr,
-                                          (const u32*)ws->ovf_list, ws->sc, dbg);
+#define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, db->d, b, od, o, ws->ctr, \
+                                                             (const u32*)ws->ovf_list, ws->sc, dbg)
+    if (db->d.compact) { if (od.big) MCQ_LAUNCH_BLOCK(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, true); else MCQ_LAUNCH_BLOCK(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, false); }
+    else               { if (od.big) MCQ_LAUNCH_BLOCK(u64, kLcapBlock, 1024, true); else MCQ_LAUNCH_BLOCK(u64, kLcapBlock, 1024, false); }
+#undef MCQ_LAUNCH_BLOCK
     rc = tm.end(); if (rc) return rc;
     HIPCHK(hipGetLastError());
     ws->last_nq = b.nq;
@@ -1773,7 +1779,7 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     if (!dev_out) { o.cands = ws->d_cands; o.ncand = ws->d_ncand; }
     else { o.cands = (u32*)out->cands; o.ncand = out->n_cand; }
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
-    rc = launch_query(db, ws, b, od, o, st, force_bits(opt->flags), dbg);
+    rc = launch_query(db, ws, b, od, o, st, force_bits(opt->flags) | (od.big ? 1 : 0), dbg);
     if (rc) return rc;
     if (!dev_out && nq) {
         HIPCHK(hipMemcpyAsync(out->cands, ws->d_cands, nq * od.max_cand * 16, hipMemcpyDeviceToHost, st));
@@ -1961,15 +1967,19 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
         hipLaunchKernelGGL(k_reduce_wave16, dim3(grid_for(ws->cap_reduce16, (n_queries + 3) / 4)), dim3(256), 0, st, db->d, od, o, ws->ctr,
                            (const u32*)ws->ovf_list, n_queries, loc_off, (const u32*)locs, query_len);
         rc = tm.mark(); if (rc) return rc;
-        hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
-                           (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len);
+        if (od.big) hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, true>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len);
+        else        hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, false>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len);
     } else {
         hipLaunchKernelGGL((k_reduce_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
                            n_queries, loc_off, (const u64*)locs, query_len);
         rc = tm.mark(); if (rc) return rc;
         rc = tm.mark(); if (rc) return rc;
-        hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
-                           (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
+        if (od.big) hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, true>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
+        else        hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, false>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
     }
     rc = tm.end(); if (rc) return rc;
     HIPCHK(hipGetLastError());

@@ -16,8 +16,11 @@ Runs only in the build container (needs /root/reference and oracle/_ref, built b
     P<p>/final.json                                 CLI -tophits + classification
   tie/                row-11 fold-order case (4 identical genomes, P = 2 vs 4)
   noanc/              target without an ancestor at -lowest species (wire quirk)
+  overpop/            -remove-overpopulated-features build
+  wide/               64 targets at P = 16, 32, 64 with -maxcand 4 (the reference's scripted rank counts);
+                      shards + CLI output only
 
-usage: python tests/golden/make_golden.py [--only kat|mini|tie|noanc]
+usage: python tests/golden/make_golden.py [--only kat|mini|tie|noanc|overpop|wide]
 """
 import argparse
 import gzip
@@ -177,13 +180,13 @@ def parse_tophits(col):
     return out
 
 
-def ref_query_cli(work, name, P, maxcand, lowest, extra=()):
+def ref_query_cli(work, name, P, maxcand, lowest, extra=(), query_limit=64):
     out = os.path.join(work, "out_P%d.txt" % P)
     if os.path.exists(out):
         os.remove(out)
     sh([os.path.join("/opt/conda/bin/mpiexec"), "-n", str(P), os.path.join(REF, "metacache_mpi"),
         "query", name, "r1.fq", "r2.fq", "-pairfiles", "-lowest", lowest, "-threads", "2",
-        "-maxcand", str(maxcand), "-hitmin", "4", "-hitdiff", "80", "-query-limit", "64",
+        "-maxcand", str(maxcand), "-hitmin", "4", "-hitdiff", "80", "-query-limit", str(query_limit),
         "-tophits", "-taxids-only", "-omit-ranks", "-out", out] + list(extra), cwd=work)
     res = {}
     with open(out) as f:
@@ -233,7 +236,7 @@ def sample_reads(rng, genomes, n_pairs, rlen_lo=100, rlen_hi=150, err=0.01):
     return names, r1, r2, truth
 
 
-def run_db_fixture(tag, nodes, genomes, names, r1, r2, Ps, maxcand, lowest, build_extra=()):
+def run_db_fixture(tag, nodes, genomes, names, r1, r2, Ps, maxcand, lowest, build_extra=(), dumps=True, query_limit=64):
     outdir = os.path.join(HERE, tag)
     shutil.rmtree(outdir, ignore_errors=True)
     os.makedirs(outdir)
@@ -259,11 +262,18 @@ def run_db_fixture(tag, nodes, genomes, names, r1, r2, Ps, maxcand, lowest, buil
         os.makedirs(pd)
         ref_build(work, tag, P, build_extra)
         for r in range(P):
-            shutil.copy(os.path.join(work, "%s.db_%d" % (tag, r)), pd)
+            if dumps:
+                shutil.copy(os.path.join(work, "%s.db_%d" % (tag, r)), pd)
+            else:           # many small shard files: stored gzipped (golden_util.Fixture unpacks them)
+                with open(os.path.join(work, "%s.db_%d" % (tag, r)), "rb") as fi, \
+                        gzip.GzipFile(os.path.join(pd, "%s.db_%d.gz" % (tag, r)), "wb", mtime=0) as fo:
+                    fo.write(fi.read())
         dump = ref_ranks_dump(work, tag, P, maxcand, lowest)
+        if not dumps:       # many ranks: keep the fixture small, the per-rank dumps of the other fixtures cover rows 7-10
+            dump["M"], dump["T"], dump["C"] = {}, {}, {}
         with gzip.open(os.path.join(pd, "ranks.json.gz"), "wt") as f:
             json.dump(dump, f, separators=(",", ":"))
-        final = ref_query_cli(work, tag, P, maxcand, lowest)
+        final = ref_query_cli(work, tag, P, maxcand, lowest, query_limit=query_limit)
         with open(os.path.join(pd, "final.json"), "w") as f:
             json.dump(final, f, separators=(",", ":"))
         ncls = sum(1 for v in final.values() if v["best"])
@@ -376,6 +386,30 @@ def make_overpop():
                    build_extra=("-remove-overpopulated-features",))
 
 
+def make_wide():
+    rng = random.Random(19)
+    # the reference's scripted rank counts: -n 32 and -n 64 with -maxcand 4 (script/ft/QueryGeneric_FT.sh:115,
+    # script/ft/queries_s4/Run_Query_AFS31_64_8T_S4.sh:2) and -n 16: 64 small targets (every one of 64 ranks
+    # owns one: the reference segfaults in `query` when a rank's shard is empty), 16 species x 4 strains in 4 genera,
+    # so that a read's candidates sit on many ranks and ties between strains decide the fold
+    nodes = [(1, 1, "no rank", "root"), (2, 1, "superkingdom", "Bacteria")]
+    for g in range(4):
+        nodes.append((100 + g, 2, "genus", "Gen%d" % g))
+    genomes = []
+    for sp in range(16):
+        taxid = 1000 + sp
+        nodes.append((taxid, 100 + sp % 4, "species", "Gen%d sp%d" % (sp % 4, sp)))
+        anc = rand_seq(rng, 1600)
+        if sp % 3 == 1:                      # sister species share half of their sequence with the previous one
+            anc = genomes[-1][2][:800] + anc[800:]
+        for st in range(4):
+            seq = anc if st == 3 and sp % 2 == 0 else mutate(rng, anc, 0.03 if st else 0.0)   # some exact duplicates
+            genomes.append(("NC_%06d.1" % (len(genomes) + 1), taxid, seq))
+    names, r1, r2, _ = sample_reads(rng, genomes, 150)
+    run_db_fixture("wide", nodes, genomes, names, r1, r2, Ps=(16, 32, 64), maxcand=4, lowest="species", dumps=False,
+                   query_limit=128)   # one block of 2 threads x 128 reads: at -n 64 the reference segfaults in a trailing block whose second thread gets no reads
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -383,6 +417,6 @@ if __name__ == "__main__":
     if not os.path.isdir("/root/reference"):
         sys.exit("needs /root/reference (build container only)")
     ensure_mpilib()
-    todo = [a.only] if a.only else ["kat", "mini", "tie", "noanc", "overpop"]
+    todo = [a.only] if a.only else ["kat", "mini", "tie", "noanc", "overpop", "wide"]
     for t in todo:
-        {"kat": make_kat, "mini": make_mini, "tie": make_tie, "noanc": make_noanc, "overpop": make_overpop}[t]()
+        {"kat": make_kat, "mini": make_mini, "tie": make_tie, "noanc": make_noanc, "overpop": make_overpop, "wide": make_wide}[t]()

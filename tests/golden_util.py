@@ -1,13 +1,17 @@
 """Loaders for the committed golden fixtures (tests/golden/, made by make_golden.py)."""
+import atexit
 import gzip
 import json
 import os
+import shutil
+import tempfile
 
 import numpy as np
 
 from oracle import dbfile
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_unpacked = {}
 
 
 def load_kat():
@@ -28,6 +32,15 @@ class Fixture:
         with open(os.path.join(d, "P%d" % P, "final.json")) as f:
             self.final = json.load(f)
         self.shard_paths = [os.path.join(d, "P%d" % P, "%s.db_%d" % (tag, r)) for r in range(P)]
+        if not os.path.exists(self.shard_paths[0]):         # stored gzipped (many-rank fixtures): unpack once per process
+            tmp = _unpacked.get((tag, P))
+            if tmp is None:
+                tmp = _unpacked[(tag, P)] = tempfile.mkdtemp(prefix="golden_%s_P%d_" % (tag, P))
+                atexit.register(shutil.rmtree, tmp, True)
+                for sp in self.shard_paths:
+                    with gzip.open(sp + ".gz", "rb") as fi, open(os.path.join(tmp, os.path.basename(sp)), "wb") as fo:
+                        fo.write(fi.read())
+            self.shard_paths = [os.path.join(tmp, os.path.basename(sp)) for sp in self.shard_paths]
         self.shards = [dbfile.parse_shard(p) for p in self.shard_paths]
         self.tax = dbfile.Taxonomy(self.shards[0]["taxa"])
         self.n_targets = self.shards[0]["target_count"]

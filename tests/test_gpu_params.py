@@ -59,7 +59,7 @@ def test_rejected_parameters():
         assert e.value.code in (eng.MCQ_E_UNSUPPORTED, eng.MCQ_E_ARG)
     db = eng.Database(*z)
     ws = eng.Workspace(db, 4, 64)
-    for kw in (dict(max_cand=0), dict(max_cand=17), dict(max_cand=16, emulate_ranks=8), dict(emulate_ranks=65)):
+    for kw in (dict(max_cand=0), dict(max_cand=17), dict(emulate_ranks=65), dict(flags=0x1000)):
         with pytest.raises(eng.McqError):
             ws.query_host(b"ACGT", np.array([0, 4], np.uint64), False, **kw)
     # an empty database answers every query with no candidates
@@ -113,7 +113,7 @@ def _reduce_against_oracle(make_lists):
     qlen = torch.full((len(lists),), 150, dtype=torch.int32, device=dev)
     doff = torch.from_numpy(loc_off).to(dev)
     ws = eng.Workspace(db, len(lists), 1)
-    for P, M in ((1, 4), (2, 2)):
+    for P, M in ((1, 4), (2, 2), (32, 4)):          # (32, 4): lists in the workgroup kernel's LDS
         for flags in (0, eng.MCQ_FORCE_RAW_SORT):
             cands = torch.zeros((len(lists), M, 4), dtype=torch.int32, device=dev)
             ncand = torch.zeros(len(lists), dtype=torch.int32, device=dev)

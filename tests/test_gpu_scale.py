@@ -123,9 +123,11 @@ def test_db_roundtrip_lookup(world):
         assert total == keys.numel()
 
 
-@pytest.mark.parametrize("P,M", [(3, 2), (5, 4), (6, 4), (8, 4), (8, 8), (16, 4), (32, 2), (64, 1)])
+@pytest.mark.parametrize("P,M", [(3, 2), (5, 4), (6, 4), (8, 4), (8, 8), (16, 4), (32, 2), (64, 1),
+                                 (32, 4), (64, 4), (16, 16), (8, 16), (33, 3), (64, 16), (24, 7)])
 def test_fold_orders_of_other_rank_counts(world, P, M):
-    """tree-fold schedules with several edges per round and the reference's non-power-of-two behaviour"""
+    """tree-fold schedules with several edges per round and the reference's non-power-of-two behaviour; from
+    pow2ceil(P) x M > 64 on (the reference's -n 32 / -n 64 with -maxcand 4) the lists live in the workgroup kernel's LDS"""
     eng, synth, gb, goff, dbs = world
     db, odb = dbs[2]
     n, L = 20000, 150
