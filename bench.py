@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 KERNELS = {"fused": ("k_query_wave", "k_query_wave16", "k_query_block"),
-           "staged": ("k_reduce_wave", "k_reduce_wave16", "k_reduce_block")}
+           "sharded": ("k_query_wave<sharded>", "k_query_wave16<sharded>", "k_query_block<sharded>")}
 EXIT_SHARDED_FAILED = 3        # the line is printed (replicas leg), the exit status says the sharded leg failed
 EXIT_PARITY_FAILED = 4         # GPU result differs from the CPU oracle / the fused kernel
 
@@ -116,16 +116,14 @@ def main():
         os.write(real_stdout, (json.dumps(obj) + "\n").encode())
 
     dist = None
-    if world > 1 or a.mode == "sharded":
+    if world > 1:
+        # control plane (barriers, the max over ranks, carrying the RCCL id): torch.distributed over gloo.  The data
+        # plane of the sharded path is the engine's own RCCL communicator (ncclSend / ncclRecv groups, csrc/mcq_shard.hpp).
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local),
-                                    timeout=datetime.timedelta(seconds=300))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU")
     dev = torch.device("cuda", local % torch.cuda.device_count())
@@ -200,12 +198,17 @@ def main():
     max_bases = max(int(o[-1].item()) for o in offsets)
     nq = B // 2 if paired else B
     sharded = None
-    n_win_per_batch = None
-    if a.workload != "long":
-        n_win_per_batch = B * (1 if L <= 128 else ((L - 128) // 113 + 1 + (1 if ((L - 128) // 113 + 1) * 113 < L else 0)))
     if with_sharded:
-        sh = importlib.import_module("metacache-mpi_amd.sharded")
-        sharded = sh.ShardedQuery(db_shard, world, rank, dev, max_queries=nq, max_bases=max_bases, read_len_hint=L)
+        sharded = eng.Shard(db_shard, world, rank, max_queries=nq, max_bases=max_bases, max_seqs=B)
+        if world > 1:
+            if a.backend == "nccl":
+                box = [eng.Shard.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                sharded.comm_rccl(box[0])
+            else:       # rehearsal on a box with one GPU: blocks through the host and gloo
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from shard_exchange_gloo import make_gloo_exchange
+                sharded.set_exchange(make_gloo_exchange())
     ws = eng.Workspace(db, nq, max_bases) if with_fused else None
     cands = torch.zeros((nq, a.max_cand, 4), dtype=torch.int32, device=dev)
     ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
@@ -217,9 +220,9 @@ def main():
 
     def step_sharded(i):
         # the next step's batch is announced so that its sketching runs on the second stream under this step's exchange
-        nxt = (batches[(i + 1) % nb], offsets[(i + 1) % nb], B) if i + 1 < a.warmup + a.steps else None
-        sharded.query(batches[i % nb], offsets[i % nb], B, paired, cands_s, ncand_s, max_cand=a.max_cand,
-                      emulate_ranks=a.emulate_ranks, n_win_hint=n_win_per_batch, next_batch=nxt)
+        nxt = (batches[(i + 1) % nb].data_ptr(), offsets[(i + 1) % nb].data_ptr(), B) if i + 1 < a.warmup + a.steps else None
+        sharded.query(batches[i % nb].data_ptr(), offsets[i % nb].data_ptr(), B, paired, cands_s.data_ptr(), ncand_s.data_ptr(),
+                      max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=a.query_flags, stream=stream, next_batch=nxt)
 
     def step_fused(i):
         r, ro = batches[i % nb], offsets[i % nb]
@@ -243,7 +246,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+            t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
@@ -275,11 +278,16 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            sharded.be.ws.timing(True)
+            # the first batch of a context runs in the exact mode and learns the block sizes of the padded mode (host
+            # round trips); it is an extra untimed step in front of the warmup
+            step_sharded(0)
+            sharded.sync(stream)
+            sharded.timing(True)
             sharded_elapsed = timed(step_sharded)
-            sh_stats = sharded.last_stats()
-            sh_kms, sh_kn = sharded.be.ws.kernel_times()
-            sharded.be.ws.timing(False)
+            sh_stats = sharded.sync(stream)
+            sh_kms, sh_kn = sharded.kernel_times()
+            sharded.timing(False)
+            sh_stats["exchange_block_features_locations"] = list(sharded.caps())
             if with_fused:
                 # same batch through the fused kernel on the replicated table: bit-identical results expected on every rank
                 last = a.warmup + a.steps - 1
@@ -288,7 +296,7 @@ def main():
                 okn = bool(torch.equal(ncand, ncand_s))
                 m = torch.arange(a.max_cand, device=dev)[None, :] < ncand[:, None]
                 okc = bool(torch.equal(cands[m], cands_s[m]))
-                flag = torch.tensor([1 if (okn and okc) else 0], dtype=torch.int32, device=dev if a.backend == "nccl" else "cpu")
+                flag = torch.tensor([1 if (okn and okc) else 0], dtype=torch.int32)
                 if world > 1:
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 sharded_ok = bool(flag.item())
@@ -310,8 +318,8 @@ def main():
                              "achieved = algorithmic bytes per batch / SUM of the three kernels' times; `kernel` = the one with the largest share" % n_batches,
               "algorithmic_bytes_per_launch": algo, "bytes_per_read": algo / B, "launches_timed": n_batches,
               "per_launch": {k: stats[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow") if k in stats}}
-        if kind == "staged":
-            rf["kernel_note"] += "; the sketch / lookup / gather kernels of the sharded path are not in this sum -- see whole_step"
+        if kind == "sharded":
+            rf["kernel_note"] += "; k_shard_sketch / k_shard_lookup and the exchange are not in this sum -- see whole_step"
             rf["whole_step"] = {"achieved": algo / (elapsed / a.steps) / 1e9, "frac": algo / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
                                 "note": "algorithmic bytes / ms_per_step (exchange included): the conservative figure for the sharded path"}
         # HBM traffic per launch from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
@@ -368,7 +376,7 @@ def main():
         if sharded_error:
             out["sharded_error"] = sharded_error
         if mode == "sharded" and sh_kn:
-            out["roofline"] = roofline("staged", sh_kms, sh_kn, sh_stats, sharded_elapsed)
+            out["roofline"] = roofline("sharded", sh_kms, sh_kn, sh_stats, sharded_elapsed)
             if kn:
                 out["roofline"]["fused_kernel_on_replica"] = roofline("fused", kms, kn, st, fused_elapsed)
         elif kn:

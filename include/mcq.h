@@ -230,6 +230,67 @@ int mcq_ws_timing(mcq_ws* ws, int enable);
 int mcq_ws_kernel_times(mcq_ws* ws, double* ms /* [3] */, uint64_t* n_batches);
 int mcq_ws_kernel_time(mcq_ws* ws, double* total_ms, uint64_t* n_batches);
 
+/* ---- feature-sharded multi-GPU path behind one call (csrc/mcq_shard.hpp) ----------------------
+ * One process per GPU.  Replaces, for a table that is partitioned over n_ranks GPUs, what mcq_query replaces on one:
+ * the worker body of query_batched_parallel2 and the MPI tree merge (src/querying.h:792-825, :867-1073).  The table
+ * is partitioned by hash range of h2(feature) (mcq_owner) instead of the reference's tgt % P
+ * (src/sketch_database.h:540-542); every rank queries its own reads; features travel to their owners and location
+ * lists back (two exchanges per batch), the reduce kernels read the received lists in place.  Results equal
+ * mcq_query's on the whole table, bit for bit (emulate_ranks reproduces the reference's fold order as there).
+ *
+ * Transport of the exchanges: RCCL (ncclSend / ncclRecv groups on the call's stream; librccl is loaded at run time)
+ * after mcq_shard_comm_rccl, a device copy when n_ranks == 1, or the caller's function (mcq_shard_set_exchange;
+ * synchronous: the engine waits for the stream before calling it).
+ *
+ * All calls are collective: every rank makes the same calls with the same flags in the same order.               */
+typedef struct mcq_shard mcq_shard;
+#define MCQ_SHARD_UNIQUE_ID_BYTES 128
+enum { MCQ_SHARD_EXACT = 1u };   /* mcq_shard_query flags: exchange exact sizes (count exchanges through the host) */
+
+typedef struct {
+    uint32_t n_ranks;                  /* 1..32 */
+    uint32_t rank;
+    uint64_t max_queries;              /* per batch and rank */
+    uint64_t max_seqs;                 /* 0 = max_queries (2 x for pairs) */
+    uint64_t max_bases;                /* per batch and rank: bounds the number of windows */
+    uint64_t max_locs_per_query;       /* as in mcq_ws_create; 0 = default */
+    uint64_t max_features_per_peer;    /* capacity of one peer's feature block; 0 = twice the even share of the batch */
+    uint64_t max_locations_per_peer;   /* capacity of one peer's location block; 0 = 768 x max_queries / n_ranks + 2^20.
+                                          Identical on every rank.  A block that overflows is reported by mcq_shard_sync
+                                          as MCQ_E_CAPACITY (never answered wrongly in silence)                       */
+} mcq_shard_cfg;
+
+/* moves send_bytes[p] bytes at send_base + send_off[p] to rank p and receives recv_bytes[p] bytes from rank p at
+ * recv_base + recv_off[p], p = 0 .. n_ranks-1 (device pointers; own rank included); returns 0 on success, and only
+ * when the received bytes are in place                                                                            */
+typedef int (*mcq_exchange_fn)(void* user, const void* send_base, const uint64_t* send_off, const uint64_t* send_bytes,
+                               void* recv_base, const uint64_t* recv_off, const uint64_t* recv_bytes,
+                               uint32_t n_ranks, uint32_t rank);
+
+int mcq_shard_create(const mcq_db* shard /* n_shards = n_ranks, shard_id = rank */, const mcq_shard_cfg* cfg, mcq_shard** out);
+int mcq_shard_destroy(mcq_shard* ctx);
+/* rank 0 makes the id (ncclGetUniqueId), the launcher carries it to the other ranks (the reference's world would use
+ * MPI_Bcast; bench.py a torch.distributed broadcast), every rank passes it to mcq_shard_comm_rccl (ncclCommInitRank) */
+int mcq_shard_unique_id(void* out /* MCQ_SHARD_UNIQUE_ID_BYTES */);
+int mcq_shard_comm_rccl(mcq_shard* ctx, const void* unique_id);
+int mcq_shard_set_exchange(mcq_shard* ctx, mcq_exchange_fn fn, void* user);
+/* One batch (device pointers).  Default (padded mode): every block travels at a fixed size learned from the last exact
+ * batch (largest count any rank saw, plus a quarter), its count inside it: the call only enqueues work, no host
+ * round trip.  The first batch of a context, and any batch with MCQ_SHARD_EXACT, exchanges exact sizes after two
+ * count exchanges through the host.  `next` (may be NULL): the batch of the following call, resident in device
+ * memory -- its sketching is enqueued on a second stream now and runs under this batch's exchange.                   */
+int mcq_shard_query(mcq_shard* ctx, const mcq_batch* in, const mcq_query_opts* opt, mcq_result* out, void* stream,
+                    uint32_t flags, const mcq_batch* next);
+/* as mcq_ws_sync; MCQ_E_CAPACITY also when a block of the exchange was too small since the last sync (repeat those
+ * batches with MCQ_SHARD_EXACT)                                                                                      */
+int mcq_shard_sync(mcq_shard* ctx, void* stream, mcq_stats* stats);
+/* block sizes of the padded mode (features / locations per peer); setting them skips the learning batch */
+int mcq_shard_set_caps(mcq_shard* ctx, uint64_t features_per_peer, uint64_t locations_per_peer);
+int mcq_shard_get_caps(const mcq_shard* ctx, uint64_t* features_per_peer, uint64_t* locations_per_peer);
+/* timing of the home side's reduce kernels, as mcq_ws_timing / mcq_ws_kernel_times */
+int mcq_shard_timing(mcq_shard* ctx, int enable);
+int mcq_shard_kernel_times(mcq_shard* ctx, double* ms /* [3] */, uint64_t* n_batches);
+
 /* ---- row f4: FASTQ ingest on the GPU ------------------------------------------------
  * text: raw FASTQ bytes in DEVICE memory (4 lines per record, as fastq_reader::read_next reads
  * them: src/sequence_io.cpp:251-285).  Writes the (begin,end) byte range of every record's

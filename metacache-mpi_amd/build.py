@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _HDR = os.path.join(os.path.dirname(_HERE), "include", "mcq.h")
 # translation unit -> what it depends on besides itself
 _UNITS = {
-    os.path.join(_HERE, "csrc", "mcq_engine.hip"): [os.path.join(_HERE, "csrc", "mcq_device.hpp"), _HDR],
+    os.path.join(_HERE, "csrc", "mcq_engine.hip"): [os.path.join(_HERE, "csrc", "mcq_device.hpp"), os.path.join(_HERE, "csrc", "mcq_shard.hpp"), _HDR],
     os.path.join(_HERE, "csrc", "mcq_build.hip"): [_HDR],       # table construction (rocPRIM sorts)
 }
 _OBJ = os.path.join(_HERE, "csrc", "_obj")
@@ -68,7 +68,7 @@ def build_hip(force=False, verbose=False):
         elif os.path.exists(out) and os.path.getmtime(out) < os.path.getmtime(obj):
             relink = True
     if relink:
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out, "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -94,6 +94,37 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
 static_assert(offsetof(CountersDev, probe_buf) == 256, "probe_buf sits 256 bytes into the block");
 #define MCQ_CTR_ZEROED offsetof(CountersDev, probe_buf)
 
+// ---- feature-sharded path: what a home rank's reduce kernels read instead of sketching and probing ------------
+// The home rank sent every feature slot of the batch (slot = global window index x s + i) to the rank that owns the
+// feature; slot_pos remembers where it went (owner << 27 | position in that owner's feature block, MCQ_EMPTY for an
+// unused slot).  The owner answered per feature, in block order, with the inclusive end of the feature's location
+// list inside its tile of MCQ_SHARD_TILE features, per tile with the start of the tile's lists inside the
+// owner's location block, and with the lists themselves.  So a probe result (off, len) is three small loads away,
+// and `off` indexes the received location buffer: the reduce kernels gather from it as the fused kernels do from
+// the table, the exchanged lists are never copied again.
+#define MCQ_SHARD_TILE 1024u
+#define MCQ_SHARD_POS_BITS 27
+#define MCQ_SHARD_MAX_RANKS 32u
+struct ShardDev {
+    const u32* slot_pos;     // [n_slots]
+    const u32* ends;         // owner o's list ends start at ends + o * ends_stride
+    const u32* tile_base;    // owner o's tile starts at tile_base + o * tile_stride
+    const u64* win_off;      // [n_seqs + 1]: first global window of every sequence
+    u32 ends_stride;         // u32 words between two owners' list ends
+    u32 tile_stride;         // u32 words between two owners' tile starts
+    u64 capL;                // locations per peer block
+};
+__device__ __forceinline__ void shard_fetch(const ShardDev& sh, u64 slot, u64& off, u32& len) {
+    off = 0; len = 0;
+    const u32 sp = sh.slot_pos[slot];
+    if (sp == MCQ_EMPTY) return;
+    const u32 o = sp >> MCQ_SHARD_POS_BITS, pos = sp & ((1u << MCQ_SHARD_POS_BITS) - 1);
+    const u32* e = sh.ends + (u64)o * sh.ends_stride + pos;
+    const u32 e1 = e[0], e0 = (pos & (MCQ_SHARD_TILE - 1)) ? e[-1] : 0u;
+    len = e1 - e0;
+    off = (u64)o * sh.capL + sh.tile_base[(u64)o * sh.tile_stride + (pos / MCQ_SHARD_TILE)] + e0;
+}
+
 // ---- overflow queues ---------------------------------------------------------------------------------
 // One array, two queues: the front one grows from index 0, the back one downwards from the array's last entry.  A wave
 // reserves MCQ_OVF_CHUNK slots per global atomic (with most of a batch overflowing, one atomic per query on a

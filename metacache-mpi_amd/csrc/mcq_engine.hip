@@ -546,9 +546,11 @@ __device__ __forceinline__ void tap_distinct(const DebugDev& dbg, const u32* SK,
     }
 }
 
-template <class KeyT, int LCAP, bool TAP = false>
+// SH (feature-sharded path, home rank): the same kernel, but the probe results of a query's feature slots come from the
+// exchange (shard_fetch) instead of sketch + probe, and db.locs is the received location buffer.
+template <class KeyT, int LCAP, bool TAP = false, bool SH = false>
 __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
-                                                    CountersDev* ctr, u32* ovf_list, int force_block, DebugDev dbg) {
+                                                    CountersDev* ctr, u32* ovf_list, int force_block, DebugDev dbg, ShardDev sh) {
     static_assert(LCAP == 512, "wave path: 8 keys per lane at most, entry index packed into 9 bits");
     __shared__ KeyT s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
@@ -584,6 +586,10 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         u32 myf = MCQ_EMPTY, nfeat = 0, T = 0, len = 0, pos = 0;
         u64 off = 0;
         if (!ovf) {
+            if constexpr (SH) {
+                nfeat = (g.nw1 + g.nw2) * db.s;          // feature slots (unused ones have no list)
+                if (lane < nfeat) shard_fetch(sh, sh.win_off[b.paired ? 2 * q : q] * db.s + lane, off, len);
+            } else {
             for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
                 u64 at; u32 wl;
                 window_span(db, g, w, at, wl);
@@ -593,6 +599,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
             if (stop == 1) { if (myf == 12345u) out.ncand[q] = nfeat; continue; }
             probe(db, myf, off, len);
             if (stop == 2) { if (len == 0x7FFFFFFFu) out.ncand[q] = (u32)off; continue; }
+            }
             u32 incl = wave_incl_scan_dpp(len);
             pos = incl - len;
             T = bcast(incl, 63);
@@ -615,12 +622,14 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                 wave_sync();                           // the slot lane 0 just took: next - 1 of the back queue
                 const u32 slot = s_ovf[wave][1] - 1;
                 ctr->probe_buf[(u64)slot * 64 + lane] = (off << 16) | len;
-                st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0));     // counted here, not in the second stage
+                if constexpr (!SH) st_feat += nfeat;
+                st_hit += (u32)__builtin_popcountll(__ballot(len > 0));     // counted here, not in the second stage
             }
 #endif
             continue;
         }
-        st_feat += nfeat; st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
+        if constexpr (!SH) st_feat += nfeat;             // (sharded: the sketch kernel counted the features)
+        st_hit += (u32)__builtin_popcountll(__ballot(len > 0)); st_loc += T;
         if constexpr (TAP) { if (dbg.mode == 1 && lane == 0) dbg.match_cnt[q] = T; }
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
 
@@ -679,8 +688,8 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         wave_sync();
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, b.nq);
-    if (lane == 0 && (st_feat | st_loc)) {
-        atomicAdd(&ctr->n_features, st_feat);
+    if (lane == 0 && (st_feat | st_loc | st_hit)) {
+        if (st_feat) atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);
         atomicAdd(&ctr->n_locations, st_loc);
         atomicAdd(&ctr->n_cands, st_cand);
@@ -696,9 +705,9 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 #ifndef MCQ_WAVE16_OCC
 #define MCQ_WAVE16_OCC 4        // waves per SIMD it is compiled for: 5 fit the LDS, but then 10 VGPRs spill (+30 % time)
 #endif
-template <bool TAP = false>
+template <bool TAP = false, bool SH = false>
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, BatchDev b, OptDev opt, OutDev out,
-                                                                      CountersDev* ctr, u32* ovf_list, DebugDev dbg) {
+                                                                      CountersDev* ctr, u32* ovf_list, DebugDev dbg, ShardDev sh) {
     constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
     __shared__ u32 s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
@@ -727,6 +736,13 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         } else
 #endif
         {
+            if constexpr (SH) {                        // feature slots of the exchange, two per lane
+                nfeat = (g.nw1 + g.nw2) * db.s;
+                two = nfeat > 64;
+                const u64 sb = sh.win_off[b.paired ? 2 * q : q] * db.s;
+                if (lane < nfeat) shard_fetch(sh, sb + lane, off0, len0);
+                if (two && 64 + lane < nfeat) shard_fetch(sh, sb + 64 + lane, off1, len1);
+            } else {
             for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
                 u64 at; u32 wl;
                 window_span(db, g, w, at, wl);
@@ -737,6 +753,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             const u32 myf1 = (two && 64 + lane < nfeat) ? feat[64 + lane] : MCQ_EMPTY;
             probe(db, myf0, off0, len0);
             if (two) probe(db, myf1, off1, len1);
+            }
         }
         const u32 incl0 = wave_incl_scan_dpp(len0);
         const u32 T0 = bcast(incl0, 63);
@@ -760,7 +777,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
 #else
         if (g.wide) {                                  // (the first stage counted the features of the others)
 #endif
-            st_feat += nfeat;
+            if constexpr (!SH) st_feat += nfeat;
             st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
         }
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
@@ -796,8 +813,8 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         wave_sync();
     }
     if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
-    if (lane == 0 && (st_feat | st_loc)) {
-        atomicAdd(&ctr->n_features, st_feat);
+    if (lane == 0 && (st_feat | st_loc | st_hit)) {
+        if (st_feat) atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);
         atomicAdd(&ctr->n_locations, st_loc);
         atomicAdd(&ctr->n_cands, st_cand);
@@ -859,9 +876,9 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
 // 32-bit keys: 8192 x (4 + 4) B = 64 KB of LDS and 64 VGPRs, so two 1024-thread workgroups share a CU -- the phases
 // of a query are serialised by workgroup barriers, and the second workgroup fills the gaps (+45 % on 8 kb reads;
 // <4096, 512> with four per CU is slower: 15 % of those reads then sort in global scratch).
-template <class KeyT, int LCAPB, int NT, bool BIG = false>
+template <class KeyT, int LCAPB, int NT, bool BIG = false, bool SH = false>
 __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
-                                                      CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg) {
+                                                      CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg, ShardDev sh) {
     static_assert(LCAPB <= 8192, "packed sweep word: 13 index bits");
     constexpr u32 NW16 = NT / 64;
     __shared__ KeyT s_buf[LCAPB];
@@ -903,6 +920,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         u64* foff = f_lds ? reinterpret_cast<u64*>(s_hits + 4096) : g_foff;
         if (tid == 0) { s_w[18] = 0; s_w[19] = 0; }
         __syncthreads();
+        if constexpr (!SH) {
         for (u32 w = wave; w < (u32)NW; w += NW16) {
             const bool m2 = w >= nw1;
             const u64 n = m2 ? n2 : n1;
@@ -917,11 +935,13 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             wave_sync();
         }
         __syncthreads();
-        const u32 F = s_w[18];
+        }
+        const u32 F = SH ? (u32)(NW * db.s) : s_w[18];     // sharded: every feature slot of the query (unused ones have no list)
         u32 nhit = 0;
         for (u32 i = tid; i < F; i += NT) {
             u64 off; u32 len;
-            probe(db, feat[i], off, len);
+            if constexpr (SH) shard_fetch(sh, sh.win_off[a] * db.s + i, off, len);
+            else probe(db, feat[i], off, len);
             foff[i] = off; fpos[i] = len; nhit += (len > 0);
         }
         nhit = wave_incl_scan_dpp(nhit);
@@ -929,7 +949,8 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         __syncthreads();
         const u32 T = block_excl_scan(fpos, F, tid, s_w);
         if (tid == 0) {
-            atomicAdd(&ctr->n_features, (unsigned long long)F); atomicAdd(&ctr->n_locations, (unsigned long long)T);
+            if (!SH) atomicAdd(&ctr->n_features, (unsigned long long)F);
+            atomicAdd(&ctr->n_locations, (unsigned long long)T);
             atomicAdd(&ctr->n_hit_features, (unsigned long long)s_w[19]);
         }
         if (dbg.mode == 1) { if (tid == 0) dbg.match_cnt[q] = T; }
@@ -1647,9 +1668,9 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     if (const char* e = getenv("MCQ_BLOCK_WGS")) ws->n_block_wgs = std::max(1, atoi(e));      // tuning knob
     ws->ev_used = new std::vector<TimedLaunch>();
     ws->ev_free = new std::vector<TimedLaunch>();
-    ws->cap_wave = db->d.compact ? resident_blocks(k_query_wave<u32, 512>, 256, db->device)
-                                 : resident_blocks(k_query_wave<u64, 512>, 256, db->device);
-    ws->cap_wave16 = resident_blocks(k_query_wave16<false>, 256, db->device);
+    ws->cap_wave = db->d.compact ? resident_blocks(k_query_wave<u32, 512, false, false>, 256, db->device)
+                                 : resident_blocks(k_query_wave<u64, 512, false, false>, 256, db->device);
+    ws->cap_wave16 = resident_blocks(k_query_wave16<false, false>, 256, db->device);
     ws->cap_reduce16 = resident_blocks(k_reduce_wave16, 256, db->device);
     const u64 nb = (u64)ws->n_block_wgs;
 #define WSCHK(expr) HIPCHK_OR(expr, (void)mcq_ws_destroy(ws))
@@ -1718,30 +1739,39 @@ struct LaunchTimer {
     }
 };
 
+// sh != nullptr: the feature-sharded home side (SH instantiations; dbd = the handle's DbDev with `locs` pointing at the
+// received location buffer); the counters are then zeroed by the caller (the sketch kernel has already counted)
 static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const OptDev& od, const OutDev& o,
-                        hipStream_t st, int force_block, const DebugDev& dbg) {
-    HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
+                        hipStream_t st, int force_block, const DebugDev& dbg, const ShardDev* shp = nullptr, const DbDev* dbd = nullptr) {
+    if (!shp) HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
     if (b.nq == 0) return MCQ_OK;
+    ShardDev sh; memset(&sh, 0, sizeof(sh));
+    if (shp) sh = *shp;
+    const DbDev& D = dbd ? *dbd : db->d;
     const u64 want = (b.nq + 3) / 4;
     const u32 grid = grid_for(ws->cap_wave, want);
     LaunchTimer tm(ws, st);
     int rc = tm.begin(); if (rc) return rc;
     const bool tap = dbg.mode != 0;     // mcq_debug_matches: the instantiations that also write the sorted match lists
-#define MCQ_LAUNCH_WAVE(KT, TAPV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV>), dim3(grid), dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg)
-    if (db->d.compact) { if (tap) MCQ_LAUNCH_WAVE(u32, true); else MCQ_LAUNCH_WAVE(u32, false); }
-    else               { if (tap) MCQ_LAUNCH_WAVE(u64, true); else MCQ_LAUNCH_WAVE(u64, false); }
+#define MCQ_LAUNCH_WAVE(KT, TAPV, SHV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV, SHV>), dim3(grid), dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg, sh)
+    if (shp)                { if (db->d.compact) MCQ_LAUNCH_WAVE(u32, false, true); else MCQ_LAUNCH_WAVE(u64, false, true); }
+    else if (db->d.compact) { if (tap) MCQ_LAUNCH_WAVE(u32, true, false); else MCQ_LAUNCH_WAVE(u32, false, false); }
+    else                    { if (tap) MCQ_LAUNCH_WAVE(u64, true, false); else MCQ_LAUNCH_WAVE(u64, false, false); }
 #undef MCQ_LAUNCH_WAVE
     rc = tm.mark(); if (rc) return rc;
     if (db->d.compact) {   // second wave stage (back queue); no queue for 64-bit keys
         const dim3 g16(grid_for(ws->cap_wave16, want));
-        if (tap) hipLaunchKernelGGL(k_query_wave16<true>, g16, dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, dbg);
-        else     hipLaunchKernelGGL(k_query_wave16<false>, g16, dim3(256), 0, st, db->d, b, od, o, ws->ctr, ws->ovf_list, dbg);
+        if (shp)      hipLaunchKernelGGL((k_query_wave16<false, true>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh);
+        else if (tap) hipLaunchKernelGGL((k_query_wave16<true, false>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh);
+        else          hipLaunchKernelGGL((k_query_wave16<false, false>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh);
     }
     rc = tm.mark(); if (rc) return rc;
-#define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, db->d, b, od, o, ws->ctr, \
-                                                             (const u32*)ws->ovf_list, ws->sc, dbg)
-    if (db->d.compact) { if (od.big) MCQ_LAUNCH_BLOCK(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, true); else MCQ_LAUNCH_BLOCK(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, false); }
-    else               { if (od.big) MCQ_LAUNCH_BLOCK(u64, kLcapBlock, 1024, true); else MCQ_LAUNCH_BLOCK(u64, kLcapBlock, 1024, false); }
+#define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV, SHV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV, SHV>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, D, b, od, o, ws->ctr, \
+                                                             (const u32*)ws->ovf_list, ws->sc, dbg, sh)
+#define MCQ_LAUNCH_BLOCK2(KT, LC, NTH, SHV) do { if (od.big) MCQ_LAUNCH_BLOCK(KT, LC, NTH, true, SHV); else MCQ_LAUNCH_BLOCK(KT, LC, NTH, false, SHV); } while (0)
+    if (db->d.compact) { if (shp) MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, true); else MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, false); }
+    else               { if (shp) MCQ_LAUNCH_BLOCK2(u64, kLcapBlock, 1024, true); else MCQ_LAUNCH_BLOCK2(u64, kLcapBlock, 1024, false); }
+#undef MCQ_LAUNCH_BLOCK2
 #undef MCQ_LAUNCH_BLOCK
     rc = tm.end(); if (rc) return rc;
     HIPCHK(hipGetLastError());
@@ -2064,3 +2094,6 @@ extern "C" int mcq_fastq_index(const char* text, uint64_t n_bytes, uint64_t* seq
     HIPCHK(hipGetLastError());
     return MCQ_OK;
 }
+
+// ------------------------------------------------------------------ feature-sharded multi-GPU path (mcq_shard_*)
+#include "mcq_shard.hpp"

@@ -1,0 +1,554 @@
+// mcq_shard.hpp -- the feature-sharded multi-GPU query path behind the C ABI (mcq_shard_* in include/mcq.h).
+// Included at the end of mcq_engine.hip (same translation unit: it launches the SH instantiations of the query kernels).
+//
+// One process per GPU, n_ranks of them.  The feature -> locations table is partitioned by hash range of h2(feature)
+// (mcq_owner); every rank keeps its shard (mcq_db with n_shards = n_ranks, shard_id = rank) and its own reads.  It
+// replaces the reference's per-rank lookups + MPI tree merge (src/querying.h:792-825, :867-1073; the reference
+// partitions by target, tgt % P, src/sketch_database.h:540-542): all locations of a read reach its home rank, so
+// per-target hit counts are the reference's, and the fold order of its P ranks is emulated on the home rank.
+//
+// Per batch, on every rank (all stages enqueued on streams; no host round trip in the padded mode):
+//   S1  k_shard_sketch     home   sketch every window (rows 1-5), route each feature to the block of its owner
+//                                 (workgroup-aggregated cursors), remember slot -> (owner, position)
+//   X1  exchange           feature blocks to their owners
+//   S2  k_shard_lookup     owner  probe (row 6) + copy the lists (row 7) into the requester's location block,
+//                                 per feature the end of its list inside its 1024-feature tile, per tile its start
+//   X2  exchange           list ends / tile starts and location blocks back
+//   S3  k_query_wave<SH> / k_query_wave16<SH> / k_query_block<SH>   home: the fused kernels with the probe results
+//                                 fetched from the exchange instead of sketch + probe (rows 8-11), lists gathered
+//                                 straight out of the received blocks
+// Exchange = ncclSend/ncclRecv groups over RCCL (xGMI), a device copy at n_ranks = 1, or a caller-supplied function
+// (tests: host-staged gloo).  Blocks travel either at fixed, learned sizes with the counts inside them (padded mode)
+// or at exact sizes after two small count exchanges through the host (exact mode, also the fallback after
+// MCQ_E_CAPACITY).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#define MCQ_SHARD_HDR 4u                  // u32 words in front of a feature block: [0] = number of features in it
+#define MCQ_SHARD_WIN_PER_ROUND 4u        // windows a wave sketches between two flushes of its workgroup
+#define MCQ_SHARD_CHUNK (4u * MCQ_SHARD_WIN_PER_ROUND * 32u)     // entries a workgroup buffers: 4 waves x 4 windows x s <= 32
+
+// ------------------------------------------------------------------ S1: sketch + route to owners
+// One wave per sequence (grid-stride), MCQ_SHARD_WIN_PER_ROUND windows per round; the workgroup buffers the
+// features of a round in LDS, counts them per owner there, reserves room in the owners' blocks with ONE global atomic
+// per owner and round (the block's header word is the cursor), then writes features and slot positions.
+__global__ __launch_bounds__(256) void k_shard_sketch(DbDev db, BatchDev b, const u64* win_off, u32 n_ranks,
+                                                      u32* sendF, u32 capF, u32* slot_pos, unsigned long long* feat_cnt, u32* err) {
+    __shared__ u32 s_sk[4][128];
+    __shared__ u32 s_f[MCQ_SHARD_CHUNK], s_slot[MCQ_SHARD_CHUNK], s_olp[MCQ_SHARD_CHUNK];
+    __shared__ u32 s_cnt[MCQ_SHARD_MAX_RANKS], s_base[MCQ_SHARD_MAX_RANKS];
+    __shared__ u32 s_n;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    u32* sk = s_sk[wave];
+    if (tid < MCQ_SHARD_MAX_RANKS) s_cnt[tid] = 0;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const u64 nwaves = (u64)gridDim.x * 4;
+    u64 i = (u64)blockIdx.x * 4 + wave;          // current sequence of this wave
+    u32 j = 0, nw = 0, n = 0;                    // next window, window count, length of it
+    u64 o0 = 0, w0 = 0;
+    bool have = false;
+    unsigned long long st_feat = 0;
+    const u64 blk = (u64)capF + MCQ_SHARD_HDR;
+    while (true) {
+        if (!have && i < b.n_seq) {
+            u64 oe; seq_bounds(b.seq_off, b.ranges, i, o0, oe);
+            n = (u32)(oe - o0); w0 = win_off[i]; nw = (u32)(win_off[i + 1] - w0); j = 0; have = true;
+        }
+        if (!__syncthreads_or(have ? 1 : 0)) break;                  // every wave of the workgroup is out of sequences
+        for (u32 r = 0; r < MCQ_SHARD_WIN_PER_ROUND && have; ++r) {
+            u32 beg, wl;
+            window_of32(n, db.winlen, db.winstride, db.magic_stride, j, beg, wl);
+            const u32 m = wave_sketch(b.bases + o0 + beg, wl, db.k, db.s, lane, sk, sk + 64);
+            st_feat += m;
+            const bool mine = lane < db.s;
+            const u32 f = (mine && lane < m) ? sk[64 + lane] : MCQ_EMPTY;
+            const u32 slot = (u32)((w0 + j) * db.s) + lane;
+            const bool valid = f != MCQ_EMPTY;
+            if (mine && !valid) slot_pos[slot] = MCQ_EMPTY;
+            const u64 vm = __ballot(valid);
+            u32 ebase = 0;
+            if (lane == 0 && vm) ebase = atomicAdd(&s_n, (u32)__builtin_popcountll(vm));
+            ebase = bcast(ebase, 0);
+            if (valid) {
+                const u32 o = (u32)(((u64)tmh(f) * n_ranks) >> 32);
+                const u32 lp = atomicAdd(&s_cnt[o], 1u);
+                const u32 e = ebase + lane_rank(vm);
+                s_f[e] = f; s_slot[e] = slot; s_olp[e] = (o << 16) | lp;
+            }
+            wave_sync();
+            if (++j == nw) { have = false; i += nwaves; }
+        }
+        __syncthreads();
+        if (tid < n_ranks) {
+            const u32 c = s_cnt[tid];
+            s_base[tid] = c ? atomicAdd(&sendF[(u64)tid * blk], c) : 0u;
+            s_cnt[tid] = 0;
+        }
+        __syncthreads();
+        const u32 ne = s_n;
+        for (u32 e = tid; e < ne; e += 256) {
+            const u32 o = s_olp[e] >> 16, pos = s_base[o] + (s_olp[e] & 0xFFFFu);
+            if (pos < capF) { sendF[(u64)o * blk + MCQ_SHARD_HDR + pos] = s_f[e]; slot_pos[s_slot[e]] = (o << MCQ_SHARD_POS_BITS) | pos; }
+            else { slot_pos[s_slot[e]] = MCQ_EMPTY; atomicOr(err, 1u); }          // the owner's block is full
+        }
+        __syncthreads();
+        if (tid == 0) s_n = 0;
+    }
+    if (lane == 0 && st_feat) atomicAdd(feat_cnt, st_feat);
+}
+__global__ void k_shard_add_count(unsigned long long* dst, const unsigned long long* src) { atomicAdd(dst, *src); }
+
+// ------------------------------------------------------------------ S2: owner side, lookup + gather
+// grid = n_ranks x tiles per block; workgroup (p, t) serves features [t*1024, +1024) of the block that came from rank p:
+// four probes in flight per thread, inclusive scan of the list lengths over the tile (feature order), one global
+// atomic per tile for its room in p's location block, then every wave copies the lists of its 64-feature groups.
+// R block of p: [0] = locations served to p so far (the cursor), [1] = features of p seen, then capT tile starts,
+// then capF list ends.
+template <class KeyT>
+__global__ __launch_bounds__(256) void k_shard_lookup(DbDev db, u32 n_ranks, const u32* recvF, u32 capF, u32 capFx, u32 capT,
+                                                      u32* sendR, KeyT* sendL, u64 capL, u32* err) {
+    __shared__ u32 s_wt[4][4];
+    __shared__ u32 s_tbase;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 p = blockIdx.x / capT, t = blockIdx.x - p * capT;
+    const u64 fblk = (u64)capF + MCQ_SHARD_HDR, rblk = (u64)MCQ_SHARD_HDR + capT + capF;
+    const u32* F = recvF + (u64)p * fblk;
+    u32 cnt = F[0];
+    if (cnt > capFx) { cnt = capFx; if (t == 0 && tid == 0) atomicOr(err, 2u); }      // more than a block carries: the sender's error
+    u32* R = sendR + (u64)p * rblk;
+    if (t == 0 && tid == 0) R[1] = cnt;
+    if (t * MCQ_SHARD_TILE >= cnt) return;
+    const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
+    u64 off[4]; u32 len[4], incl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 i = t * MCQ_SHARD_TILE + k * 256 + tid;
+        probe(db, i < cnt ? F[MCQ_SHARD_HDR + i] : MCQ_EMPTY, off[k], len[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        incl[k] = wave_incl_scan_dpp(len[k]);
+        if (lane == 63) s_wt[k][wave] = incl[k];
+    }
+    __syncthreads();
+    u32 before[4], total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if ((u32)w == wave) before[k] = total; total += s_wt[k][w]; }
+    if (tid == 0) {
+        const u32 tb = total ? atomicAdd(&R[0], total) : 0u;
+        s_tbase = tb;
+        R[MCQ_SHARD_HDR + t] = tb;
+        if ((u64)tb + total > capL) atomicOr(err, 4u);                            // p's location block is full
+    }
+    __syncthreads();
+    const u32 tbase = s_tbase;
+    const bool fits = (u64)tbase + total <= capL;
+    KeyT* L = sendL + (u64)p * capL + tbase;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 i = t * MCQ_SHARD_TILE + k * 256 + tid;
+        if (i < cnt) R[MCQ_SHARD_HDR + capT + i] = before[k] + incl[k];
+        if (!fits) continue;
+        // the 64 lists of this wave's group k, copied cooperatively (as k_lookup_gather)
+        const u32 pos = incl[k] - len[k];
+        const u32 Tg = bcast(incl[k], 63);
+        for (u32 base = 0; base < Tg; base += 256) {
+            KeyT v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = 0;
+                if (base + (u32)(u * 64) < Tg) {
+                    const u32 x = base + u * 64 + lane;
+                    const u32 xx = x < Tg ? x : Tg - 1;
+                    u32 lo = 0;
+#pragma unroll
+                    for (u32 step = 32; step > 0; step >>= 1) {
+                        const u32 c = lo + step;
+                        const u32 pc = __shfl(pos, (int)(c & 63), 64);
+                        if (c < 64 && pc <= xx) lo = c;
+                    }
+                    const u32 pj = __shfl(pos, (int)lo, 64);
+                    const u32 olo = __shfl((u32)off[k], (int)lo, 64), ohi = __shfl((u32)(off[k] >> 32), (int)lo, 64);
+                    if (x < Tg) v[u] = locs[(((u64)ohi << 32) | olo) + (xx - pj)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const u32 x = base + u * 64 + lane;
+                if (x < Tg) L[before[k] + x] = v[u];
+            }
+        }
+    }
+}
+
+// zero the cursors / headers of the n_ranks blocks (stride in u32 words)
+__global__ void k_shard_zero_headers(u32* a, u64 stride_a, u32* c, u64 stride_c, u32 n_ranks) {
+    const u32 i = threadIdx.x;
+    if (i < n_ranks) {
+        for (u32 k = 0; k < MCQ_SHARD_HDR; ++k) { a[(u64)i * stride_a + k] = 0; c[(u64)i * stride_c + k] = 0; }
+    }
+}
+// home side after X2: a peer that served more locations than a block carries has truncated this rank's lists
+__global__ void k_shard_check(const u32* recvR, u64 rblk, u32 n_ranks, u64 capLx, u32* err) {
+    const u32 i = threadIdx.x;
+    if (i < n_ranks && (u64)recvR[(u64)i * rblk] > capLx) atomicOr(err, 8u);
+}
+
+// ------------------------------------------------------------------ transports
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+static int rccl_load() {
+    if (g_rccl.lib) return MCQ_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);      // the one torch has loaded, if any; else ROCm's
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(MCQ_E_UNSUPPORTED, std::string("librccl not found: ") + dlerror());
+#define MCQ_SYM(field, name) g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+    if (!g_rccl.field) return fail(MCQ_E_UNSUPPORTED, std::string("librccl lacks ") + name)
+    MCQ_SYM(GetUniqueId, "ncclGetUniqueId"); MCQ_SYM(CommInitRank, "ncclCommInitRank"); MCQ_SYM(CommDestroy, "ncclCommDestroy");
+    MCQ_SYM(Send, "ncclSend"); MCQ_SYM(Recv, "ncclRecv"); MCQ_SYM(GroupStart, "ncclGroupStart"); MCQ_SYM(GroupEnd, "ncclGroupEnd");
+    MCQ_SYM(GetErrorString, "ncclGetErrorString");
+#undef MCQ_SYM
+    g_rccl.lib = h;
+    return MCQ_OK;
+}
+#define NCCLCHK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) \
+    return fail(MCQ_E_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); } while (0)
+
+// ------------------------------------------------------------------ context
+struct ShardBuf {             // the device buffers of one batch in flight
+    u32* sendF = nullptr;     // [n][HDR + capF]
+    u32* slot_pos = nullptr;  // [max_slots]
+    u64* win_off = nullptr;   // [max_seqs + 1]
+    unsigned long long* feat_cnt = nullptr;   // features sketched (for the statistics)
+};
+struct mcq_shard {
+    const mcq_db* db; mcq_ws* ws;
+    int device; u32 n, rank;
+    u64 max_queries, max_seqs, max_slots;
+    u32 capF, capT; u64 capL;             // block capacities (buffers)
+    u32 capFx; u64 capLx;                 // what travels per peer in the padded mode (0 = not learned yet)
+    u32 locb;
+    ShardBuf sb[2]; int cur;              // double-buffered home side: the next batch's S1 runs under this batch's exchange
+    u32* recvF; u32* sendR; u32* recvR; void* sendL; void* recvL;
+    u32* err; u32* err_host;              // device flag word, pinned copy
+    u32* cnt_dev; u32* cnt_host;          // 4 x n words staging of the exact mode's count exchanges
+    hipStream_t side; hipEvent_t ev_prep[2], ev_done[2];
+    bool prepared[2]; const void* prep_key[2][3];
+    // transport
+    ncclComm_t comm; bool have_comm;
+    mcq_exchange_fn xfn; void* xuser;
+    u64 last_nq; u64 sent_features, sent_locations;
+};
+static u64 rblk_words(const mcq_shard* c) { return (u64)MCQ_SHARD_HDR + c->capT + c->capF; }
+static u64 fblk_words(const mcq_shard* c) { return (u64)MCQ_SHARD_HDR + c->capF; }
+
+// moves send_bytes[p] bytes from send_base + p*send_stride to rank p and receives recv_bytes[p] bytes from it at
+// recv_base + p*recv_stride
+static int shard_exchange(mcq_shard* c, const void* send_base, u64 send_stride, const u64* send_bytes,
+                          void* recv_base, u64 recv_stride, const u64* recv_bytes, hipStream_t st) {
+    const u32 n = c->n;
+    if (c->xfn) {                         // caller's transport (host-staged in the tests): synchronous
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<u64> so(n), ro(n);
+        for (u32 p = 0; p < n; ++p) { so[p] = p * send_stride; ro[p] = p * recv_stride; }
+        if (c->xfn(c->xuser, send_base, so.data(), send_bytes, recv_base, ro.data(), recv_bytes, n, c->rank) != 0)
+            return fail(MCQ_E_HIP, "the caller's exchange function failed");
+        return MCQ_OK;
+    }
+    if (n == 1) {
+        if (send_bytes[0] != recv_bytes[0]) return fail(MCQ_E_ARG, "self exchange with different sizes");
+        if (send_bytes[0]) HIPCHK(hipMemcpyAsync(recv_base, send_base, send_bytes[0], hipMemcpyDeviceToDevice, st));
+        return MCQ_OK;
+    }
+    if (!c->have_comm) return fail(MCQ_E_ARG, "no transport: call mcq_shard_comm_rccl or mcq_shard_set_exchange first");
+    NCCLCHK(g_rccl.GroupStart());
+    for (u32 p = 0; p < n; ++p) {
+        if (send_bytes[p]) NCCLCHK(g_rccl.Send((const char*)send_base + p * send_stride, send_bytes[p], ncclUint8, (int)p, c->comm, st));
+        if (recv_bytes[p]) NCCLCHK(g_rccl.Recv((char*)recv_base + p * recv_stride, recv_bytes[p], ncclUint8, (int)p, c->comm, st));
+    }
+    NCCLCHK(g_rccl.GroupEnd());
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_unique_id(void* out128) {
+    if (!out128) return fail(MCQ_E_ARG, "null argument");
+    int rc = rccl_load(); if (rc) return rc;
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == MCQ_SHARD_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(out128, &id, sizeof(id));
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_destroy(mcq_shard* c) {
+    if (!c) return MCQ_OK;
+    (void)hipSetDevice(c->device);
+    if (c->have_comm) (void)g_rccl.CommDestroy(c->comm);
+    for (auto& b : c->sb) { (void)hipFree(b.sendF); (void)hipFree(b.slot_pos); (void)hipFree(b.win_off); (void)hipFree(b.feat_cnt); }
+    (void)hipFree(c->recvF); (void)hipFree(c->sendR); (void)hipFree(c->recvR); (void)hipFree(c->sendL); (void)hipFree(c->recvL);
+    (void)hipFree(c->err); (void)hipHostFree(c->err_host); (void)hipFree(c->cnt_dev); (void)hipHostFree(c->cnt_host);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    for (auto e : c->ev_prep) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_done) if (e) (void)hipEventDestroy(e);
+    (void)mcq_ws_destroy(c->ws);
+    delete c;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, mcq_shard** out) {
+    if (!shard || !cfg || !out) return fail(MCQ_E_ARG, "null argument");
+    if (cfg->n_ranks < 1 || cfg->n_ranks > MCQ_SHARD_MAX_RANKS) return fail(MCQ_E_UNSUPPORTED, "n_ranks must be 1..32");
+    if (cfg->rank >= cfg->n_ranks) return fail(MCQ_E_ARG, "rank >= n_ranks");
+    if (shard->n_shards != cfg->n_ranks || shard->shard_id != cfg->rank)
+        return fail(MCQ_E_ARG, "the handle must be shard `rank` of `n_ranks` (mcq_db_desc.n_shards / shard_id)");
+    const u64 n = cfg->n_ranks;
+    const u64 max_seqs = cfg->max_seqs ? cfg->max_seqs : cfg->max_queries;
+    // a sequence of L bases has at most L / stride + 2 windows
+    const u64 max_win = cfg->max_bases / shard->d.winstride + 2 * max_seqs;
+    const u64 max_slots = max_win * shard->d.s;
+    if (max_slots >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "more than 2^32 feature slots per batch");
+    // block capacities: features hash uniformly over the owners, so twice the even share (plus slack for small batches)
+    // holds any real batch; adversarial ones (all reads alike) are reported as MCQ_E_CAPACITY, never mis-answered
+    u64 capF = cfg->max_features_per_peer ? cfg->max_features_per_peer : std::min<u64>(max_slots, 2 * max_slots / n + 65536);
+    capF = (capF + MCQ_SHARD_TILE - 1) / MCQ_SHARD_TILE * MCQ_SHARD_TILE;
+    if (capF >= (1ull << MCQ_SHARD_POS_BITS)) return fail(MCQ_E_UNSUPPORTED, "more than 2^27 features per peer and batch");
+    const u64 capL = cfg->max_locations_per_peer ? cfg->max_locations_per_peer : (cfg->max_queries * 768 / n + (1u << 20));
+    if (capL >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "more than 2^32 locations per peer and batch");
+    HIPCHK(hipSetDevice(shard->device));
+    mcq_shard* c = new mcq_shard();
+    memset(c, 0, sizeof(*c));
+    c->db = shard; c->device = shard->device; c->n = (u32)n; c->rank = cfg->rank;
+    c->max_queries = cfg->max_queries; c->max_seqs = max_seqs; c->max_slots = max_slots;
+    c->capF = (u32)capF; c->capT = (u32)(capF / MCQ_SHARD_TILE); c->capL = capL;
+    c->locb = shard->d.compact ? 4 : 8;
+    int rc = mcq_ws_create(shard, cfg->max_queries, 1, cfg->max_locs_per_query, &c->ws);
+    if (rc) { delete c; return rc; }
+#define SCHK(expr) HIPCHK_OR(expr, (void)mcq_shard_destroy(c))
+    for (auto& b : c->sb) {
+        SCHK(hipMalloc(&b.sendF, n * fblk_words(c) * 4));
+        SCHK(hipMalloc(&b.slot_pos, std::max<u64>(1, max_slots) * 4));
+        SCHK(hipMalloc(&b.win_off, (max_seqs + 1) * 8));
+        SCHK(hipMalloc(&b.feat_cnt, 8));
+    }
+    SCHK(hipMalloc(&c->recvF, n * fblk_words(c) * 4));
+    SCHK(hipMalloc(&c->sendR, n * rblk_words(c) * 4));
+    SCHK(hipMalloc(&c->recvR, n * rblk_words(c) * 4));
+    SCHK(hipMalloc(&c->sendL, n * capL * c->locb));
+    SCHK(hipMalloc(&c->recvL, n * capL * c->locb));
+    SCHK(hipMalloc(&c->err, 4)); SCHK(hipMemset(c->err, 0, 4));
+    SCHK(hipHostMalloc(&c->err_host, 4));
+    SCHK(hipMalloc(&c->cnt_dev, 4 * n * 8)); SCHK(hipHostMalloc(&c->cnt_host, 4 * n * 8));
+    SCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    for (auto& e : c->ev_prep) SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : c->ev_done) SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+#undef SCHK
+    *out = c;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_comm_rccl(mcq_shard* c, const void* unique_id) {
+    if (!c || !unique_id) return fail(MCQ_E_ARG, "null argument");
+    if (c->n == 1) return MCQ_OK;                     // nothing to connect: blocks are copied on the device
+    int rc = rccl_load(); if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    ncclUniqueId id; memcpy(&id, unique_id, sizeof(id));
+    NCCLCHK(g_rccl.CommInitRank(&c->comm, (int)c->n, id, (int)c->rank));
+    c->have_comm = true;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_set_exchange(mcq_shard* c, mcq_exchange_fn fn, void* user) {
+    if (!c) return fail(MCQ_E_ARG, "null argument");
+    c->xfn = fn; c->xuser = user;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_set_caps(mcq_shard* c, uint64_t features_per_peer, uint64_t locations_per_peer) {
+    if (!c) return fail(MCQ_E_ARG, "null argument");
+    if (features_per_peer > c->capF || locations_per_peer > c->capL) return fail(MCQ_E_ARG, "beyond the buffers' capacity");
+    c->capFx = (u32)features_per_peer; c->capLx = locations_per_peer;
+    return MCQ_OK;
+}
+extern "C" int mcq_shard_get_caps(const mcq_shard* c, uint64_t* features_per_peer, uint64_t* locations_per_peer) {
+    if (!c) return fail(MCQ_E_ARG, "null argument");
+    if (features_per_peer) *features_per_peer = c->capFx;
+    if (locations_per_peer) *locations_per_peer = c->capLx;
+    return MCQ_OK;
+}
+
+// S1 of a batch into buffer slot k, on stream st
+static int shard_prepare(mcq_shard* c, int k, const mcq_batch* in, hipStream_t st) {
+    ShardBuf& b = c->sb[k];
+    int rc = mcq_count_windows(c->db, in, b.win_off, st); if (rc) return rc;
+    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendF, fblk_words(c), b.sendF, fblk_words(c), c->n);
+    HIPCHK(hipMemsetAsync(b.feat_cnt, 0, 8, st));
+    BatchDev bd; bd.bases = in->bases; bd.seq_off = in->seq_off; bd.n_seq = in->n_seqs; bd.nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
+    bd.paired = in->paired ? 1 : 0; bd.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
+    if (in->n_seqs) {
+        const u32 grid = (u32)std::min<u64>((in->n_seqs + 3) / 4, 256ull * 8);
+        hipLaunchKernelGGL(k_shard_sketch, dim3(grid), dim3(256), 0, st, c->db->d, bd, (const u64*)b.win_off, c->n, b.sendF, c->capF,
+                           b.slot_pos, b.feat_cnt, c->err);
+    }
+    HIPCHK(hipGetLastError());
+    return MCQ_OK;
+}
+
+// exact mode helper: my[p] (u64, device) -> theirs[p] on every rank, through the host
+static int shard_exchange_counts(mcq_shard* c, const u64* mine_host, u64* theirs_host, hipStream_t st) {
+    const u32 n = c->n;
+    u64* d_send = reinterpret_cast<u64*>(c->cnt_dev);
+    u64* d_recv = d_send + n;
+    HIPCHK(hipMemcpyAsync(d_send, mine_host, n * 8, hipMemcpyHostToDevice, st));
+    std::vector<u64> eight(n, 8);
+    int rc = shard_exchange(c, d_send, 8, eight.data(), d_recv, 8, eight.data(), st); if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(theirs_host, d_recv, n * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_query_opts* opt, mcq_result* out, void* stream,
+                               uint32_t flags, const mcq_batch* next) {
+    if (!c || !in || !opt || !out) return fail(MCQ_E_ARG, "null argument");
+    if (!(in->flags & MCQ_DEVICE_PTRS) || !(out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the sharded path takes device pointers");
+    if (next && !(next->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the sharded path takes device pointers");
+    OptDev od;
+    int rc = make_opt(opt, od); if (rc) return rc;
+    const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
+    if (nq > c->max_queries || in->n_seqs > c->max_seqs) return fail(MCQ_E_ARG, "batch larger than the context allows");
+    const bool exact = (flags & MCQ_SHARD_EXACT) || c->capFx == 0;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const u32 n = c->n;
+    mcq_ws* ws = c->ws;
+
+    // ---- S1 (unless the previous call already ran it for this batch on the side stream)
+    int k = c->cur;
+    const bool was_prepared = c->prepared[k] && c->prep_key[k][0] == in->bases && c->prep_key[k][1] == in->seq_off &&
+                              c->prep_key[k][2] == (const void*)(uintptr_t)in->n_seqs;
+    if (c->prepared[k]) HIPCHK(hipStreamWaitEvent(st, c->ev_prep[k], 0));      // (a prepared batch that is not this one drains, then is overwritten)
+    if (!was_prepared) { rc = shard_prepare(c, k, in, st); if (rc) return rc; }
+    c->prepared[k] = false;
+    ShardBuf& b = c->sb[k];
+    HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
+
+    std::vector<u64> sbytes(n), rbytes(n), cnt_mine(n), cnt_theirs(n);
+    // ---- X1: feature blocks to their owners
+    u32 capFx = c->capFx; u64 capLx = c->capLx;
+    if (exact) {
+        HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, b.sendF, fblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        u64 mx = 0;
+        for (u32 p = 0; p < n; ++p) { cnt_mine[p] = std::min<u64>(c->cnt_host[p], c->capF); mx = std::max(mx, cnt_mine[p]); }
+        rc = shard_exchange_counts(c, cnt_mine.data(), cnt_theirs.data(), st); if (rc) return rc;
+        for (u32 p = 0; p < n; ++p) { sbytes[p] = (MCQ_SHARD_HDR + cnt_mine[p]) * 4; rbytes[p] = (MCQ_SHARD_HDR + cnt_theirs[p]) * 4; mx = std::max(mx, cnt_theirs[p]); }
+        capFx = c->capF;                                  // the lookup accepts whatever the header says
+        c->sent_features = mx;
+    } else {
+        for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = ((u64)MCQ_SHARD_HDR + capFx) * 4;
+    }
+    rc = shard_exchange(c, b.sendF, fblk_words(c) * 4, sbytes.data(), c->recvF, fblk_words(c) * 4, rbytes.data(), st); if (rc) return rc;
+
+    // ---- the next batch's S1 on the side stream, into the other buffer set: it runs under this batch's exchange, lookup and
+    // reduce.  That set was last read by the reduce kernels of the previous batch (ev_done); the caller guarantees that the
+    // next batch's inputs are resident.
+    if (next && next->n_seqs <= c->max_seqs) {
+        const int k2 = k ^ 1;
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev_done[k2], 0));
+        rc = shard_prepare(c, k2, next, c->side); if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_prep[k2], c->side));
+        c->prepared[k2] = true;
+        c->prep_key[k2][0] = next->bases; c->prep_key[k2][1] = next->seq_off; c->prep_key[k2][2] = (const void*)(uintptr_t)next->n_seqs;
+    }
+
+    // ---- S2: owner side
+    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, c->sendR, rblk_words(c), c->sendR, rblk_words(c), n);
+    if (nq || true) {
+        const dim3 grid(n * c->capT);
+        if (c->db->d.compact) hipLaunchKernelGGL(k_shard_lookup<u32>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)c->recvF, c->capF, capFx, c->capT,
+                                                 c->sendR, (u32*)c->sendL, c->capL, c->err);
+        else                  hipLaunchKernelGGL(k_shard_lookup<u64>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)c->recvF, c->capF, capFx, c->capT,
+                                                 c->sendR, (u64*)c->sendL, c->capL, c->err);
+    }
+    HIPCHK(hipGetLastError());
+
+    // ---- X2: list ends + tile starts, and the location blocks, back to the requesters
+    if (exact) {
+        // ends of the features each peer sent (counts known from X1), locations served to each peer (cursor word of its R block)
+        for (u32 p = 0; p < n; ++p) { sbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_theirs[p]) * 4; rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_mine[p]) * 4; }
+        rc = shard_exchange(c, c->sendR, rblk_words(c) * 4, sbytes.data(), c->recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc;
+        HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, c->sendR, rblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        u64 mx = 0;
+        std::vector<u64> served(n), coming(n);
+        for (u32 p = 0; p < n; ++p) { served[p] = std::min<u64>(c->cnt_host[p], c->capL); mx = std::max(mx, served[p]); }
+        rc = shard_exchange_counts(c, served.data(), coming.data(), st); if (rc) return rc;
+        for (u32 p = 0; p < n; ++p) { sbytes[p] = served[p] * c->locb; rbytes[p] = coming[p] * c->locb; mx = std::max(mx, coming[p]); }
+        rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), c->recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc;
+        c->sent_locations = mx;
+        capLx = c->capL;
+        // learn the padded mode's block sizes: the largest count any rank saw this batch, plus a quarter
+        std::vector<u64> mine2(n, (c->sent_features << 32) | std::min<u64>(c->sent_locations, 0xFFFFFFFFull)), all2(n);
+        rc = shard_exchange_counts(c, mine2.data(), all2.data(), st); if (rc) return rc;
+        u64 gf = 0, gl = 0;
+        for (u32 p = 0; p < n; ++p) { gf = std::max<u64>(gf, all2[p] >> 32); gl = std::max<u64>(gl, all2[p] & 0xFFFFFFFFull); }
+        c->capFx = std::max<u32>(c->capFx, (u32)std::min<u64>(c->capF, (gf + gf / 4 + 4096 + MCQ_SHARD_TILE - 1) / MCQ_SHARD_TILE * MCQ_SHARD_TILE));
+        c->capLx = std::max<u64>(c->capLx, std::min<u64>(c->capL, gl + gl / 4 + 65536));
+    } else {
+        for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + capFx) * 4;
+        rc = shard_exchange(c, c->sendR, rblk_words(c) * 4, sbytes.data(), c->recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc;
+        for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = capLx * c->locb;
+        rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), c->recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc;
+        hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(64), 0, st, (const u32*)c->recvR, rblk_words(c), n, capLx, c->err);
+    }
+
+    // ---- S3: home side, the fused kernels fed from the exchange
+    ShardDev sh;
+    sh.slot_pos = b.slot_pos; sh.ends = c->recvR + MCQ_SHARD_HDR + c->capT; sh.tile_base = c->recvR + MCQ_SHARD_HDR;
+    sh.win_off = b.win_off; sh.ends_stride = (u32)rblk_words(c); sh.tile_stride = (u32)rblk_words(c); sh.capL = c->capL;
+    DbDev dbd = c->db->d; dbd.locs = c->recvL;
+    BatchDev bd; bd.bases = in->bases; bd.seq_off = in->seq_off; bd.n_seq = in->n_seqs; bd.nq = nq; bd.paired = in->paired ? 1 : 0;
+    bd.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
+    OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
+    DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
+    rc = launch_query(c->db, ws, bd, od, o, st, force_bits(opt->flags) | (od.big ? 1 : 0), dbg, &sh, &dbd); if (rc) return rc;
+    hipLaunchKernelGGL(k_shard_add_count, dim3(1), dim3(1), 0, st, &ws->ctr->n_features, (const unsigned long long*)b.feat_cnt);
+    HIPCHK(hipEventRecord(c->ev_done[k], st));            // this buffer set may be overwritten
+    c->last_nq = nq;
+    c->cur = k ^ 1;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_sync(mcq_shard* c, void* stream, mcq_stats* stats) {
+    if (!c) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(c->err_host, c->err, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(c->err, 0, 4, st));
+    int rc = mcq_ws_sync(c->ws, stream, stats);
+    if (stats) stats->n_queries = c->last_nq;
+    const u32 e = *c->err_host;
+    if (e) return fail(MCQ_E_CAPACITY, std::string("a block of the exchange was too small (") + ((e & 1) ? "features to an owner; " : "") +
+                       ((e & 2) ? "features in the padded mode; " : "") + ((e & 4) ? "locations for a requester; " : "") +
+                       ((e & 8) ? "locations in the padded mode; " : "") + "): results of the batches since the last sync are incomplete -- "
+                       "repeat them with MCQ_SHARD_EXACT or larger capacities");
+    return rc;
+}
+
+extern "C" int mcq_shard_timing(mcq_shard* c, int enable) { return c ? mcq_ws_timing(c->ws, enable) : fail(MCQ_E_ARG, "null argument"); }
+extern "C" int mcq_shard_kernel_times(mcq_shard* c, double* ms, uint64_t* n_batches) { return c ? mcq_ws_kernel_times(c->ws, ms, n_batches) : fail(MCQ_E_ARG, "null argument"); }

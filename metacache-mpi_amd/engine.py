@@ -65,6 +65,18 @@ class Stats(C.Structure):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
 
 
+class ShardCfg(C.Structure):
+    _fields_ = [("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("max_queries", C.c_uint64), ("max_seqs", C.c_uint64),
+                ("max_bases", C.c_uint64), ("max_locs_per_query", C.c_uint64), ("max_features_per_peer", C.c_uint64),
+                ("max_locations_per_peer", C.c_uint64)]
+
+
+# mcq_exchange_fn
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p,
+                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_uint32, C.c_uint32)
+MCQ_SHARD_EXACT = 1
+MCQ_SHARD_UNIQUE_ID_BYTES = 128
+
 _lib = None
 
 
@@ -107,6 +119,18 @@ def lib():
         L.mcq_build_last_error.restype = C.c_char_p
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
+        L.mcq_shard_create.argtypes = [C.c_void_p, C.POINTER(ShardCfg), C.POINTER(C.c_void_p)]
+        L.mcq_shard_destroy.argtypes = [C.c_void_p]
+        L.mcq_shard_unique_id.argtypes = [C.c_void_p]
+        L.mcq_shard_comm_rccl.argtypes = [C.c_void_p, C.c_void_p]
+        L.mcq_shard_set_exchange.argtypes = [C.c_void_p, EXCHANGE_FN, C.c_void_p]
+        L.mcq_shard_query.argtypes = [C.c_void_p, C.POINTER(Batch), C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p,
+                                      C.c_uint32, C.POINTER(Batch)]
+        L.mcq_shard_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.mcq_shard_set_caps.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.mcq_shard_get_caps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mcq_shard_timing.argtypes = [C.c_void_p, C.c_int]
+        L.mcq_shard_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -287,6 +311,78 @@ class Workspace:
         m = np.zeros(max(1, int(moff[nq])), np.uint64)
         _chk(lib().mcq_debug_matches(self.db.h, self.h, C.byref(b), path_flags, _np_ptr(moff), _np_ptr(m), len(m)))
         return moff, m[:int(moff[nq])]
+
+
+class Shard:
+    """mcq_shard_*: the feature-sharded multi-GPU path of one rank (one process per GPU).  `db` is this rank's shard
+    (Database(..., n_shards=n_ranks, shard_id=rank)).  All calls are collective."""
+
+    def __init__(self, db, n_ranks, rank, max_queries, max_bases, max_seqs=0, max_locs_per_query=0,
+                 max_features_per_peer=0, max_locations_per_peer=0):
+        self.db, self.n_ranks, self.rank = db, n_ranks, rank
+        cfg = ShardCfg(n_ranks, rank, max_queries, max_seqs, max_bases, max_locs_per_query, max_features_per_peer,
+                       max_locations_per_peer)
+        h = C.c_void_p()
+        _chk(lib().mcq_shard_create(db.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._xfn = None
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(MCQ_SHARD_UNIQUE_ID_BYTES)
+        _chk(lib().mcq_shard_unique_id(buf))
+        return buf.raw
+
+    def comm_rccl(self, unique_id):
+        assert len(unique_id) == MCQ_SHARD_UNIQUE_ID_BYTES
+        _chk(lib().mcq_shard_comm_rccl(self.h, C.create_string_buffer(unique_id, MCQ_SHARD_UNIQUE_ID_BYTES)))
+
+    def set_exchange(self, fn):
+        """fn: an EXCHANGE_FN (kept alive here)"""
+        self._xfn = fn
+        _chk(lib().mcq_shard_set_exchange(self.h, fn, None))
+
+    def query(self, bases_ptr, seq_off_ptr, n_seqs, paired, cands_ptr, ncand_ptr, max_cand=2, emulate_ranks=1,
+              insert_size_max=0, flags=0, stream=None, exact=False, next_batch=None):
+        """next_batch = (bases_ptr, seq_off_ptr, n_seqs) of the following call (resident): sketched under this batch's exchange"""
+        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 1 if paired else 0, MCQ_DEVICE_PTRS)
+        o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
+        r = Result(cands_ptr, ncand_ptr, MCQ_DEVICE_PTRS)
+        nb = None
+        if next_batch is not None:
+            nb = C.byref(Batch(next_batch[2], next_batch[0], next_batch[1], 1 if paired else 0, MCQ_DEVICE_PTRS))
+        _chk(lib().mcq_shard_query(self.h, C.byref(b), C.byref(o), C.byref(r), stream, MCQ_SHARD_EXACT if exact else 0, nb))
+
+    def sync(self, stream=None):
+        st = Stats()
+        _chk(lib().mcq_shard_sync(self.h, stream, C.byref(st)))
+        return st.as_dict()
+
+    def caps(self):
+        f, l = C.c_uint64(0), C.c_uint64(0)
+        _chk(lib().mcq_shard_get_caps(self.h, C.byref(f), C.byref(l)))
+        return int(f.value), int(l.value)
+
+    def set_caps(self, features_per_peer, locations_per_peer):
+        _chk(lib().mcq_shard_set_caps(self.h, features_per_peer, locations_per_peer))
+
+    def timing(self, enable):
+        _chk(lib().mcq_shard_timing(self.h, 1 if enable else 0))
+
+    def kernel_times(self):
+        ms, n = (C.c_double * 3)(), C.c_uint64(0)
+        _chk(lib().mcq_shard_kernel_times(self.h, ms, C.byref(n)))
+        return [float(x) for x in ms], int(n.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcq_shard_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream=None):

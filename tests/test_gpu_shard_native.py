@@ -1,0 +1,129 @@
+"""The native sharded path (mcq_shard_*: csrc/mcq_shard.hpp) against the oracle.
+
+* n_ranks = 1 in-process (device-copy transport): exact and padded mode, prepared next batch, every query class, both
+  location widths, capacity errors reported.
+* 2 and 4 ranks on one GPU, one hash-range shard each, blocks exchanged through gloo by a caller-supplied exchange
+  function (RCCL refuses two ranks on one device): same results as the oracle on every rank.
+"""
+import glob
+import importlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same(cands, ncand, oc, on, what):
+    gc = cands.cpu().numpy().view(np.uint32); gn = ncand.cpu().numpy().view(np.uint32)
+    bad = np.nonzero(gn != on)[0]
+    assert len(bad) == 0, (what, "ncand differs at", bad[:5], gn[bad[:5]], on[bad[:5]])
+    mask = np.arange(gc.shape[1])[None, :] < on[:, None]
+    neq = np.any((gc != oc) & mask[:, :, None], axis=(1, 2))
+    bad = np.nonzero(neq)[0]
+    assert len(bad) == 0, (what, "cands differ at", bad[:5], gc[bad[0]], oc[bad[0]])
+
+
+@pytest.fixture(scope="module")
+def world1():
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    synth = importlib.import_module("metacache-mpi_amd.synth")
+    dev = torch.device("cuda", 0)
+    gb, goff, species = synth.make_genomes(6, 12, 200_000, 400_000, 0.02, seed=5, device=dev)
+    table = eng.Table(gb.data_ptr(), goff.data_ptr(), goff.numel() - 1, emulate_ranks=2)
+    keys, off, locs, _ = table.to_host()
+    sp32 = species.to(torch.int32).contiguous()
+    dbs = {}
+    for f in (0, eng.MCQ_DB_LOCS_64):
+        dbs[f] = eng.Database(None, None, None, None, flags=f,
+                              device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr, tgt2tax=sp32.data_ptr(),
+                                               n_keys=table.n_keys, n_locs=table.n_locs, n_targets=sp32.numel()))
+    table.close()
+    odb = orc.OracleDb(keys, off, locs, species.cpu().numpy().astype(np.uint32))
+    return eng, synth, dev, gb, goff, dbs, odb
+
+
+@pytest.mark.parametrize("locs64", [0, 1])
+def test_one_rank_every_query_class(world1, locs64):
+    eng, synth, dev, gb, goff, dbs, odb = world1
+    db = dbs[eng.MCQ_DB_LOCS_64 if locs64 else 0]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for paired, L, n in ((False, 150, 40000), (True, 150, 40000), (False, 500, 6000), (True, 250, 6000), (False, 6000, 300)):
+        batches = []
+        for sd in (1, 2):
+            if paired:
+                r, ro, _ = synth.sample_pairs(gb, goff, n // 2, L, 300, 700, 0.01, 0.002, seed=100 * L + sd)
+            else:
+                r, ro, _ = synth.sample_reads(gb, goff, n, L, 0.01, 0.002, seed=100 * L + sd)
+            batches.append((r, ro))
+        nq = n // 2 if paired else n
+        sh = eng.Shard(db, 1, 0, max_queries=nq, max_bases=n * L, max_seqs=n)
+        for P, M in ((2, 2), (4, 4), (32, 4)):
+            for i, (r, ro) in enumerate(batches + batches[:1]):
+                nxt = batches[(i + 1) % 2] if i < 2 else None
+                cands = torch.zeros((nq, M, 4), dtype=torch.int32, device=dev); ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
+                sh.query(r.data_ptr(), ro.data_ptr(), n, paired, cands.data_ptr(), ncand.data_ptr(), max_cand=M, emulate_ranks=P, stream=st,
+                         next_batch=None if nxt is None else (nxt[0].data_ptr(), nxt[1].data_ptr(), n))
+                stats = sh.sync(st)
+                oc, on, ost = odb.query(r.cpu().numpy().tobytes(), ro.cpu().numpy().astype(np.uint64), paired, max_cand=M, emulate_ranks=P,
+                                        threads=8, want_stats=True)
+                _same(cands, ncand, oc, on, "paired=%d L=%d P=%d M=%d batch %d" % (paired, L, P, M, i))
+                assert stats["n_queries"] == nq and stats["n_features"] == int(ost[0]) and stats["n_locations"] == int(ost[2]), (stats, ost)
+        f, l = sh.caps()
+        assert f > 0 and l > 0            # learned from the first (exact) batch
+        sh.close()
+
+
+def test_capacity_errors_are_reported(world1):
+    eng, synth, dev, gb, goff, dbs, odb = world1
+    db = dbs[0]
+    st = torch.cuda.current_stream(dev).cuda_stream
+    n, L = 20000, 150
+    r, ro, _ = synth.sample_reads(gb, goff, n, L, 0.01, 0.002, seed=77)
+    cands = torch.zeros((n, 2, 4), dtype=torch.int32, device=dev); ncand = torch.zeros(n, dtype=torch.int32, device=dev)
+    # location blocks far too small for the batch
+    sh = eng.Shard(db, 1, 0, max_queries=n, max_bases=n * L, max_locations_per_peer=4096)
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), stream=st)
+    with pytest.raises(eng.McqError) as e:
+        sh.sync(st)
+    assert e.value.code == eng.MCQ_E_CAPACITY
+    sh.close()
+    # padded blocks smaller than the batch needs: reported, and the exact mode then answers correctly
+    sh = eng.Shard(db, 1, 0, max_queries=n, max_bases=n * L)
+    sh.set_caps(1024, 4096)
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+    with pytest.raises(eng.McqError) as e:
+        sh.sync(st)
+    assert e.value.code == eng.MCQ_E_CAPACITY
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st, exact=True)
+    sh.sync(st)
+    oc, on = odb.query(r.cpu().numpy().tobytes(), ro.cpu().numpy().astype(np.uint64), False, max_cand=2, emulate_ranks=2, threads=8)
+    _same(cands, ncand, oc, on, "exact mode after a capacity error")
+    sh.close()
+
+
+@pytest.mark.parametrize("paired,world,locs64", [(0, 2, 0), (1, 2, 1), (0, 4, 0)])
+def test_ranks_on_one_gpu_over_gloo(paired, world, locs64):
+    with tempfile.TemporaryDirectory() as d:
+        outp = os.path.join(d, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29800 + paired + 10 * world),
+               os.path.join(ROOT, "tests", "shard_native_worker.py"), outp, str(paired), str(locs64)]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        files = sorted(glob.glob(outp + ".*.npz"))
+        assert len(files) == world
+        for f in files:
+            z = np.load(f)
+            assert bool(z["ok"][0]), f
+            assert (z["overflow"] >= (36 if paired else 72)).all(), z["overflow"]     # wide and long reads left the first stage
+            assert (z["caps"] > 0).all()
