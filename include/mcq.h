@@ -255,7 +255,8 @@ typedef struct {
     uint64_t max_bases;                /* per batch and rank: bounds the number of windows */
     uint64_t max_locs_per_query;       /* as in mcq_ws_create; 0 = default */
     uint64_t max_features_per_peer;    /* capacity of one peer's feature block; 0 = twice the even share of the batch */
-    uint64_t max_locations_per_peer;   /* capacity of one peer's location block; 0 = 768 x max_queries / n_ranks + 2^20.
+    uint64_t max_locations_per_peer;   /* capacity of one peer's location block; 0 = 16 per feature slot the batch can have
+                                          (max_bases / stride x sketch size), shared out over the ranks, + 2^20.
                                           Identical on every rank.  A block that overflows is reported by mcq_shard_sync
                                           as MCQ_E_CAPACITY (never answered wrongly in silence)                       */
 } mcq_shard_cfg;

@@ -119,10 +119,15 @@ __device__ __forceinline__ void shard_fetch(const ShardDev& sh, u64 slot, u64& o
     const u32 sp = sh.slot_pos[slot];
     if (sp == MCQ_EMPTY) return;
     const u32 o = sp >> MCQ_SHARD_POS_BITS, pos = sp & ((1u << MCQ_SHARD_POS_BITS) - 1);
+    const u32* tb = sh.tile_base + (u64)o * sh.tile_stride;
+    if (pos >= tb[-3]) return;               // header word 1 of the owner's answer: the features it served (a block that
+                                             // travelled truncated answers only those; the error is flagged elsewhere)
     const u32* e = sh.ends + (u64)o * sh.ends_stride + pos;
     const u32 e1 = e[0], e0 = (pos & (MCQ_SHARD_TILE - 1)) ? e[-1] : 0u;
+    const u64 start = (u64)tb[pos / MCQ_SHARD_TILE] + e0;
+    if (start + (e1 - e0) > sh.capL) return; // the owner's location block was full: nothing was copied for this list
     len = e1 - e0;
-    off = (u64)o * sh.capL + sh.tile_base[(u64)o * sh.tile_stride + (pos / MCQ_SHARD_TILE)] + e0;
+    off = (u64)o * sh.capL + start;
 }
 
 // ---- overflow queues ---------------------------------------------------------------------------------

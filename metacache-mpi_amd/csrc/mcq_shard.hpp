@@ -9,7 +9,7 @@
 //
 // Per batch, on every rank (all stages enqueued on streams; no host round trip in the padded mode):
 //   S1  k_shard_sketch     home   sketch every window (rows 1-5), route each feature to the block of its owner
-//                                 (workgroup-aggregated cursors), remember slot -> (owner, position)
+//                                 (per-wave chunk reservations), remember slot -> (owner, position)
 //   X1  exchange           feature blocks to their owners
 //   S2  k_shard_lookup     owner  probe (row 6) + copy the lists (row 7) into the requester's location block,
 //                                 per feature the end of its list inside its 1024-feature tile, per tile its start
@@ -24,40 +24,35 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#define MCQ_SHARD_HDR 4u                  // u32 words in front of a feature block: [0] = number of features in it
-#define MCQ_SHARD_WIN_PER_ROUND 4u        // windows a wave sketches between two flushes of its workgroup
-#define MCQ_SHARD_CHUNK (4u * MCQ_SHARD_WIN_PER_ROUND * 32u)     // entries a workgroup buffers: 4 waves x 4 windows x s <= 32
+#define MCQ_SHARD_HDR 4u                  // u32 words in front of a feature block: [0] = number of feature positions in it
 
 // ------------------------------------------------------------------ S1: sketch + route to owners
-// One wave per sequence (grid-stride), MCQ_SHARD_WIN_PER_ROUND windows per round; the workgroup buffers the
-// features of a round in LDS, counts them per owner there, reserves room in the owners' blocks with ONE global atomic
-// per owner and round (the block's header word is the cursor), then writes features and slot positions.
-__global__ __launch_bounds__(256) void k_shard_sketch(DbDev db, BatchDev b, const u64* win_off, u32 n_ranks,
+// One wave per sequence (grid-stride), no workgroup barriers.  A wave keeps, per owner, a reservation of `chunk`
+// positions in that owner's feature block (next / left in its LDS words; the block's header word is the global
+// cursor, one atomic per chunk), hands the features of a window out of it -- one round per distinct owner among
+// the window's <= s features: ballot of the lanes with that owner, ranks by mbcnt -- and records slot -> (owner,
+// position).  What is left of a chunk when a window does not fit, or when the wave ends, is filled with MCQ_EMPTY:
+// the owner's lookup skips such positions without a memory access.  chunk = the wave's expected share of an owner's
+// block / 8, so the filler stays below an eighth of the block and the atomics on one cursor at ~8 per wave.
+__global__ __launch_bounds__(256) void k_shard_sketch(DbDev db, BatchDev b, const u64* win_off, u32 n_ranks, u32 chunk,
                                                       u32* sendF, u32 capF, u32* slot_pos, unsigned long long* feat_cnt, u32* err) {
     __shared__ u32 s_sk[4][128];
-    __shared__ u32 s_f[MCQ_SHARD_CHUNK], s_slot[MCQ_SHARD_CHUNK], s_olp[MCQ_SHARD_CHUNK];
-    __shared__ u32 s_cnt[MCQ_SHARD_MAX_RANKS], s_base[MCQ_SHARD_MAX_RANKS];
-    __shared__ u32 s_n;
-    const u32 tid = threadIdx.x, lane = tid & 63;
-    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ u32 s_res[4][2 * MCQ_SHARD_MAX_RANKS];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32* sk = s_sk[wave];
-    if (tid < MCQ_SHARD_MAX_RANKS) s_cnt[tid] = 0;
-    if (tid == 0) s_n = 0;
-    __syncthreads();
+    u32* res = s_res[wave];                          // [2 o] next position, [2 o + 1] positions left of owner o's chunk
+    if (lane < 2 * n_ranks) res[lane] = 0;
+    wave_sync();
     const u64 nwaves = (u64)gridDim.x * 4;
-    u64 i = (u64)blockIdx.x * 4 + wave;          // current sequence of this wave
-    u32 j = 0, nw = 0, n = 0;                    // next window, window count, length of it
-    u64 o0 = 0, w0 = 0;
-    bool have = false;
-    unsigned long long st_feat = 0;
     const u64 blk = (u64)capF + MCQ_SHARD_HDR;
-    while (true) {
-        if (!have && i < b.n_seq) {
-            u64 oe; seq_bounds(b.seq_off, b.ranges, i, o0, oe);
-            n = (u32)(oe - o0); w0 = win_off[i]; nw = (u32)(win_off[i + 1] - w0); j = 0; have = true;
-        }
-        if (!__syncthreads_or(have ? 1 : 0)) break;                  // every wave of the workgroup is out of sequences
-        for (u32 r = 0; r < MCQ_SHARD_WIN_PER_ROUND && have; ++r) {
+    unsigned long long st_feat = 0;
+    for (u64 i = (u64)blockIdx.x * 4 + wave; i < b.n_seq; i += nwaves) {
+        u64 o0, oe; seq_bounds(b.seq_off, b.ranges, i, o0, oe);
+        const u32 n = (u32)(oe - o0);
+        const u64 w0 = win_off[i];
+        const u32 nw = (u32)(win_off[i + 1] - w0);
+        for (u32 j = 0; j < nw; ++j) {
             u32 beg, wl;
             window_of32(n, db.winlen, db.winstride, db.magic_stride, j, beg, wl);
             const u32 m = wave_sketch(b.bases + o0 + beg, wl, db.k, db.s, lane, sk, sk + 64);
@@ -67,34 +62,36 @@ __global__ __launch_bounds__(256) void k_shard_sketch(DbDev db, BatchDev b, cons
             const u32 slot = (u32)((w0 + j) * db.s) + lane;
             const bool valid = f != MCQ_EMPTY;
             if (mine && !valid) slot_pos[slot] = MCQ_EMPTY;
-            const u64 vm = __ballot(valid);
-            u32 ebase = 0;
-            if (lane == 0 && vm) ebase = atomicAdd(&s_n, (u32)__builtin_popcountll(vm));
-            ebase = bcast(ebase, 0);
-            if (valid) {
-                const u32 o = (u32)(((u64)tmh(f) * n_ranks) >> 32);
-                const u32 lp = atomicAdd(&s_cnt[o], 1u);
-                const u32 e = ebase + lane_rank(vm);
-                s_f[e] = f; s_slot[e] = slot; s_olp[e] = (o << 16) | lp;
+            const u32 own = valid ? (u32)(((u64)tmh(f) * n_ranks) >> 32) : MCQ_EMPTY;
+            u64 todo = __ballot(valid);
+            while (todo) {                                   // wave-uniform: one round per distinct owner
+                const u32 ol = bcast(own, (u32)__builtin_ctzll(todo));
+                const u64 mm = __ballot(own == ol);
+                const u32 c = (u32)__builtin_popcountll(mm);
+                u32 next = res[2 * ol], left = res[2 * ol + 1];
+                u32* F = sendF + (u64)ol * blk + MCQ_SHARD_HDR;
+                if (left < c) {                              // the rest of the chunk (< 16 positions) stays unused
+                    if (lane < left && next + lane < capF) F[next + lane] = MCQ_EMPTY;
+                    u32 nb = 0;
+                    if (lane == 0) nb = atomicAdd(&sendF[(u64)ol * blk], chunk);
+                    next = bcast(nb, 0); left = chunk;
+                }
+                if (own == ol) {
+                    const u32 pos = next + lane_rank(mm);
+                    if (pos < capF) { F[pos] = f; slot_pos[slot] = (ol << MCQ_SHARD_POS_BITS) | pos; }
+                    else { slot_pos[slot] = MCQ_EMPTY; atomicOr(err, 1u); }       // the owner's block is full
+                }
+                wave_sync();
+                if (lane == 0) { res[2 * ol] = next + c; res[2 * ol + 1] = left - c; }
+                wave_sync();
+                todo &= ~mm;
             }
-            wave_sync();
-            if (++j == nw) { have = false; i += nwaves; }
         }
-        __syncthreads();
-        if (tid < n_ranks) {
-            const u32 c = s_cnt[tid];
-            s_base[tid] = c ? atomicAdd(&sendF[(u64)tid * blk], c) : 0u;
-            s_cnt[tid] = 0;
-        }
-        __syncthreads();
-        const u32 ne = s_n;
-        for (u32 e = tid; e < ne; e += 256) {
-            const u32 o = s_olp[e] >> 16, pos = s_base[o] + (s_olp[e] & 0xFFFFu);
-            if (pos < capF) { sendF[(u64)o * blk + MCQ_SHARD_HDR + pos] = s_f[e]; slot_pos[s_slot[e]] = (o << MCQ_SHARD_POS_BITS) | pos; }
-            else { slot_pos[s_slot[e]] = MCQ_EMPTY; atomicOr(err, 1u); }          // the owner's block is full
-        }
-        __syncthreads();
-        if (tid == 0) s_n = 0;
+    }
+    for (u32 o = 0; o < n_ranks; ++o) {                      // what is left of the last chunks
+        const u32 next = res[2 * o], left = res[2 * o + 1];
+        u32* F = sendF + (u64)o * blk + MCQ_SHARD_HDR;
+        for (u32 t = lane; t < left; t += 64) if (next + t < capF) F[next + t] = MCQ_EMPTY;
     }
     if (lane == 0 && st_feat) atomicAdd(feat_cnt, st_feat);
 }
@@ -123,10 +120,26 @@ __global__ __launch_bounds__(256) void k_shard_lookup(DbDev db, u32 n_ranks, con
     if (t * MCQ_SHARD_TILE >= cnt) return;
     const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
     u64 off[4]; u32 len[4], incl[4];
+    {   // the first slot of all four probes in one round trip; a probe that has to walk on (load 0.25: one in eight) goes alone
+        u32 f[4], idx[4]; uint4 sl[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const u32 i = t * MCQ_SHARD_TILE + k * 256 + tid;
-        probe(db, i < cnt ? F[MCQ_SHARD_HDR + i] : MCQ_EMPTY, off[k], len[k]);
+        for (int k = 0; k < 4; ++k) {
+            const u32 i = t * MCQ_SHARD_TILE + k * 256 + tid;
+            f[k] = i < cnt ? F[MCQ_SHARD_HDR + i] : MCQ_EMPTY;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            idx[k] = tmh(f[k]) & db.slot_mask;
+            sl[k] = make_uint4(MCQ_EMPTY, 0, 0, 0);
+            if (f[k] != MCQ_EMPTY) sl[k] = db.slots[idx[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            while (sl[k].x != f[k] && sl[k].x != MCQ_EMPTY) { idx[k] = (idx[k] + 1) & db.slot_mask; sl[k] = db.slots[idx[k]]; }
+            const bool hit = f[k] != MCQ_EMPTY && sl[k].x == f[k];
+            len[k] = hit ? sl[k].y : 0u;
+            off[k] = hit ? (((u64)sl[k].w << 32) | sl[k].z) : 0ull;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -328,7 +341,9 @@ extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, m
     u64 capF = cfg->max_features_per_peer ? cfg->max_features_per_peer : std::min<u64>(max_slots, 2 * max_slots / n + 65536);
     capF = (capF + MCQ_SHARD_TILE - 1) / MCQ_SHARD_TILE * MCQ_SHARD_TILE;
     if (capF >= (1ull << MCQ_SHARD_POS_BITS)) return fail(MCQ_E_UNSUPPORTED, "more than 2^27 features per peer and batch");
-    const u64 capL = cfg->max_locations_per_peer ? cfg->max_locations_per_peer : (cfg->max_queries * 768 / n + (1u << 20));
+    // locations: an average list of 16 entries for every feature slot the batch can have (C2 has 3.4, a 33 Gbp table 11)
+    const u64 capL = cfg->max_locations_per_peer ? cfg->max_locations_per_peer
+                                                 : (std::max<u64>(cfg->max_queries * 512, max_slots * 16) / n + (1u << 20));
     if (capL >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "more than 2^32 locations per peer and batch");
     HIPCHK(hipSetDevice(shard->device));
     mcq_shard* c = new mcq_shard();
@@ -402,7 +417,10 @@ static int shard_prepare(mcq_shard* c, int k, const mcq_batch* in, hipStream_t s
     bd.paired = in->paired ? 1 : 0; bd.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
     if (in->n_seqs) {
         const u32 grid = (u32)std::min<u64>((in->n_seqs + 3) / 4, 256ull * 8);
-        hipLaunchKernelGGL(k_shard_sketch, dim3(grid), dim3(256), 0, st, c->db->d, bd, (const u64*)b.win_off, c->n, b.sendF, c->capF,
+        // a wave's reservation in an owner's block: an eighth of its expected share (one window's features at least)
+        const u64 slots_guess = (in->n_seqs * 2) * c->db->d.s;       // ~2 windows per sequence; only a granularity, any value is correct
+        const u32 chunk = (u32)std::min<u64>(4096, std::max<u64>(32, slots_guess / ((u64)c->n * grid * 4 * 8)));
+        hipLaunchKernelGGL(k_shard_sketch, dim3(grid), dim3(256), 0, st, c->db->d, bd, (const u64*)b.win_off, c->n, chunk, b.sendF, c->capF,
                            b.slot_pos, b.feat_cnt, c->err);
     }
     HIPCHK(hipGetLastError());

@@ -17,10 +17,11 @@ Runs only in the build container (needs /root/reference and oracle/_ref, built b
   tie/                row-11 fold-order case (4 identical genomes, P = 2 vs 4)
   noanc/              target without an ancestor at -lowest species (wire quirk)
   overpop/            -remove-overpopulated-features build
+  */P*/cli_*.out.gz   the reference CLI's whole -out file in several output layouts (make_cliout)
   wide/               64 targets at P = 16, 32, 64 with -maxcand 4 (the reference's scripted rank counts);
                       shards + CLI output only
 
-usage: python tests/golden/make_golden.py [--only kat|mini|tie|noanc|overpop|wide]
+usage: python tests/golden/make_golden.py [--only kat|mini|tie|noanc|overpop|wide|cliout]
 """
 import argparse
 import gzip
@@ -386,6 +387,37 @@ def make_overpop():
                    build_extra=("-remove-overpopulated-features",))
 
 
+CLI_VARIANTS = {"default": [], "tophits": ["-tophits"], "lineage": ["-tophits", "-taxids", "-lineage"],
+                "idsonly": ["-tophits", "-taxids-only", "-omit-ranks", "-mapped-only"]}
+
+
+def make_cliout():
+    """the reference CLI's whole -out file (parameter lines, table layout, mapping lines, summary) for a committed fixture,
+    in several output layouts: tests/golden/<tag>/P<p>/cli_<variant>.out.gz"""
+    for tag, P, maxcand in (("mini", 4, 4), ("tie", 2, 2)):
+        d = os.path.join(HERE, tag)
+        work = tempfile.mkdtemp(prefix="golden_cli_" + tag + "_")
+        os.makedirs(os.path.join(work, "genomes")); os.makedirs(os.path.join(work, "tax"))
+        shutil.copy(os.path.join(d, "nodes.dmp"), os.path.join(work, "tax"))
+        shutil.copy(os.path.join(d, "names.dmp"), os.path.join(work, "tax"))
+        with gzip.open(os.path.join(d, "genomes.fa.gz"), "rt") as f, open(os.path.join(work, "genomes", "all.fna"), "w") as o:
+            o.write(f.read())
+        with open(os.path.join(d, "queries.json")) as f:
+            q = json.load(f)
+        write_fastq(os.path.join(work, "r1.fq"), q["names"], q["r1"])
+        write_fastq(os.path.join(work, "r2.fq"), q["names"], q["r2"])
+        ref_build(work, tag, P)
+        for name, extra in CLI_VARIANTS.items():
+            out = os.path.join(work, "out_%s.txt" % name)
+            sh([os.path.join("/opt/conda/bin/mpiexec"), "-n", str(P), os.path.join(REF, "metacache_mpi"),
+                "query", tag, "r1.fq", "r2.fq", "-pairfiles", "-lowest", q["lowest"], "-threads", "2",
+                "-maxcand", str(maxcand), "-hitmin", "4", "-hitdiff", "80", "-query-limit", "128", "-out", out] + extra, cwd=work)
+            with open(out, "rb") as fi, gzip.GzipFile(os.path.join(d, "P%d" % P, "cli_%s.out.gz" % name), "wb", mtime=0) as fo:
+                fo.write(fi.read())
+            print("%s P=%d cli_%s: %d lines" % (tag, P, name, sum(1 for _ in open(out))))
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def make_wide():
     rng = random.Random(19)
     # the reference's scripted rank counts: -n 32 and -n 64 with -maxcand 4 (script/ft/QueryGeneric_FT.sh:115,
@@ -417,6 +449,6 @@ if __name__ == "__main__":
     if not os.path.isdir("/root/reference"):
         sys.exit("needs /root/reference (build container only)")
     ensure_mpilib()
-    todo = [a.only] if a.only else ["kat", "mini", "tie", "noanc", "overpop", "wide"]
+    todo = [a.only] if a.only else ["kat", "mini", "tie", "noanc", "overpop", "wide", "cliout"]
     for t in todo:
-        {"kat": make_kat, "mini": make_mini, "tie": make_tie, "noanc": make_noanc, "overpop": make_overpop, "wide": make_wide}[t]()
+        {"kat": make_kat, "mini": make_mini, "tie": make_tie, "noanc": make_noanc, "overpop": make_overpop, "wide": make_wide, "cliout": make_cliout}[t]()

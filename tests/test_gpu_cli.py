@@ -35,3 +35,40 @@ def test_cli_output_equals_reference(tag, P, tmp_path):
         mine = [[int(a), int(b)] for a, b in (t.rsplit(":", 1) for t in top.split(",") if t)]
         assert mine == ref["tophits"], (name, line)
         assert int(best) == ref["best"], (name, line)
+
+
+VARIANTS = {"default": [], "tophits": ["-tophits"], "lineage": ["-tophits", "-taxids", "-lineage"],
+            "idsonly": ["-tophits", "-taxids-only", "-omit-ranks", "-mapped-only"]}
+
+
+@pytest.mark.parametrize("tag,P", [("mini", 4), ("tie", 2)])
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, tmp_path):
+    """the whole -out file -- parameter lines, TABLE_LAYOUT, mapping lines in the default rank:name layout and the
+    other layouts, the summary with its statistics (src/printing.cpp:622-641, :522-555; src/classification.cpp:583-632)
+    -- against the file the reference wrote under mpiexec -n P (tests/golden/*/P*/cli_*.out.gz); compared sorted (the
+    reference's line order depends on its threads), the measured values of "# time:" / "# speed:" masked"""
+    import gzip
+    import re
+    pkg = importlib.import_module("metacache-mpi_amd")
+    pkg.build_host()
+    fx = Fixture(tag, P)
+    cwd = tmp_path
+    for fn, seqs in (("r1.fq", fx.r1), ("r2.fq", fx.r2)):
+        with open(cwd / fn, "w") as f:
+            for n, s in zip(fx.names, seqs):
+                f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+    prefix = fx.shard_paths[0][: -len(".db_0")]
+    r = subprocess.run([pkg.cli_path(), prefix, str(P), "r1.fq", "r2.fq", "-lowest", fx.q["lowest"], "-maxcand", str(fx.maxcand),
+                        "-hitmin", str(fx.hitmin), "-hitdiff", str(fx.q["hitdiff"]), "-threads", "2", "-out", "out.txt"] + VARIANTS[variant],
+                       cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+
+    def norm(text):
+        text = re.sub(r"^# time:    .*$", "# time:    T ms", text, flags=re.M)
+        text = re.sub(r"^# speed:   .*$", "# speed:   S queries/min", text, flags=re.M)
+        return sorted(text.split("\n"))
+    with gzip.open(os.path.join(os.path.dirname(fx.shard_paths[0]) if tag != "wide" else "", "cli_%s.out.gz" % variant), "rt") as f:
+        ref = f.read()
+    mine = open(cwd / "out.txt").read()
+    assert norm(mine) == norm(ref)
