@@ -362,7 +362,8 @@ def main():
                 "db_scaling": "fixed" if (world == 1 or a.db_fixed) else "%d species per GPU: the table grows with N, and with it the locations per read" % a.species,
                 "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "distinct_batches": nb,
                 "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
-                                "sharded": "feature table hash-range-sharded over %d GPU(s), all-to-all of features and hits (RCCL)" % world}[mode],
+                                "sharded": "feature table hash-range-sharded over %d GPU(s), features to their owners and hits back (%s)" %
+                                           (world, "device copy" if world == 1 else ("RCCL send/recv groups" if a.backend == "nccl" else "host-staged gloo rehearsal"))}[mode],
                 "setup_s": round(t_setup, 1), "db_build_s": round(t_build, 3),
             },
         }

@@ -465,6 +465,11 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     ShardBuf& b = c->sb[k];
     HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
 
+    // a rank's own blocks never travel: with one rank the owner side reads the home side's send buffers in place
+    const bool alias = n == 1 && !c->xfn;
+    u32* const recvF = alias ? b.sendF : c->recvF;
+    u32* const recvR = alias ? c->sendR : c->recvR;
+    void* const recvL = alias ? c->sendL : c->recvL;
     std::vector<u64> sbytes(n), rbytes(n), cnt_mine(n), cnt_theirs(n);
     // ---- X1: feature blocks to their owners
     u32 capFx = c->capFx; u64 capLx = c->capLx;
@@ -480,7 +485,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     } else {
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = ((u64)MCQ_SHARD_HDR + capFx) * 4;
     }
-    rc = shard_exchange(c, b.sendF, fblk_words(c) * 4, sbytes.data(), c->recvF, fblk_words(c) * 4, rbytes.data(), st); if (rc) return rc;
+    if (!alias) { rc = shard_exchange(c, b.sendF, fblk_words(c) * 4, sbytes.data(), recvF, fblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
 
     // ---- the next batch's S1 on the side stream, into the other buffer set: it runs under this batch's exchange, lookup and
     // reduce.  That set was last read by the reduce kernels of the previous batch (ev_done); the caller guarantees that the
@@ -498,9 +503,9 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, c->sendR, rblk_words(c), c->sendR, rblk_words(c), n);
     if (nq || true) {
         const dim3 grid(n * c->capT);
-        if (c->db->d.compact) hipLaunchKernelGGL(k_shard_lookup<u32>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)c->recvF, c->capF, capFx, c->capT,
+        if (c->db->d.compact) hipLaunchKernelGGL(k_shard_lookup<u32>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
                                                  c->sendR, (u32*)c->sendL, c->capL, c->err);
-        else                  hipLaunchKernelGGL(k_shard_lookup<u64>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)c->recvF, c->capF, capFx, c->capT,
+        else                  hipLaunchKernelGGL(k_shard_lookup<u64>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
                                                  c->sendR, (u64*)c->sendL, c->capL, c->err);
     }
     HIPCHK(hipGetLastError());
@@ -509,7 +514,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     if (exact) {
         // ends of the features each peer sent (counts known from X1), locations served to each peer (cursor word of its R block)
         for (u32 p = 0; p < n; ++p) { sbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_theirs[p]) * 4; rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_mine[p]) * 4; }
-        rc = shard_exchange(c, c->sendR, rblk_words(c) * 4, sbytes.data(), c->recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc;
+        if (!alias) { rc = shard_exchange(c, c->sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
         HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, c->sendR, rblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         u64 mx = 0;
@@ -517,7 +522,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
         for (u32 p = 0; p < n; ++p) { served[p] = std::min<u64>(c->cnt_host[p], c->capL); mx = std::max(mx, served[p]); }
         rc = shard_exchange_counts(c, served.data(), coming.data(), st); if (rc) return rc;
         for (u32 p = 0; p < n; ++p) { sbytes[p] = served[p] * c->locb; rbytes[p] = coming[p] * c->locb; mx = std::max(mx, coming[p]); }
-        rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), c->recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc;
+        if (!alias) { rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
         c->sent_locations = mx;
         capLx = c->capL;
         // learn the padded mode's block sizes: the largest count any rank saw this batch, plus a quarter
@@ -529,17 +534,17 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
         c->capLx = std::max<u64>(c->capLx, std::min<u64>(c->capL, gl + gl / 4 + 65536));
     } else {
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + capFx) * 4;
-        rc = shard_exchange(c, c->sendR, rblk_words(c) * 4, sbytes.data(), c->recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc;
+        if (!alias) { rc = shard_exchange(c, c->sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = capLx * c->locb;
-        rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), c->recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc;
-        hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(64), 0, st, (const u32*)c->recvR, rblk_words(c), n, capLx, c->err);
+        if (!alias) { rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
+        hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(64), 0, st, (const u32*)recvR, rblk_words(c), n, capLx, c->err);
     }
 
     // ---- S3: home side, the fused kernels fed from the exchange
     ShardDev sh;
-    sh.slot_pos = b.slot_pos; sh.ends = c->recvR + MCQ_SHARD_HDR + c->capT; sh.tile_base = c->recvR + MCQ_SHARD_HDR;
+    sh.slot_pos = b.slot_pos; sh.ends = recvR + MCQ_SHARD_HDR + c->capT; sh.tile_base = recvR + MCQ_SHARD_HDR;
     sh.win_off = b.win_off; sh.ends_stride = (u32)rblk_words(c); sh.tile_stride = (u32)rblk_words(c); sh.capL = c->capL;
-    DbDev dbd = c->db->d; dbd.locs = c->recvL;
+    DbDev dbd = c->db->d; dbd.locs = recvL;
     BatchDev bd; bd.bases = in->bases; bd.seq_off = in->seq_off; bd.n_seq = in->n_seqs; bd.nq = nq; bd.paired = in->paired ? 1 : 0;
     bd.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;

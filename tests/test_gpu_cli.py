@@ -24,10 +24,10 @@ def test_cli_output_equals_reference(tag, P, tmp_path):
     prefix = fx.shard_paths[0][: -len(".db_0")]
     r = subprocess.run([pkg.cli_path(), prefix, str(P), str(tmp_path / "r1.fq"), str(tmp_path / "r2.fq"),
                         "-lowest", fx.q["lowest"], "-maxcand", str(fx.maxcand), "-hitmin", str(fx.hitmin),
-                        "-hitdiff", str(fx.q["hitdiff"]), "-out", str(out)],
+                        "-hitdiff", str(fx.q["hitdiff"]), "-tophits", "-taxids-only", "-omit-ranks", "-out", str(out)],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
-    lines = open(out).read().strip().split("\n")
+    lines = [l for l in open(out).read().strip().split("\n") if not l.startswith("#")]
     assert len(lines) == len(fx.names)
     for line in lines:
         name, top, best = line.split("\t|\t")
