@@ -51,6 +51,12 @@ enum {
                                    (begin,end) byte ranges into `bases` instead of n_seqs+1 offsets:
                                    the sequences may sit anywhere in the buffer, e.g. inside raw
                                    FASTQ text indexed by mcq_fastq_index                          */
+    MCQ_BATCH_PACKED = 0x10u,   /* mcq_batch.flags: `bases` is not ASCII but the packed form mcq_pack_bases writes (3 bits per
+                                   base instead of 8: what a host that keeps its reads packed sends over PCIe): u32 words of
+                                   2-bit codes, 16 bases per word, first base in the top bits (A/a 0, C/c 1, G/g 2, T/t 3), one
+                                   zero pad word, then u32 words of ambiguity bits, 32 bases per word, first base in the top bit
+                                   (1 = not ACGT: src/dna_encoding.h:326-336), one zero pad word.  seq_off stays in bases;
+                                   mcq_batch.n_bases = seq_off[n_seqs].  Not with MCQ_BATCH_RANGES                        */
     MCQ_FORCE_BLOCK_PATH = 0x100u, /* test hook: every query takes the workgroup path    */
     MCQ_FORCE_RAW_SORT = 0x400u,   /* test hook: the wave path sorts the raw match list instead of
                                       de-duplicating it first (the path of > 256 distinct keys / 64-bit keys) */
@@ -108,8 +114,14 @@ typedef struct {
     const char* bases;
     const uint64_t* seq_off;    /* [n_seqs + 1] */
     uint32_t paired;
-    uint32_t flags;             /* MCQ_DEVICE_PTRS */
+    uint32_t flags;             /* MCQ_DEVICE_PTRS, MCQ_BATCH_RANGES, MCQ_BATCH_PACKED */
+    uint64_t n_bases;           /* MCQ_BATCH_PACKED with device pointers: bases of the whole batch (locates the planes) */
 } mcq_batch;
+
+/* bytes of the packed form of n_bases bases, and the packer: ASCII (host, or device with MCQ_DEVICE_PTRS: then a
+ * kernel on `stream`) -> packed buffer of mcq_packed_bytes(n_bases) bytes in the same memory space                  */
+uint64_t mcq_packed_bytes(uint64_t n_bases);
+int mcq_pack_bases(const char* bases, uint64_t n_bases, void* out, uint32_t flags, void* stream);
 
 /* classification_options / candidate_generation_rules subset that the path uses
  * (src/query_options.h:123-135, src/candidates.h:89-101).                            */

@@ -178,7 +178,7 @@ int main(int argc, char** argv) {
     }
     mcq_ws* ws = nullptr;
     if (mcq_ws_create(edb, nq, bases.size() + 1, 0, &ws)) { std::fprintf(stderr, "ABORT: %s\n", mcq_last_error()); return 1; }
-    mcq_batch in; in.n_seqs = off.size() - 1; in.bases = bases.data(); in.seq_off = off.data(); in.paired = paired ? 1 : 0; in.flags = 0;
+    mcq_batch in; std::memset(&in, 0, sizeof(in)); in.n_seqs = off.size() - 1; in.bases = bases.data(); in.seq_off = off.data(); in.paired = paired ? 1 : 0; in.flags = 0;
     mcq_query_opts qo; qo.max_cand = maxcand; qo.emulate_ranks = P; qo.insert_size_max = insertsize;
     qo.flags = quirks ? MCQ_QUIRK_SEQ_DROP : 0;
     std::vector<mcq_cand> cands(std::max<size_t>(1, nq) * maxcand);

@@ -44,12 +44,16 @@ struct DbDev {
 };
 
 struct BatchDev {
-    const char* bases;
-    const u64* seq_off;      // [n_seq+1] back-to-back, or [2*n_seq] (begin,end) pairs when `ranges`
+    const char* bases;       // ASCII, or (packed) the u32 words of MCQ_BATCH_PACKED
+    const u64* seq_off;      // [n_seq+1] back-to-back, or [2*n_seq] (begin,end) pairs when `ranges`; always in bases
     u64 n_seq;
     u64 nq;
     u32 paired;
     u32 ranges;
+    u32 packed;              // MCQ_BATCH_PACKED: 2-bit codes (16 per word, first base in the top bits) + ambiguity bits (32 per word)
+    u32 amb_off;             // first word of the ambiguity bits
+    u32 last_word;           // index of the (zero) pad word behind the 2-bit codes: loads are clamped to it
+    u32 amb_last;            // the same for the ambiguity plane (relative to amb_off)
 };
 // byte range [beg,end) of sequence a of the batch
 __device__ __forceinline__ void seq_bounds(const u64* seq_off, u32 ranges, u64 a, u64& beg, u64& end) {
@@ -422,22 +426,40 @@ __device__ __forceinline__ void window_chars(const char* __restrict__ seq, u32 n
     c0 = c & 0xFFu; c1 = c >> 8;
 }
 
-// sketch of a window whose bases are already in registers (window_chars)
-__device__ __forceinline__ u32 wave_sketch_chars(u32 c0, u32 c1, u32 n, u32 k, u32 s, u32 lane, u32* tmp, u32* dst) {
-    if (n < k) return 0;
-    u32 cap = n - k + 1;
-    u32 sl = s < cap ? s : cap;
+// the bases of a window, two per lane (window_chars), as the words the sketch works on: w = the 16 bases
+// [16 * (lane / 8), +16) of the window, 2 bits each, first base in the top bits; am = the ambiguity bits of the 32 bases
+// [32 * (lane / 16), +32), first base in the top bit
+__device__ __forceinline__ void wave_words_of_chars(u32 c0, u32 c1, u32 lane, u32& w, u32& am) {
     // A/a=0 C/c=1 G/g=2 T/t=3 (src/dna_encoding.h:326-336); anything else ambiguous
     u32 u0 = c0 & 0xDFu, u1 = c1 & 0xDFu;
     u32 x0 = (u0 >> 1) & 3u, x1 = (u1 >> 1) & 3u;
     x0 ^= x0 >> 1; x1 ^= x1 >> 1;
     u32 a0 = !(u0 == 'A' || u0 == 'C' || u0 == 'G' || u0 == 'T');
     u32 a1 = !(u1 == 'A' || u1 == 'C' || u1 == 'G' || u1 == 'T');
-
-    u32 w = ((x0 << 2) | x1) << (28 - 4 * (lane & 7));
+    w = ((x0 << 2) | x1) << (28 - 4 * (lane & 7));
     w |= xor_lane<1>(w, lane); w |= xor_lane<2>(w, lane); w |= xor_lane<4>(w, lane);
-    u32 am = ((a0 << 1) | a1) << (30 - 2 * (lane & 15));
+    am = ((a0 << 1) | a1) << (30 - 2 * (lane & 15));
     am |= xor_lane<1>(am, lane); am |= xor_lane<2>(am, lane); am |= xor_lane<4>(am, lane); am |= xor_lane<8>(am, lane);
+}
+// the same words out of an MCQ_BATCH_PACKED buffer: the window starts at base `at` of the batch; two (broadcast) loads and
+// a funnel shift per plane.  Bits behind the window's end are never looked at (a k-mer must end inside the window).
+__device__ __forceinline__ void wave_words_of_packed(const BatchDev& b, u64 at, u32 lane, u32& w, u32& am) {
+    const u32* __restrict__ P2 = reinterpret_cast<const u32*>(b.bases);
+    const u32 wi = (u32)(at >> 4) + (lane >> 3), sh = (u32)(at & 15) * 2;
+    const u32 p0 = P2[wi < b.last_word ? wi : b.last_word], p1 = P2[wi + 1 < b.last_word ? wi + 1 : b.last_word];
+    w = (u32)((((u64)p0 << 32) | p1) >> (32 - sh));
+    const u32 ai = (u32)(at >> 5) + (lane >> 4), ash = (u32)(at & 31);
+    const u32 alast = b.amb_last;
+    const u32* __restrict__ AM = P2 + b.amb_off;
+    const u32 a0 = AM[ai < alast ? ai : alast], a1 = AM[ai + 1 < alast ? ai + 1 : alast];
+    am = (u32)((((u64)a0 << 32) | a1) >> (32 - ash));
+}
+
+// sketch of a window given as words (see wave_words_of_chars)
+__device__ __forceinline__ u32 wave_sketch_words(u32 w, u32 am, u32 n, u32 k, u32 s, u32 lane, u32* tmp, u32* dst) {
+    if (n < k) return 0;
+    u32 cap = n - k + 1;
+    u32 sl = s < cap ? s : cap;
 
     // a window with at most 64 k-mer start positions (the tail window of a read) needs only slot 0
     const bool one_slot = cap <= 64;
@@ -511,9 +533,18 @@ __device__ __forceinline__ u32 wave_sketch_chars(u32 c0, u32 c1, u32 n, u32 k, u
 __device__ __forceinline__ u32 wave_sketch(const char* __restrict__ seq, u32 n, u32 k, u32 s,
                                            u32 lane, u32* tmp, u32* dst) {
     if (n < k) return 0;
-    u32 c0, c1;
+    u32 c0, c1, w, am;
     window_chars(seq, n, lane, c0, c1);
-    return wave_sketch_chars(c0, c1, n, k, s, lane, tmp, dst);
+    wave_words_of_chars(c0, c1, lane, w, am);
+    return wave_sketch_words(w, am, n, k, s, lane, tmp, dst);
+}
+// window [at, at + n) of the batch, whichever form the batch is in
+__device__ __forceinline__ u32 wave_sketch_b(const BatchDev& b, u64 at, u32 n, u32 k, u32 s, u32 lane, u32* tmp, u32* dst) {
+    if (n < k) return 0;
+    u32 w, am;
+    if (b.packed) wave_words_of_packed(b, at, lane, w, am);
+    else { u32 c0, c1; window_chars(b.bases + at, n, lane, c0, c1); wave_words_of_chars(c0, c1, lane, w, am); }
+    return wave_sketch_words(w, am, n, k, s, lane, tmp, dst);
 }
 
 // ------------------------------------------------------------------ row 6: probe

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
             for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
                 u64 at; u32 wl;
                 window_span(db, g, w, at, wl);
-                nfeat += wave_sketch(b.bases + at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
+                nfeat += wave_sketch_b(b, at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
             }
             if (lane < nfeat) myf = feat[lane];
             if (stop == 1) { if (myf == 12345u) out.ncand[q] = nfeat; continue; }
@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
                 u64 at; u32 wl;
                 window_span(db, g, w, at, wl);
-                nfeat += wave_sketch(b.bases + at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
+                nfeat += wave_sketch_b(b, at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
             }
             two = nfeat > 64;                          // wave-uniform
             const u32 myf0 = lane < nfeat ? feat[lane] : MCQ_EMPTY;
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             const u64 sb = m2 ? o1 : o0;
             u64 beg; u32 wl;
             window_of(n, W, S, m2 ? w - nw1 : w, beg, wl);
-            u32 m = wave_sketch(b.bases + sb + beg, wl, db.k, db.s, lane, sk, sk + 64);
+            u32 m = wave_sketch_b(b, sb + beg, wl, db.k, db.s, lane, sk, sk + 64);
             u32 base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_w[18], m);
             base = bcast(base, 0);
@@ -1710,10 +1710,75 @@ extern "C" int mcq_ws_destroy(mcq_ws* ws) {
 
 static int ensure_staging(mcq_ws* ws) {
     if (ws->d_bases) return MCQ_OK;
-    HIPCHK(hipMalloc(&ws->d_bases, std::max<u64>(1, ws->max_bases)));
+    HIPCHK(hipMalloc(&ws->d_bases, std::max<u64>(1, ws->max_bases) + 16));
     HIPCHK(hipMalloc(&ws->d_seq_off, (2 * ws->max_queries + 2) * 8));
     HIPCHK(hipMalloc(&ws->d_cands, std::max<u64>(1, ws->max_queries) * 16 * 16));
     HIPCHK(hipMalloc(&ws->d_ncand, std::max<u64>(1, ws->max_queries) * 4));
+    return MCQ_OK;
+}
+
+// layout of an MCQ_BATCH_PACKED buffer for n bases (u32 words): [ceil(n/16) words of 2-bit codes][1 zero pad word]
+// [ceil(n/32) words of ambiguity bits][1 zero pad word]
+static u64 packed_words2(u64 n) { return (n + 15) / 16; }
+static u64 packed_wordsA(u64 n) { return (n + 31) / 32; }
+extern "C" uint64_t mcq_packed_bytes(uint64_t n_bases) { return (packed_words2(n_bases) + 1 + packed_wordsA(n_bases) + 1) * 4; }
+
+// device-side view of a batch whose buffers are (already) in device memory
+static int batch_dev(const mcq_batch* in, const char* d_bases, const u64* d_seq_off, BatchDev& b) {
+    memset(&b, 0, sizeof(b));
+    b.bases = d_bases; b.seq_off = d_seq_off; b.n_seq = in->n_seqs; b.nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
+    b.paired = in->paired ? 1 : 0;
+    b.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
+    if (in->flags & MCQ_BATCH_PACKED) {
+        if (b.ranges) return fail(MCQ_E_ARG, "MCQ_BATCH_PACKED and MCQ_BATCH_RANGES exclude each other");
+        if (in->n_bases >= (1ull << 35)) return fail(MCQ_E_UNSUPPORTED, "packed batches hold fewer than 2^35 bases");
+        b.packed = 1;
+        b.last_word = (u32)packed_words2(in->n_bases);
+        b.amb_off = b.last_word + 1;
+        b.amb_last = (u32)packed_wordsA(in->n_bases);
+    }
+    return MCQ_OK;
+}
+
+// ASCII bases -> MCQ_BATCH_PACKED words; one thread per 32 bases
+__global__ void k_pack_bases(const char* __restrict__ src, u64 n, u32* __restrict__ dst, u64 n2, u64 amb_off, u64 nA) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > nA) return;
+    u32 w0 = 0, w1 = 0, am = 0;
+    for (u32 j = 0; j < 32; ++j) {
+        const u64 i = g * 32 + j;
+        u32 code = 0, amb = 0;                                  // behind the end: code 0, not ambiguous (never looked at)
+        if (i < n) {
+            const u32 u = (u32)(unsigned char)src[i] & 0xDFu;
+            code = (u >> 1) & 3u; code ^= code >> 1;
+            amb = !(u == 'A' || u == 'C' || u == 'G' || u == 'T');
+            if (amb) code = 0;
+        }
+        if (j < 16) w0 |= code << (30 - 2 * j); else w1 |= code << (30 - 2 * (j - 16));
+        am |= amb << (31 - j);
+    }
+    if (2 * g <= n2) dst[2 * g] = (2 * g < n2) ? w0 : 0u;      // index n2 is the zero pad word
+    if (2 * g + 1 <= n2) dst[2 * g + 1] = (2 * g + 1 < n2) ? w1 : 0u;
+    dst[amb_off + g] = g < nA ? am : 0u;
+}
+
+extern "C" int mcq_pack_bases(const char* bases, uint64_t n_bases, void* out, uint32_t flags, void* stream) {
+    if (!out || (n_bases && !bases)) return fail(MCQ_E_ARG, "null argument");
+    const u64 n2 = packed_words2(n_bases), nA = packed_wordsA(n_bases), amb_off = n2 + 1;
+    if (flags & MCQ_DEVICE_PTRS) {
+        hipLaunchKernelGGL(k_pack_bases, dim3((u32)((nA + 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bases, n_bases, (u32*)out, n2, amb_off, nA);
+        HIPCHK(hipGetLastError());
+        return MCQ_OK;
+    }
+    u32* dst = (u32*)out;
+    memset(dst, 0, mcq_packed_bytes(n_bases));
+    for (u64 i = 0; i < n_bases; ++i) {
+        const u32 u = (u32)(unsigned char)bases[i] & 0xDFu;
+        u32 code = (u >> 1) & 3u; code ^= code >> 1;
+        const bool amb = !(u == 'A' || u == 'C' || u == 'G' || u == 'T');
+        if (amb) dst[amb_off + (i >> 5)] |= 1u << (31 - (i & 31));
+        else dst[i >> 4] |= code << (30 - 2 * (i & 15));
+    }
     return MCQ_OK;
 }
 
@@ -1790,22 +1855,26 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
     if (nq > ws->max_queries) return fail(MCQ_E_ARG, "batch has more queries than the workspace allows");
     const bool dev_in = (in->flags & MCQ_DEVICE_PTRS) != 0, dev_out = (out->flags & MCQ_DEVICE_PTRS) != 0;
-    BatchDev b; b.n_seq = in->n_seqs; b.nq = nq; b.paired = in->paired ? 1 : 0;
-    b.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
-    if (b.ranges && !dev_in) return fail(MCQ_E_ARG, "MCQ_BATCH_RANGES needs device pointers");
+    const bool packed = (in->flags & MCQ_BATCH_PACKED) != 0;
+    if ((in->flags & MCQ_BATCH_RANGES) && !dev_in) return fail(MCQ_E_ARG, "MCQ_BATCH_RANGES needs device pointers");
     OutDev o;
     u64 nbases = 0;
     if (!dev_in) {
         nbases = in->n_seqs ? in->seq_off[in->n_seqs] - in->seq_off[0] : 0;
         if (nbases > ws->max_bases) return fail(MCQ_E_ARG, "batch has more bases than the workspace allows");
         if (in->n_seqs && in->seq_off[0] != 0) return fail(MCQ_E_ARG, "host batches must start at offset 0");
+        if (packed && in->n_bases && in->n_bases != nbases) return fail(MCQ_E_ARG, "mcq_batch.n_bases must equal seq_off[n_seqs] for a packed batch");
     }
     if (!dev_in || !dev_out) { rc = ensure_staging(ws); if (rc) return rc; }
+    BatchDev b;
     if (!dev_in) {
-        if (nbases) HIPCHK(hipMemcpyAsync(ws->d_bases, in->bases, nbases, hipMemcpyHostToDevice, st));
+        const u64 bytes = packed ? mcq_packed_bytes(nbases) : nbases;      // (a packed batch is at most as large as its ASCII form + 16 B)
+        if (bytes) HIPCHK(hipMemcpyAsync(ws->d_bases, in->bases, bytes, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(ws->d_seq_off, in->seq_off, (in->n_seqs + 1) * 8, hipMemcpyHostToDevice, st));
-        b.bases = ws->d_bases; b.seq_off = ws->d_seq_off;
-    } else { b.bases = in->bases; b.seq_off = in->seq_off; }
+        mcq_batch hin = *in; hin.n_bases = nbases;
+        rc = batch_dev(&hin, ws->d_bases, ws->d_seq_off, b);
+    } else rc = batch_dev(in, in->bases, in->seq_off, b);
+    if (rc) return rc;
     if (!dev_out) { o.cands = ws->d_cands; o.ncand = ws->d_ncand; }
     else { o.cands = (u32*)out->cands; o.ncand = out->n_cand; }
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
@@ -1852,7 +1921,8 @@ extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* 
     HIPCHK(hipMemcpy(ws->d_seq_off, in->seq_off, (in->n_seqs + 1) * 8, hipMemcpyHostToDevice));
     mcq_query_opts qo; qo.max_cand = 1; qo.emulate_ranks = 1; qo.insert_size_max = 0; qo.flags = 0;
     OptDev od; rc = make_opt(&qo, od); if (rc) return rc;
-    BatchDev b; b.bases = ws->d_bases; b.seq_off = ws->d_seq_off; b.n_seq = in->n_seqs; b.nq = nq; b.paired = in->paired ? 1 : 0; b.ranges = 0;
+    if (in->flags & (MCQ_BATCH_PACKED | MCQ_BATCH_RANGES)) return fail(MCQ_E_ARG, "debug tap takes plain ASCII batches");
+    BatchDev b; rc = batch_dev(in, ws->d_bases, ws->d_seq_off, b); if (rc) return rc;
     OutDev o; o.cands = ws->d_cands; o.ncand = ws->d_ncand;
     u64 *d_cnt = nullptr, *d_off = nullptr, *d_m = nullptr;
     HIPCHK(hipMalloc(&d_cnt, std::max<u64>(1, nq) * 8));
@@ -1899,6 +1969,7 @@ extern "C" int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t*
                           uint32_t* features, uint32_t* n_feat, void* stream) {
     if (!db || !in || !win_off || !features || !n_feat) return fail(MCQ_E_ARG, "null argument");
     if (!(in->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "staged entry points take device pointers");
+    if (in->flags & MCQ_BATCH_PACKED) return fail(MCQ_E_ARG, "mcq_sketch takes ASCII batches");
     HIPCHK(hipSetDevice(db->device));
     if (in->n_seqs == 0) return MCQ_OK;
     // many short sequences (reads): one wave per sequence; few long ones (genomes): one wave per window

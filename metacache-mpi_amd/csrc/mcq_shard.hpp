@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_shard_sketch(DbDev db, BatchDev b, cons
         for (u32 j = 0; j < nw; ++j) {
             u32 beg, wl;
             window_of32(n, db.winlen, db.winstride, db.magic_stride, j, beg, wl);
-            const u32 m = wave_sketch(b.bases + o0 + beg, wl, db.k, db.s, lane, sk, sk + 64);
+            const u32 m = wave_sketch_b(b, o0 + beg, wl, db.k, db.s, lane, sk, sk + 64);
             st_feat += m;
             const bool mine = lane < db.s;
             const u32 f = (mine && lane < m) ? sk[64 + lane] : MCQ_EMPTY;
@@ -413,8 +413,7 @@ static int shard_prepare(mcq_shard* c, int k, const mcq_batch* in, hipStream_t s
     int rc = mcq_count_windows(c->db, in, b.win_off, st); if (rc) return rc;
     hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendF, fblk_words(c), b.sendF, fblk_words(c), c->n);
     HIPCHK(hipMemsetAsync(b.feat_cnt, 0, 8, st));
-    BatchDev bd; bd.bases = in->bases; bd.seq_off = in->seq_off; bd.n_seq = in->n_seqs; bd.nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
-    bd.paired = in->paired ? 1 : 0; bd.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
+    BatchDev bd; rc = batch_dev(in, in->bases, in->seq_off, bd); if (rc) return rc;
     if (in->n_seqs) {
         const u32 grid = (u32)std::min<u64>((in->n_seqs + 3) / 4, 256ull * 8);
         // a wave's reservation in an owner's block: an eighth of its expected share (one window's features at least)
@@ -545,8 +544,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     sh.slot_pos = b.slot_pos; sh.ends = recvR + MCQ_SHARD_HDR + c->capT; sh.tile_base = recvR + MCQ_SHARD_HDR;
     sh.win_off = b.win_off; sh.ends_stride = (u32)rblk_words(c); sh.tile_stride = (u32)rblk_words(c); sh.capL = c->capL;
     DbDev dbd = c->db->d; dbd.locs = recvL;
-    BatchDev bd; bd.bases = in->bases; bd.seq_off = in->seq_off; bd.n_seq = in->n_seqs; bd.nq = nq; bd.paired = in->paired ? 1 : 0;
-    bd.ranges = (in->flags & MCQ_BATCH_RANGES) ? 1 : 0;
+    BatchDev bd; rc = batch_dev(in, in->bases, in->seq_off, bd); if (rc) return rc;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
     rc = launch_query(c->db, ws, bd, od, o, st, force_bits(opt->flags) | (od.big ? 1 : 0), dbg, &sh, &dbd); if (rc) return rc;

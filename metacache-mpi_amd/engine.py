@@ -13,6 +13,7 @@ from .build import lib_path
 MCQ_DEVICE_PTRS = 1
 MCQ_QUIRK_SEQ_DROP = 2
 MCQ_BATCH_RANGES = 8             # seq_off = (begin,end) pairs into `bases` (device pointers only)
+MCQ_BATCH_PACKED = 0x10          # bases in the packed form of mcq_pack_bases (3 bits per base)
 MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-query path
 MCQ_DB_LOCS_64 = 0x200           # Database(flags=...): keep 64-bit locations
 MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000   # Table / Database.build: -remove-overpopulated-features
@@ -45,7 +46,7 @@ class BuildDesc(C.Structure):
 
 class Batch(C.Structure):
     _fields_ = [("n_seqs", C.c_uint64), ("bases", C.c_void_p), ("seq_off", C.c_void_p),
-                ("paired", C.c_uint32), ("flags", C.c_uint32)]
+                ("paired", C.c_uint32), ("flags", C.c_uint32), ("n_bases", C.c_uint64)]
 
 
 class QueryOpts(C.Structure):
@@ -119,6 +120,8 @@ def lib():
         L.mcq_build_last_error.restype = C.c_char_p
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
+        L.mcq_packed_bytes.restype = C.c_uint64; L.mcq_packed_bytes.argtypes = [C.c_uint64]
+        L.mcq_pack_bases.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p]
         L.mcq_shard_create.argtypes = [C.c_void_p, C.POINTER(ShardCfg), C.POINTER(C.c_void_p)]
         L.mcq_shard_destroy.argtypes = [C.c_void_p]
         L.mcq_shard_unique_id.argtypes = [C.c_void_p]
@@ -256,13 +259,15 @@ class Workspace:
         return st.as_dict()
 
     # ---- host-buffer call: numpy in, numpy out (copies + sync inside) -------------
-    def query_host(self, bases, seq_off, paired, max_cand=2, emulate_ranks=1, insert_size_max=0, flags=0):
+    def query_host(self, bases, seq_off, paired, max_cand=2, emulate_ranks=1, insert_size_max=0, flags=0, packed=False):
+        """packed: `bases` holds the packed form (pack_bases) of the batch instead of ASCII"""
         seq_off = np.ascontiguousarray(seq_off, np.uint64)
         n_seqs = len(seq_off) - 1
         nq = n_seqs // 2 if paired else n_seqs
         bases_arr = np.frombuffer(bases, dtype=np.uint8) if not isinstance(bases, np.ndarray) else bases
         bases_arr = np.ascontiguousarray(bases_arr)
-        b = Batch(n_seqs, _np_ptr(bases_arr) if len(bases_arr) else None, _np_ptr(seq_off), 1 if paired else 0, 0)
+        b = Batch(n_seqs, _np_ptr(bases_arr) if len(bases_arr) else None, _np_ptr(seq_off), 1 if paired else 0,
+                  MCQ_BATCH_PACKED if packed else 0, int(seq_off[-1]) if packed else 0)
         o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
         cands = np.zeros((max(nq, 1), max_cand, 4), np.uint32)
         ncand = np.zeros(max(nq, 1), np.uint32)
@@ -272,8 +277,10 @@ class Workspace:
 
     # ---- device-buffer call: raw pointers, enqueue only --------------------------
     def query_device(self, bases_ptr, seq_off_ptr, n_seqs, paired, cands_ptr, ncand_ptr, max_cand=2,
-                     emulate_ranks=1, insert_size_max=0, flags=0, stream=None, ranges=False):
-        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 1 if paired else 0, MCQ_DEVICE_PTRS | (MCQ_BATCH_RANGES if ranges else 0))
+                     emulate_ranks=1, insert_size_max=0, flags=0, stream=None, ranges=False, packed_bases=0):
+        """packed_bases > 0: bases_ptr is the packed form of a batch of that many bases"""
+        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 1 if paired else 0,
+                  MCQ_DEVICE_PTRS | (MCQ_BATCH_RANGES if ranges else 0) | (MCQ_BATCH_PACKED if packed_bases else 0), packed_bases)
         o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
         r = Result(cands_ptr, ncand_ptr, MCQ_DEVICE_PTRS)
         _chk(lib().mcq_query(self.db.h, self.h, C.byref(b), C.byref(o), C.byref(r), stream))
@@ -383,6 +390,22 @@ class Shard:
             self.close()
         except Exception:
             pass
+
+
+def packed_bytes(n_bases):
+    return int(lib().mcq_packed_bytes(n_bases))
+
+
+def pack_bases_host(bases):
+    """ASCII bytes -> the packed form (numpy uint8 array of packed_bytes(len) bytes)"""
+    src = np.frombuffer(bases, dtype=np.uint8) if not isinstance(bases, np.ndarray) else np.ascontiguousarray(bases, np.uint8)
+    out = np.zeros(packed_bytes(len(src)), np.uint8)
+    _chk(lib().mcq_pack_bases(_np_ptr(src) if len(src) else None, len(src), _np_ptr(out), 0, None))
+    return out
+
+
+def pack_bases_device(bases_ptr, n_bases, out_ptr, stream=None):
+    _chk(lib().mcq_pack_bases(bases_ptr, n_bases, out_ptr, MCQ_DEVICE_PTRS, stream))
 
 
 def bucket_features(features_ptr, n, n_shards, counts_ptr, bucketed_ptr, src_index_ptr, stream=None):

@@ -1,0 +1,102 @@
+"""MCQ_BATCH_PACKED (2-bit codes + ambiguity bits, 3 bits per base instead of 8): the packers agree, and a packed batch
+gives exactly the results of its ASCII form on every path (first / second wave stage, workgroup kernel, sharded)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    synth = importlib.import_module("metacache-mpi_amd.synth")
+    dev = torch.device("cuda", 0)
+    gb, goff, species = synth.make_genomes(6, 6, 150_000, 300_000, 0.02, seed=8, device=dev)
+    table = eng.Table(gb.data_ptr(), goff.data_ptr(), goff.numel() - 1, emulate_ranks=2)
+    keys, off, locs, _ = table.to_host()
+    table.close()
+    sp = species.cpu().numpy().astype(np.uint32)
+    return eng, synth, dev, gb, goff, eng.Database(keys, off, locs, sp), orc.OracleDb(keys, off, locs, sp)
+
+
+def _ragged_batch(gb, goff, seed):
+    rng = np.random.default_rng(seed)
+    host = gb.cpu().numpy(); offs = goff.cpu().numpy()
+    seqs = []
+    for L in [0, 1, 15, 16, 17, 31, 32, 33, 100, 127, 128, 129, 150, 151, 241, 300, 500, 777, 1000, 6000] * 30:
+        t = int(rng.integers(0, len(offs) - 1))
+        a = int(rng.integers(offs[t], offs[t + 1] - max(L, 1)))
+        sq = host[a:a + L].copy()
+        if L > 20 and rng.random() < 0.3:
+            sq[rng.integers(0, L, size=rng.integers(1, 4))] = rng.choice(np.frombuffer(b"NnRYxX-", np.uint8))
+        if L > 20 and rng.random() < 0.3:
+            sq[:L // 3] |= 0x20
+        seqs.append(sq.tobytes())
+    order = rng.permutation(len(seqs))
+    return [seqs[i] for i in order]
+
+
+def test_packers_agree_and_decode(world):
+    eng, synth, dev, gb, goff, db, odb = world
+    rb, ro = orc.pack_reads(_ragged_batch(gb, goff, 1))
+    raw = np.frombuffer(rb, np.uint8)
+    host = eng.pack_bases_host(rb)
+    src = torch.from_numpy(raw.copy()).to(dev)
+    out = torch.zeros(eng.packed_bytes(len(raw)), dtype=torch.uint8, device=dev)
+    eng.pack_bases_device(src.data_ptr(), len(raw), out.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), host)
+    # decode: 2-bit codes (first base in the top bits of a u32) and ambiguity bits
+    n = len(raw); n2 = (n + 15) // 16
+    words = host.view(np.uint32)
+    u = raw & 0xDF
+    code = np.select([u == ord("A"), u == ord("C"), u == ord("G"), u == ord("T")], [0, 1, 2, 3], default=0).astype(np.uint32)
+    amb = ~np.isin(u, np.frombuffer(b"ACGT", np.uint8))
+    i = np.arange(n)
+    assert np.array_equal((words[i >> 4] >> (30 - 2 * (i & 15))) & 3, code)
+    assert np.array_equal(((words[n2 + 1 + (i >> 5)] >> (31 - (i & 31))) & 1).astype(bool), amb)
+    assert words[n2] == 0
+
+
+@pytest.mark.parametrize("paired", [False, True])
+def test_packed_batch_equals_ascii_batch(world, paired):
+    eng, synth, dev, gb, goff, db, odb = world
+    seqs = _ragged_batch(gb, goff, 2 + paired)
+    rb, ro = orc.pack_reads(seqs)
+    nq = len(seqs) // 2 if paired else len(seqs)
+    ws = eng.Workspace(db, nq, len(rb) + 64)
+    oc, on = odb.query(rb, ro, paired, max_cand=4, emulate_ranks=2, threads=8)
+    packed = eng.pack_bases_host(rb)
+    for qf in (0, eng.MCQ_NO_WAVE16, eng.MCQ_FORCE_BLOCK_PATH):
+        c0, n0 = ws.query_host(rb, ro, paired, max_cand=4, emulate_ranks=2, flags=qf)
+        c1, n1 = ws.query_host(packed, ro, paired, max_cand=4, emulate_ranks=2, flags=qf, packed=True)
+        assert np.array_equal(n0, on) and np.array_equal(n1, on), qf
+        mask = np.arange(4)[None, :] < on[:, None]
+        assert np.array_equal(c0[mask], oc[mask]) and np.array_equal(c1[mask], oc[mask]), qf
+
+
+def test_packed_batch_on_the_sharded_path(world):
+    eng, synth, dev, gb, goff, db, odb = world
+    seqs = _ragged_batch(gb, goff, 5)
+    rb, ro = orc.pack_reads(seqs)
+    n = len(seqs)
+    oc, on = odb.query(rb, ro, False, max_cand=2, emulate_ranks=2, threads=8)
+    packed = torch.from_numpy(eng.pack_bases_host(rb)).to(dev)
+    doff = torch.from_numpy(ro.astype(np.int64)).to(dev)
+    cands = torch.zeros((n, 2, 4), dtype=torch.int32, device=dev); ncand = torch.zeros(n, dtype=torch.int32, device=dev)
+    sh = eng.Shard(db, 1, 0, max_queries=n, max_bases=len(rb) + 64)
+    b = eng.Batch(n, packed.data_ptr(), doff.data_ptr(), 0, eng.MCQ_DEVICE_PTRS | eng.MCQ_BATCH_PACKED, len(rb))
+    o = eng.QueryOpts(2, 2, 0, 0)
+    r = eng.Result(cands.data_ptr(), ncand.data_ptr(), eng.MCQ_DEVICE_PTRS)
+    import ctypes as C
+    eng._chk(eng.lib().mcq_shard_query(sh.h, C.byref(b), C.byref(o), C.byref(r), None, 0, None))
+    sh.sync()
+    gn = ncand.cpu().numpy().view(np.uint32); gc = cands.cpu().numpy().view(np.uint32)
+    assert np.array_equal(gn, on)
+    mask = np.arange(2)[None, :] < on[:, None]
+    assert np.array_equal(gc[mask], oc[mask])
