@@ -185,6 +185,15 @@ int mcq_ws_destroy(mcq_ws* ws);
 int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, const mcq_query_opts* opt,
               mcq_result* out, void* stream);
 
+/* The same for a caller that streams batch after batch from HOST buffers (pinned memory for full speed): the call
+ * returns once the work is enqueued; batch i+1 is copied in and batch i-1 copied out on their own streams while
+ * batch i computes (two batches in flight, staging inside the workspace).  *ticket names the call; mcq_ws_wait(ticket)
+ * returns when its results are in `out` -- until then `in` and `out` must stay untouched.  Calls complete in order.
+ * ASCII bases: bound by PCIe (157 MB per 1 M x 150 bp reads); MCQ_BATCH_PACKED: bound by the kernels.               */
+int mcq_query_pipelined(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, const mcq_query_opts* opt,
+                        mcq_result* out, uint64_t* ticket);
+int mcq_ws_wait(mcq_ws* ws, uint64_t ticket);
+
 /* Waits for the stream, returns MCQ_E_CAPACITY if any query of the last call on ws
  * overflowed the workspace, fills stats (may be NULL).                              */
 int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats);

@@ -99,6 +99,14 @@ struct mcq_ws {
     // staging for host-pointer calls
     char* d_bases; u64* d_seq_off; u32* d_cands; u32* d_ncand;
     u64 last_nq;
+    // host-buffer pipeline (mcq_query_pipelined): two staging sets, copy streams on both sides of the compute stream
+    struct Pipe {
+        char* d_bases[2]; u64* d_seq_off[2]; u32* d_cands[2]; u32* d_ncand[2];
+        hipStream_t s_in, s_k, s_out;
+        hipEvent_t ev_in[2], ev_k[2], ev_out[2];
+        u64 issued;             // calls so far; call i uses set i & 1
+        bool ready;
+    } pipe;
     // optional per-launch timing of the path's kernels (events between them on the call's stream)
     int timing;
     std::vector<TimedLaunch>* ev_used;
@@ -1699,6 +1707,13 @@ extern "C" int mcq_ws_destroy(mcq_ws* ws) {
     if (ws->d_seq_off) (void)hipFree(ws->d_seq_off);
     if (ws->d_cands) (void)hipFree(ws->d_cands);
     if (ws->d_ncand) (void)hipFree(ws->d_ncand);
+    if (ws->pipe.ready) {
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(ws->pipe.d_bases[k]); (void)hipFree(ws->pipe.d_seq_off[k]); (void)hipFree(ws->pipe.d_cands[k]); (void)hipFree(ws->pipe.d_ncand[k]);
+            (void)hipEventDestroy(ws->pipe.ev_in[k]); (void)hipEventDestroy(ws->pipe.ev_k[k]); (void)hipEventDestroy(ws->pipe.ev_out[k]);
+        }
+        (void)hipStreamDestroy(ws->pipe.s_in); (void)hipStreamDestroy(ws->pipe.s_k); (void)hipStreamDestroy(ws->pipe.s_out);
+    }
     for (auto* v : {ws->ev_used, ws->ev_free}) {
         if (!v) continue;
         for (auto& t : *v) for (auto e : t.ev) (void)hipEventDestroy(e);
@@ -1888,10 +1903,91 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     return MCQ_OK;
 }
 
+// ------------------------------------------------------------------ host buffers at rate: copy in / compute / copy out overlapped
+// mcq_query with host pointers is synchronous (copy, run, copy, wait): 1.87e8 reads/s on configs[1], the copies being
+// 3.3 ms of the 5.6.  The pipelined form keeps two batches in flight: batch i+1 is copied in and batch i-1 copied out
+// on their own streams while batch i computes -- 3.2e8 reads/s with ASCII bases (then bound by PCIe: 157 MB per 1 M reads
+// at 47 GB/s), kernel-bound with MCQ_BATCH_PACKED.
+static int pipe_init(mcq_ws* ws) {
+    auto& p = ws->pipe;
+    if (p.ready) return MCQ_OK;
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipMalloc(&p.d_bases[k], std::max<u64>(1, ws->max_bases) + 16));
+        HIPCHK(hipMalloc(&p.d_seq_off[k], (2 * ws->max_queries + 2) * 8));
+        HIPCHK(hipMalloc(&p.d_cands[k], std::max<u64>(1, ws->max_queries) * 16 * 16));
+        HIPCHK(hipMalloc(&p.d_ncand[k], std::max<u64>(1, ws->max_queries) * 4));
+        HIPCHK(hipEventCreateWithFlags(&p.ev_in[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p.ev_k[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p.ev_out[k], hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&p.s_k, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking));
+    p.issued = 0; p.ready = true;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_query_pipelined(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, const mcq_query_opts* opt,
+                                   mcq_result* out, uint64_t* ticket) {
+    if (!db || !ws || !in || !opt || !out || !ticket) return fail(MCQ_E_ARG, "null argument");
+    if ((in->flags & MCQ_DEVICE_PTRS) || (out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the pipelined call takes host buffers");
+    if (in->flags & MCQ_BATCH_RANGES) return fail(MCQ_E_ARG, "MCQ_BATCH_RANGES needs device pointers");
+    OptDev od;
+    int rc = make_opt(opt, od); if (rc) return rc;
+    HIPCHK(hipSetDevice(db->device));
+    const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
+    if (nq > ws->max_queries) return fail(MCQ_E_ARG, "batch has more queries than the workspace allows");
+    const u64 nbases = in->n_seqs ? in->seq_off[in->n_seqs] - in->seq_off[0] : 0;
+    if (nbases > ws->max_bases) return fail(MCQ_E_ARG, "batch has more bases than the workspace allows");
+    if (in->n_seqs && in->seq_off[0] != 0) return fail(MCQ_E_ARG, "host batches must start at offset 0");
+    const bool packed = (in->flags & MCQ_BATCH_PACKED) != 0;
+    if (packed && in->n_bases && in->n_bases != nbases) return fail(MCQ_E_ARG, "mcq_batch.n_bases must equal seq_off[n_seqs] for a packed batch");
+    rc = pipe_init(ws); if (rc) return rc;
+    auto& p = ws->pipe;
+    const u64 i = p.issued;
+    const int k = (int)(i & 1);
+    // in: this staging set was last read by the kernels of call i - 2
+    if (i >= 2) HIPCHK(hipStreamWaitEvent(p.s_in, p.ev_k[k], 0));
+    const u64 bytes = packed ? mcq_packed_bytes(nbases) : nbases;
+    if (bytes) HIPCHK(hipMemcpyAsync(p.d_bases[k], in->bases, bytes, hipMemcpyHostToDevice, p.s_in));
+    HIPCHK(hipMemcpyAsync(p.d_seq_off[k], in->seq_off, (in->n_seqs + 1) * 8, hipMemcpyHostToDevice, p.s_in));
+    HIPCHK(hipEventRecord(p.ev_in[k], p.s_in));
+    // compute: after its input arrived and its result set was copied out (call i - 2)
+    HIPCHK(hipStreamWaitEvent(p.s_k, p.ev_in[k], 0));
+    if (i >= 2) HIPCHK(hipStreamWaitEvent(p.s_k, p.ev_out[k], 0));
+    mcq_batch hin = *in; hin.n_bases = nbases;
+    BatchDev b; rc = batch_dev(&hin, p.d_bases[k], p.d_seq_off[k], b); if (rc) return rc;
+    OutDev o; o.cands = p.d_cands[k]; o.ncand = p.d_ncand[k];
+    DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
+    rc = launch_query(db, ws, b, od, o, p.s_k, force_bits(opt->flags) | (od.big ? 1 : 0), dbg); if (rc) return rc;
+    HIPCHK(hipEventRecord(p.ev_k[k], p.s_k));
+    // out
+    HIPCHK(hipStreamWaitEvent(p.s_out, p.ev_k[k], 0));
+    if (nq) {
+        HIPCHK(hipMemcpyAsync(out->cands, p.d_cands[k], nq * od.max_cand * 16, hipMemcpyDeviceToHost, p.s_out));
+        HIPCHK(hipMemcpyAsync(out->n_cand, p.d_ncand[k], nq * 4, hipMemcpyDeviceToHost, p.s_out));
+    }
+    HIPCHK(hipEventRecord(p.ev_out[k], p.s_out));
+    *ticket = i;
+    p.issued = i + 1;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_ws_wait(mcq_ws* ws, uint64_t ticket) {
+    if (!ws || !ws->pipe.ready) return fail(MCQ_E_ARG, "no pipelined call on this workspace");
+    auto& p = ws->pipe;
+    if (ticket >= p.issued) return fail(MCQ_E_ARG, "unknown ticket");
+    if (ticket + 2 < p.issued) return MCQ_OK;              // a later call on the same staging set has already waited for it
+    HIPCHK(hipSetDevice(ws->device));
+    HIPCHK(hipEventSynchronize(p.ev_out[ticket & 1]));
+    return MCQ_OK;
+}
+
 extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
     if (!ws) return fail(MCQ_E_ARG, "null argument");
     HIPCHK(hipSetDevice(ws->device));
     hipStream_t st = (hipStream_t)stream;
+    if (ws->pipe.ready && ws->pipe.issued) { HIPCHK(hipStreamSynchronize(ws->pipe.s_k)); HIPCHK(hipStreamSynchronize(ws->pipe.s_out)); }
     HIPCHK(hipMemcpyAsync(ws->ctr_host, ws->ctr, sizeof(CountersDev), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (stats) {

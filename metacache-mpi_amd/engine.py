@@ -98,6 +98,8 @@ def lib():
         L.mcq_ws_destroy.argtypes = [C.c_void_p]
         L.mcq_query.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         L.mcq_ws_sync.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.mcq_query_pipelined.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.POINTER(QueryOpts), C.POINTER(Result), C.POINTER(C.c_uint64)]
+        L.mcq_ws_wait.argtypes = [C.c_void_p, C.c_uint64]
         L.mcq_owner.restype = C.c_uint32; L.mcq_owner.argtypes = [C.c_uint32, C.c_uint32]
         L.mcq_debug_matches.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Batch), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64]
         L.mcq_ws_timing.argtypes = [C.c_void_p, C.c_int]
@@ -284,6 +286,19 @@ class Workspace:
         o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
         r = Result(cands_ptr, ncand_ptr, MCQ_DEVICE_PTRS)
         _chk(lib().mcq_query(self.db.h, self.h, C.byref(b), C.byref(o), C.byref(r), stream))
+
+    # ---- host buffers, pipelined: raw HOST pointers (pinned), returns a ticket for wait()
+    def query_pipelined(self, bases_ptr, seq_off_ptr, n_seqs, paired, cands_ptr, ncand_ptr, max_cand=2, emulate_ranks=1,
+                        insert_size_max=0, flags=0, packed_bases=0):
+        b = Batch(n_seqs, bases_ptr, seq_off_ptr, 1 if paired else 0, MCQ_BATCH_PACKED if packed_bases else 0, packed_bases)
+        o = QueryOpts(max_cand, emulate_ranks, insert_size_max, flags)
+        r = Result(cands_ptr, ncand_ptr, 0)
+        t = C.c_uint64(0)
+        _chk(lib().mcq_query_pipelined(self.db.h, self.h, C.byref(b), C.byref(o), C.byref(r), C.byref(t)))
+        return int(t.value)
+
+    def wait(self, ticket):
+        _chk(lib().mcq_ws_wait(self.h, ticket))
 
     def timing(self, enable):
         _chk(lib().mcq_ws_timing(self.h, 1 if enable else 0))

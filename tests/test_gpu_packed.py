@@ -100,3 +100,34 @@ def test_packed_batch_on_the_sharded_path(world):
     assert np.array_equal(gn, on)
     mask = np.arange(2)[None, :] < on[:, None]
     assert np.array_equal(gc[mask], oc[mask])
+
+
+def test_pipelined_host_calls_equal_synchronous_ones(world):
+    """mcq_query_pipelined: six batches (ASCII and packed alternating) with two in flight; every ticket's result equals
+    the synchronous mcq_query on the same batch"""
+    eng, synth, dev, gb, goff, db, odb = world
+    n = 600
+    ws = eng.Workspace(db, n, 2_000_000)
+    want, got, tickets, keep = [], [], [], []
+    for i in range(6):
+        seqs = _ragged_batch(gb, goff, 40 + i)
+        rb, ro = orc.pack_reads(seqs)
+        sync = eng.Workspace(db, n, len(rb) + 64)
+        want.append(sync.query_host(rb, ro, False, max_cand=3, emulate_ranks=2))
+        src = eng.pack_bases_host(rb) if i % 2 else np.frombuffer(rb, np.uint8).copy()
+        ro = np.ascontiguousarray(ro, np.uint64)
+        cands = np.zeros((n, 3, 4), np.uint32); ncand = np.zeros(n, np.uint32)
+        keep.append((src, ro, cands, ncand))
+        if i >= 2:
+            ws.wait(tickets[i - 2])
+        tickets.append(ws.query_pipelined(src.ctypes.data, ro.ctypes.data, n, False, cands.ctypes.data, ncand.ctypes.data, max_cand=3,
+                                          emulate_ranks=2, packed_bases=len(rb) if i % 2 else 0))
+    for t in tickets:
+        ws.wait(t)
+    for i in range(6):
+        wc, wn = want[i]
+        _, _, cands, ncand = keep[i]
+        assert np.array_equal(ncand, wn), i
+        mask = np.arange(3)[None, :] < wn[:, None]
+        assert np.array_equal(cands[mask], wc[mask]), i
+    assert ws.sync()["n_queries"] == n
