@@ -32,9 +32,12 @@ namespace mcq {
 
 // ------------------------------------------------------------------ structures
 struct DbDev {
-    const uint4* slots;      // {key, len, off_lo, off_hi}; key == MCQ_EMPTY: unused
+    const uint4* slots;      // 64-B buckets, 4 uint4 each: {key, len, 14 words}; key == MCQ_EMPTY: unused.  A list of up to
+                             // 14 compact (7 wide) locations sits in the bucket itself, a longer one behind the buckets:
+                             // words 2,3 = its offset there
     u32 slot_mask;           // nslots - 1 (power of two)
-    const void* locs;        // u64 (tgt<<32)|win, or u32 (tgt<<wb)|win when `compact`
+    const void* locs;        // base of all lists = the bucket array itself (the long lists follow it in the same allocation):
+                             // u64 (tgt<<32)|win, or u32 (tgt<<wb)|win when `compact`
     u32 wb;                  // window-id bits inside a location word (32 for u64 locations)
     u32 compact;
     const u32* tgt2tax;
@@ -548,14 +551,27 @@ __device__ __forceinline__ u32 wave_sketch_b(const BatchDev& b, u64 at, u32 n, u
 }
 
 // ------------------------------------------------------------------ row 6: probe
-// Linear probing over 16-byte slots; one 16-B load returns key, list length and offset.
+// Linear probing over 64-B buckets; one 16-B load returns key and list length -- and, for the short lists most features
+// have, the bucket IS the list: its locations are in the same 64-B sector the probe has just brought in, so the gather
+// that follows hits the cache instead of fetching a second random sector (r01: 55 sectors per read, 29 of them list
+// heads).  off = index of the list's first location relative to db.locs, in location units, for both kinds of list.
+#define MCQ_BUCKET_BYTES 64u
+__device__ __forceinline__ uint4 bucket_head(const DbDev& db, u32 idx) { return db.slots[(u64)idx * (MCQ_BUCKET_BYTES / 16)]; }
+// locations per bucket unit / inline capacity / first inline location, by location width (compact: 4 B, else 8 B)
+__device__ __host__ __forceinline__ u32 bucket_units(u32 compact) { return 8u << compact; }
+__device__ __host__ __forceinline__ u32 bucket_inline_max(u32 compact) { return 7u << compact; }
+__device__ __forceinline__ void bucket_list(const DbDev& db, u32 idx, const uint4& sl, u64& off, u32& len) {
+    len = sl.y;
+    off = len <= bucket_inline_max(db.compact) ? (u64)idx * bucket_units(db.compact) + (1u << db.compact)
+                                                : (((u64)db.slot_mask + 1) << (3 + db.compact)) + (((u64)sl.w << 32) | sl.z);
+}
 __device__ __forceinline__ void probe(const DbDev& db, u32 f, u64& off, u32& len) {
     len = 0; off = 0;
     if (f == MCQ_EMPTY) return;
     u32 idx = tmh(f) & db.slot_mask;
     while (true) {
-        uint4 sl = db.slots[idx];
-        if (sl.x == f) { len = sl.y; off = ((u64)sl.w << 32) | sl.z; return; }
+        const uint4 sl = bucket_head(db, idx);
+        if (sl.x == f) { bucket_list(db, idx, sl, off, len); return; }
         if (sl.x == MCQ_EMPTY) return;
         idx = (idx + 1) & db.slot_mask;
     }

@@ -65,8 +65,7 @@ struct mcq_db {
     int device;
     u64 nslots;
     u64 n_keys_local, n_locs_local;
-    uint4* slots;
-    void* locs;
+    uint4* slots;             // one allocation: the buckets, then the lists too long for a bucket
     u32* tgt2tax;
     u32 n_shards, shard_id;
     u64 bytes;
@@ -115,49 +114,57 @@ struct mcq_ws {
 };
 
 // ------------------------------------------------------------------ kernels: table build
-__global__ void k_fill_slots(uint4* slots, u64 n) {
+__global__ void k_fill_slots(uint4* slots, u64 n_uint4) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) slots[i] = make_uint4(MCQ_EMPTY, 0, 0, 0);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_uint4; i += stride) slots[i] = make_uint4(MCQ_EMPTY, 0, 0, 0);
 }
 
-// one thread per key: claim a slot with CAS on the key word, then fill length/offset.
-// new_off[i] = offset of key i's list in the handle's own location array.
-__global__ void k_insert_keys(uint4* slots, u32 mask, const u32* keys, const u64* new_off, u64 n_keys,
-                              u32 n_shards, u32 shard_id) {
+// one thread per key: claim a bucket with CAS on the key word, then fill it: length, and either the list itself
+// (up to 14 compact / 7 wide locations) or the offset of the list among the long ones (ext_off)
+template <class KeyT>
+__global__ void k_insert_keys(uint4* slots, u32 mask, const u32* keys, const u64* list_off, const u64* own_len, const u64* ext_off,
+                              const u64* locs, u64 n_keys, u32 wb) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_keys) return;
-    u32 key = keys[i];
-    u64 b = new_off[i], e = new_off[i + 1];
-    if (e == b) return;                                   // foreign or empty
-    (void)n_shards; (void)shard_id;
+    const u32 len = (u32)own_len[i];
+    if (len == 0) return;                                 // foreign or empty
+    const u32 key = keys[i];
+    constexpr u32 INL = (MCQ_BUCKET_BYTES - 8) / sizeof(KeyT);
     u32 idx = tmh(key) & mask;
     while (true) {
-        u32 prev = atomicCAS(reinterpret_cast<u32*>(&slots[idx]), MCQ_EMPTY, key);
+        u32* w = reinterpret_cast<u32*>(&slots[(u64)idx * (MCQ_BUCKET_BYTES / 16)]);
+        const u32 prev = atomicCAS(w, MCQ_EMPTY, key);
         if (prev == MCQ_EMPTY) {
-            u32* w = reinterpret_cast<u32*>(&slots[idx]);
-            w[1] = (u32)(e - b); w[2] = (u32)b; w[3] = (u32)(b >> 32);
+            w[1] = len;
+            if (len <= INL) {
+                KeyT* dst = reinterpret_cast<KeyT*>(w + 2);
+                const u64 src = list_off[i];
+                for (u32 t = 0; t < len; ++t) { const u64 l = locs[src + t]; dst[t] = (KeyT)(((l >> 32) << wb) | (l & 0xFFFFFFFFull)); }
+            } else { const u64 b = ext_off[i]; w[2] = (u32)b; w[3] = (u32)(b >> 32); }
             return;
         }
         idx = (idx + 1) & mask;
     }
 }
 
-// list length per key if owned by this shard, else 0
-__global__ void k_owned_len(const u32* keys, const u64* list_off, u64 n_keys, u32 n_shards, u32 shard_id, u64* out_len) {
+// list length per key if owned by this shard, else 0; ext_len: the same for lists that do not fit a bucket
+__global__ void k_owned_len(const u32* keys, const u64* list_off, u64 n_keys, u32 n_shards, u32 shard_id, u32 inline_max, u64* out_len, u64* ext_len) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_keys) return;
     u32 own = (u32)(((u64)tmh(keys[i]) * n_shards) >> 32);
-    out_len[i] = (own == shard_id) ? (list_off[i + 1] - list_off[i]) : 0;
+    const u64 len = (own == shard_id) ? (list_off[i + 1] - list_off[i]) : 0;
+    out_len[i] = len;
+    ext_len[i] = len > inline_max ? len : 0;
 }
 
-// copy owned lists into the compacted location array
+// copy the owned long lists behind the buckets
 template <class KeyT>
-__global__ void k_copy_lists(const u64* list_off, const u64* new_off, const u64* locs, KeyT* out, u64 n_keys, u32 wb) {
+__global__ void k_copy_lists(const u64* list_off, const u64* ext_off, const u64* locs, KeyT* out, u64 n_keys, u32 wb) {
     // one wave per key, grid-stride (the grid is bounded: total threads must stay < 2^32)
     const u32 lane = threadIdx.x & 63;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 key = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; key < n_keys; key += nwaves) {
-        u64 b = new_off[key], n = new_off[key + 1] - b, src = list_off[key];
+        u64 b = ext_off[key], n = ext_off[key + 1] - b, src = list_off[key];
         for (u64 t = lane; t < n; t += 64) {
             u64 l = locs[src + t];
             out[b + t] = (KeyT)(((l >> 32) << wb) | (l & 0xFFFFFFFFull));
@@ -1570,29 +1577,8 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
         d_keys = t_keys; d_off = t_off; d_locs = t_locs;
     }
 
-    // owned list lengths -> compacted offsets
-    u64 *d_len = nullptr, *d_new = nullptr;
-    HIPCHK(tmp.alloc((void**)&d_len, std::max<u64>(1, nk) * 8));
-    HIPCHK(tmp.alloc((void**)&d_new, (nk + 1) * 8));
-    const u32 TB = 256;
-    if (nk) hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id, d_len);
-    { int rcs = device_exclusive_scan<u64>(d_len, d_new, nk, 0); if (rcs) return rcs; }
-    u64 nl_local = 0;
-    HIPCHK(hipMemcpy(&nl_local, d_new + nk, 8, hipMemcpyDeviceToHost));
-    // number of owned non-empty keys (for the table size) -- count on host from lengths
-    u64 nk_local = 0;
-    {
-        std::vector<u64> h_len(nk);
-        if (nk) HIPCHK(hipMemcpy(h_len.data(), d_len, nk * 8, hipMemcpyDeviceToHost));
-        for (u64 i = 0; i < nk; ++i) nk_local += h_len[i] > 0;
-    }
-    // load factor <= 0.25: 43 % of a read's features are not in the table and an unsuccessful linear probe
-    // walks 2.5 slots at load 0.5 but 1.4 at 0.25 -- fewer 64-B sectors per read for 16 B per key more
-    u64 slots_per_key = 4;
-    if (const char* e = getenv("MCQ_SLOTS_PER_KEY")) slots_per_key = std::max<u64>(1, strtoull(e, nullptr, 10));   // tuning knob
-    const u64 nslots = std::max<u64>(1024, pow2ceil64(nk_local * slots_per_key));
-    if (nslots > (1ull << 32)) { return fail(MCQ_E_UNSUPPORTED, "table too large"); }
     // compact locations: (tgt << wb) | win in 32 bits when target and window ids fit
+    const u32 TB = 256;
     u32 wb = 32, compact = 0;
     if (!(desc->flags & MCQ_DB_LOCS_64)) {
         u32* d_mw = nullptr; u32 maxwin = 0;
@@ -1609,37 +1595,64 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     }
     const u64 locsz = compact ? 4 : 8;
 
+    // owned list lengths; offsets of the lists that do not fit a bucket
+    u64 *d_len = nullptr, *d_ext = nullptr, *d_new = nullptr;
+    HIPCHK(tmp.alloc((void**)&d_len, std::max<u64>(1, nk) * 8));
+    HIPCHK(tmp.alloc((void**)&d_ext, std::max<u64>(1, nk) * 8));
+    HIPCHK(tmp.alloc((void**)&d_new, (nk + 1) * 8));
+    if (nk) hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id,
+                               bucket_inline_max(compact), d_len, d_ext);
+    { int rcs = device_exclusive_scan<u64>(d_ext, d_new, nk, 0); if (rcs) return rcs; }
+    u64 nl_ext = 0;
+    HIPCHK(hipMemcpy(&nl_ext, d_new + nk, 8, hipMemcpyDeviceToHost));
+    // owned non-empty keys (for the table size) and owned locations -- counted on the host from the lengths
+    u64 nk_local = 0, nl_local = 0;
+    {
+        std::vector<u64> h_len(nk);
+        if (nk) HIPCHK(hipMemcpy(h_len.data(), d_len, nk * 8, hipMemcpyDeviceToHost));
+        for (u64 i = 0; i < nk; ++i) { nk_local += h_len[i] > 0; nl_local += h_len[i]; }
+    }
+    // load factor <= 0.25 (43 % of a read's features are not in the table, and every step of a linear probe is a new
+    // 64-B sector) while the buckets stay below 48 GB, else <= 0.5; MCQ_SLOTS_PER_KEY overrides
+    u64 slots_per_key = (pow2ceil64(nk_local * 4) * MCQ_BUCKET_BYTES <= (48ull << 30)) ? 4 : 2;
+    if (const char* e = getenv("MCQ_SLOTS_PER_KEY")) slots_per_key = std::max<u64>(1, strtoull(e, nullptr, 10));   // tuning knob
+    const u64 nslots = std::max<u64>(1024, pow2ceil64(nk_local * slots_per_key));
+    if (nslots > (1ull << 32)) { return fail(MCQ_E_UNSUPPORTED, "table too large"); }
+
     mcq_db* db = new mcq_db();
     memset(db, 0, sizeof(*db));
     db->device = desc->device; db->n_shards = n_shards; db->shard_id = desc->shard_id;
     db->n_keys_local = nk_local; db->n_locs_local = nl_local; db->nslots = nslots;
+    const u64 table_bytes = nslots * MCQ_BUCKET_BYTES + std::max<u64>(1, nl_ext) * locsz;
 #define DBCHK(expr) HIPCHK_OR(expr, (void)mcq_db_destroy(db))
-    DBCHK(hipMalloc(&db->slots, db->nslots * sizeof(uint4)));
-    DBCHK(hipMalloc(&db->locs, std::max<u64>(1, nl_local) * locsz));
+    DBCHK(hipMalloc(&db->slots, table_bytes));
     DBCHK(hipMalloc(&db->tgt2tax, std::max<u32>(1, desc->n_targets) * 4));
     if (desc->n_targets)
         DBCHK(hipMemcpy(db->tgt2tax, desc->tgt2tax, (u64)desc->n_targets * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_fill_slots, dim3((u32)std::min<u64>((db->nslots + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, db->slots, db->nslots);
+    const u64 n_uint4 = nslots * (MCQ_BUCKET_BYTES / 16);
+    hipLaunchKernelGGL(k_fill_slots, dim3((u32)std::min<u64>((n_uint4 + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, db->slots, n_uint4);
     if (nk) {
-        hipLaunchKernelGGL(k_insert_keys, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, db->slots, (u32)(db->nslots - 1),
-                           d_keys, d_new, nk, n_shards, desc->shard_id);
+        const dim3 ig((u32)((nk + TB - 1) / TB));
+        if (compact) hipLaunchKernelGGL(k_insert_keys<u32>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), d_keys, d_off, (const u64*)d_len, (const u64*)d_new, d_locs, nk, wb);
+        else         hipLaunchKernelGGL(k_insert_keys<u64>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), d_keys, d_off, (const u64*)d_len, (const u64*)d_new, d_locs, nk, 32u);
         DBCHK(hipGetLastError());
+        char* ext = reinterpret_cast<char*>(db->slots) + nslots * MCQ_BUCKET_BYTES;
         const dim3 cg((u32)std::min<u64>((nk * 64 + TB - 1) / TB, 1u << 20));
-        if (compact) hipLaunchKernelGGL(k_copy_lists<u32>, cg, dim3(TB), 0, 0, d_off, d_new, d_locs, (u32*)db->locs, nk, wb);
-        else         hipLaunchKernelGGL(k_copy_lists<u64>, cg, dim3(TB), 0, 0, d_off, d_new, d_locs, (u64*)db->locs, nk, 32u);
+        if (compact) hipLaunchKernelGGL(k_copy_lists<u32>, cg, dim3(TB), 0, 0, d_off, (const u64*)d_new, d_locs, (u32*)ext, nk, wb);
+        else         hipLaunchKernelGGL(k_copy_lists<u64>, cg, dim3(TB), 0, 0, d_off, (const u64*)d_new, d_locs, (u64*)ext, nk, 32u);
         DBCHK(hipGetLastError());
     }
     DBCHK(hipDeviceSynchronize());
 #undef DBCHK
 
-    db->d.slots = db->slots; db->d.slot_mask = (u32)(db->nslots - 1); db->d.locs = db->locs;
+    db->d.slots = db->slots; db->d.slot_mask = (u32)(db->nslots - 1); db->d.locs = db->slots;
     db->d.wb = wb; db->d.compact = compact;
     db->d.tgt2tax = db->tgt2tax; db->d.n_targets = desc->n_targets;
     db->d.k = desc->k; db->d.s = desc->sketch_size; db->d.winlen = desc->winlen; db->d.winstride = desc->winstride;
     db->d.tgt_winstride = desc->tgt_winstride ? desc->tgt_winstride : desc->winstride;
     db->d.magic_stride = (u32)std::min<u64>((1ull << 32) / db->d.winstride, 0xFFFFFFFFull);
     db->d.magic_tgt_stride = (u32)std::min<u64>((1ull << 32) / db->d.tgt_winstride, 0xFFFFFFFFull);
-    db->bytes = db->nslots * sizeof(uint4) + std::max<u64>(1, nl_local) * locsz + (u64)desc->n_targets * 4;
+    db->bytes = table_bytes + (u64)desc->n_targets * 4;
     *out = db;
     return MCQ_OK;
 }
@@ -1647,7 +1660,7 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
 extern "C" int mcq_db_destroy(mcq_db* db) {
     if (!db) return MCQ_OK;
     (void)hipSetDevice(db->device);
-    (void)hipFree(db->slots); (void)hipFree(db->locs); (void)hipFree(db->tgt2tax);
+    (void)hipFree(db->slots); (void)hipFree(db->tgt2tax);
     delete db;
     return MCQ_OK;
 }

@@ -131,14 +131,13 @@ __global__ __launch_bounds__(256) void k_shard_lookup(DbDev db, u32 n_ranks, con
         for (int k = 0; k < 4; ++k) {
             idx[k] = tmh(f[k]) & db.slot_mask;
             sl[k] = make_uint4(MCQ_EMPTY, 0, 0, 0);
-            if (f[k] != MCQ_EMPTY) sl[k] = db.slots[idx[k]];
+            if (f[k] != MCQ_EMPTY) sl[k] = bucket_head(db, idx[k]);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            while (sl[k].x != f[k] && sl[k].x != MCQ_EMPTY) { idx[k] = (idx[k] + 1) & db.slot_mask; sl[k] = db.slots[idx[k]]; }
-            const bool hit = f[k] != MCQ_EMPTY && sl[k].x == f[k];
-            len[k] = hit ? sl[k].y : 0u;
-            off[k] = hit ? (((u64)sl[k].w << 32) | sl[k].z) : 0ull;
+            while (sl[k].x != f[k] && sl[k].x != MCQ_EMPTY) { idx[k] = (idx[k] + 1) & db.slot_mask; sl[k] = bucket_head(db, idx[k]); }
+            len[k] = 0; off[k] = 0;
+            if (f[k] != MCQ_EMPTY && sl[k].x == f[k]) bucket_list(db, idx[k], sl[k], off[k], len[k]);
         }
     }
 #pragma unroll

@@ -13,7 +13,7 @@ for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "WRITE_SIZE TCC_MISS_sum TCC_EA0_RDREQ_sum" \
            "TCC_EA0_RDREQ_32B_sum TCC_REQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $PMC --kernel-include-regex "k_query|k_reduce" --output-format csv -d gpurun_out/${TAG}_pmc$i -- python3 bench.py $ARGS > gpurun_out/${TAG}_pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 gpurun_out/${TAG}_pmc$i.log; }
+  rocprofv3 --kernel-trace --pmc $PMC --kernel-include-regex "k_query|k_reduce|k_shard" --output-format csv -d gpurun_out/${TAG}_pmc$i -- python3 bench.py $ARGS > gpurun_out/${TAG}_pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -5 gpurun_out/${TAG}_pmc$i.log; }
   echo "pass $i done"
 done
 python3 scripts/summarize_prof.py $TAG gpurun_out/${TAG}_trace gpurun_out/${TAG}_pmc1 gpurun_out/${TAG}_pmc2 gpurun_out/${TAG}_pmc3 gpurun_out/${TAG}_pmc4 gpurun_out/${TAG}_pmc5 > gpurun_out/${TAG}_summary.txt 2>&1

@@ -26,7 +26,7 @@ for d in sys.argv[3:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if k.startswith("k_query") or k.startswith("k_reduce") or k.startswith("k_sketch") or k.startswith("k_lookup"):
+            if k.startswith("k_query") or k.startswith("k_reduce") or k.startswith("k_sketch") or k.startswith("k_lookup") or k.startswith("k_shard"):
                 pm[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 if pm:
     with open(os.path.join(out, tag + "_pmc.csv"), "w") as w:
