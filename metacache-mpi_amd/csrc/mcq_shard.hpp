@@ -283,7 +283,7 @@ static int shard_exchange(mcq_shard* c, const void* send_base, u64 send_stride, 
             return fail(MCQ_E_HIP, "the caller's exchange function failed");
         return MCQ_OK;
     }
-    if (n == 1) {
+    if (n == 1 && !c->have_comm) {
         if (send_bytes[0] != recv_bytes[0]) return fail(MCQ_E_ARG, "self exchange with different sizes");
         if (send_bytes[0]) HIPCHK(hipMemcpyAsync(recv_base, send_base, send_bytes[0], hipMemcpyDeviceToDevice, st));
         return MCQ_OK;
@@ -378,7 +378,10 @@ extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, m
 
 extern "C" int mcq_shard_comm_rccl(mcq_shard* c, const void* unique_id) {
     if (!c || !unique_id) return fail(MCQ_E_ARG, "null argument");
-    if (c->n == 1) return MCQ_OK;                     // nothing to connect: blocks are copied on the device
+    // one rank: nothing to connect, its own blocks are read in place -- unless the test hook asks for the real thing
+    // (a communicator of one rank whose blocks go through ncclSend / ncclRecv to itself: the only way to run the RCCL
+    // code path on a box with one GPU)
+    if (c->n == 1 && !getenv("MCQ_SHARD_FORCE_RCCL")) return MCQ_OK;
     int rc = rccl_load(); if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
     ncclUniqueId id; memcpy(&id, unique_id, sizeof(id));
@@ -464,7 +467,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
 
     // a rank's own blocks never travel: with one rank the owner side reads the home side's send buffers in place
-    const bool alias = n == 1 && !c->xfn;
+    const bool alias = n == 1 && !c->xfn && !c->have_comm;
     u32* const recvF = alias ? b.sendF : c->recvF;
     u32* const recvR = alias ? c->sendR : c->recvR;
     void* const recvL = alias ? c->sendL : c->recvL;

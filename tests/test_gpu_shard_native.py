@@ -127,3 +127,40 @@ def test_ranks_on_one_gpu_over_gloo(paired, world, locs64):
             assert bool(z["ok"][0]), f
             assert (z["overflow"] >= (36 if paired else 72)).all(), z["overflow"]     # wide and long reads left the first stage
             assert (z["caps"] > 0).all()
+
+
+def test_rccl_transport_with_one_rank(tmp_path):
+    """the RCCL code path itself (dlopen of librccl, ncclGetUniqueId, ncclCommInitRank, grouped ncclSend / ncclRecv of
+    every block) on a box with one GPU: a communicator of ONE rank whose blocks travel to itself through RCCL
+    (MCQ_SHARD_FORCE_RCCL) -- exact mode, then padded mode -- against the fused kernel.  In a child process with a
+    timeout: a transport that hangs must fail the test, not the suite."""
+    code = r"""
+import importlib, os, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+eng = importlib.import_module("metacache-mpi_amd.engine")
+synth = importlib.import_module("metacache-mpi_amd.synth")
+dev = torch.device("cuda", 0)
+gb, goff, species = synth.make_genomes(5, 6, 150_000, 250_000, 0.02, seed=3, device=dev)
+sp32 = species.to(torch.int32).contiguous()
+db = eng.Database.build(gb.data_ptr(), goff.data_ptr(), sp32.data_ptr(), goff.numel() - 1, emulate_ranks=2)
+n, L = 30000, 150
+st = torch.cuda.current_stream(dev).cuda_stream
+sh = eng.Shard(db, 1, 0, max_queries=n, max_bases=n * L)
+sh.comm_rccl(eng.Shard.unique_id())
+ws = eng.Workspace(db, n, n * L)
+ok = True
+for i in range(3):
+    r, ro, _ = synth.sample_reads(gb, goff, n, L, 0.01, 0.002, seed=10 + i)
+    c0 = torch.zeros((n, 2, 4), dtype=torch.int32, device=dev); n0 = torch.zeros(n, dtype=torch.int32, device=dev)
+    c1 = torch.zeros_like(c0); n1 = torch.zeros_like(n0)
+    ws.query_device(r.data_ptr(), ro.data_ptr(), n, False, c0.data_ptr(), n0.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, c1.data_ptr(), n1.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+    sh.sync(st)
+    m = torch.arange(2, device=dev)[None, :] < n0[:, None]
+    ok = ok and bool(torch.equal(n0, n1)) and bool(torch.equal(c0[m], c1[m])) and int(n0.sum()) > n
+print("RCCL_SELF_OK" if ok else "RCCL_SELF_MISMATCH", sh.caps())
+""" % ROOT
+    env = dict(os.environ, MCQ_SHARD_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL_SELF_OK" in r.stdout, r.stdout[-3000:]
