@@ -4,7 +4,7 @@
 set -o pipefail
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="--steps 6 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps 6 --warmup 1 --no-cpu-baseline --no-pcie-leg $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_trace -- python3 bench.py $ARGS > gpurun_out/${TAG}_trace.log 2>&1 || exit 1
 i=0
 for PMC in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
