@@ -130,7 +130,10 @@ def main():
     torch.cuda.set_device(dev)
 
     pkg = importlib.import_module("metacache-mpi_amd")
-    pkg.build_hip()
+    if rank == 0:
+        pkg.build_hip()                 # a no-op when the shipped library is current; never N concurrent builds
+    if dist is not None:
+        dist.barrier()
     eng = importlib.import_module("metacache-mpi_amd.engine")
     synth = importlib.import_module("metacache-mpi_amd.synth")
 
