@@ -70,6 +70,7 @@ def parse():
                     help="experiments: extra mcq_query_opts.flags (0x400 raw sort); results stay exact")
     ap.add_argument("--distinct-batches", type=int, default=0, help="0 = one per step (capped by memory)")
     ap.add_argument("--no-pcie-leg", action="store_true")
+    ap.add_argument("--packed-input", action="store_true", help="experiment: the resident batches in the MCQ_BATCH_PACKED form (c2 / paired, fused leg)")
     return ap.parse_args()
 
 
@@ -227,8 +228,23 @@ def main():
         sharded.query(batches[i % nb].data_ptr(), offsets[i % nb].data_ptr(), B, paired, cands_s.data_ptr(), ncand_s.data_ptr(),
                       max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=a.query_flags, stream=stream, next_batch=nxt)
 
+    packed_batches = None
+    if a.packed_input and with_fused:
+        packed_batches = []
+        for r, ro in zip(batches, offsets):
+            nbs = int(ro[-1].item())
+            t = torch.empty(eng.packed_bytes(nbs), dtype=torch.uint8, device=dev)
+            eng.pack_bases_device(r.data_ptr(), nbs, t.data_ptr(), stream)
+            packed_batches.append((t, nbs))
+        torch.cuda.synchronize(dev)
+
     def step_fused(i):
         r, ro = batches[i % nb], offsets[i % nb]
+        if packed_batches is not None:
+            t, nbs = packed_batches[i % nb]
+            ws.query_device(t.data_ptr(), ro.data_ptr(), B, paired, cands.data_ptr(), ncand.data_ptr(),
+                            max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=qflags, stream=stream, packed_bases=nbs)
+            return
         ws.query_device(r.data_ptr(), ro.data_ptr(), B, paired, cands.data_ptr(), ncand.data_ptr(),
                         max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=qflags, stream=stream)
 
@@ -351,7 +367,8 @@ def main():
         out = {
             "metric": "query reads/sec (whole node)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic" + (" (resident batches in the packed 3-bit form)" if a.packed_input else ""),
             "config": {
                 "workload": "%s: %d synthetic genomes (%d species x %d strains, %.1f%% divergence, %.2f Gbp) in HBM, %s per step per GPU, "
                             "k=16 s=16 w=128/113" %
