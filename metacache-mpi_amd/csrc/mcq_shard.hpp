@@ -199,11 +199,9 @@ __global__ __launch_bounds__(256) void k_shard_lookup(DbDev db, u32 n_ranks, con
 }
 
 // zero the cursors / headers of the n_ranks blocks (stride in u32 words)
-__global__ void k_shard_zero_headers(u32* a, u64 stride_a, u32* c, u64 stride_c, u32 n_ranks) {
+__global__ void k_shard_zero_headers(u32* blocks, u64 stride, u32 n_ranks) {
     const u32 i = threadIdx.x;
-    if (i < n_ranks) {
-        for (u32 k = 0; k < MCQ_SHARD_HDR; ++k) { a[(u64)i * stride_a + k] = 0; c[(u64)i * stride_c + k] = 0; }
-    }
+    if (i < n_ranks) for (u32 k = 0; k < MCQ_SHARD_HDR; ++k) blocks[(u64)i * stride + k] = 0;
 }
 // home side after X2: a peer that served more locations than a block carries has truncated this rank's lists
 __global__ void k_shard_check(const u32* recvR, u64 rblk, u32 n_ranks, u64 capLx, u32* err) {
@@ -259,13 +257,14 @@ struct mcq_shard {
     ShardBuf sb[2]; int cur;              // double-buffered home side: the next batch's S1 runs under this batch's exchange
     u32* recvF; u32* sendR; u32* recvR; void* sendL; void* recvL;
     u32* err; u32* err_host;              // device flag word, pinned copy
-    u32* cnt_dev; u32* cnt_host;          // 4 x n words staging of the exact mode's count exchanges
+    u32* cnt_dev; u32* cnt_host;          // staging of the exact mode's count exchanges (2 x n u64 on the device, n u32 / u64 pinned)
     hipStream_t side; hipEvent_t ev_prep[2], ev_done[2];
     bool prepared[2]; const void* prep_key[2][3];
     // transport
     ncclComm_t comm; bool have_comm;
     mcq_exchange_fn xfn; void* xuser;
-    u64 last_nq; u64 sent_features, sent_locations;
+    u64 last_nq;
+    u64 seen_features, seen_locations;    // exact mode: the largest per-peer counts of the batch (sizes the padded mode's blocks)
 };
 static u64 rblk_words(const mcq_shard* c) { return (u64)MCQ_SHARD_HDR + c->capT + c->capF; }
 static u64 fblk_words(const mcq_shard* c) { return (u64)MCQ_SHARD_HDR + c->capF; }
@@ -413,7 +412,7 @@ extern "C" int mcq_shard_get_caps(const mcq_shard* c, uint64_t* features_per_pee
 static int shard_prepare(mcq_shard* c, int k, const mcq_batch* in, hipStream_t st) {
     ShardBuf& b = c->sb[k];
     int rc = mcq_count_windows(c->db, in, b.win_off, st); if (rc) return rc;
-    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendF, fblk_words(c), b.sendF, fblk_words(c), c->n);
+    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendF, fblk_words(c), c->n);
     HIPCHK(hipMemsetAsync(b.feat_cnt, 0, 8, st));
     BatchDev bd; rc = batch_dev(in, in->bases, in->seq_off, bd); if (rc) return rc;
     if (in->n_seqs) {
@@ -482,7 +481,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
         rc = shard_exchange_counts(c, cnt_mine.data(), cnt_theirs.data(), st); if (rc) return rc;
         for (u32 p = 0; p < n; ++p) { sbytes[p] = (MCQ_SHARD_HDR + cnt_mine[p]) * 4; rbytes[p] = (MCQ_SHARD_HDR + cnt_theirs[p]) * 4; mx = std::max(mx, cnt_theirs[p]); }
         capFx = c->capF;                                  // the lookup accepts whatever the header says
-        c->sent_features = mx;
+        c->seen_features = mx;
     } else {
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = ((u64)MCQ_SHARD_HDR + capFx) * 4;
     }
@@ -501,8 +500,8 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     }
 
     // ---- S2: owner side
-    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, c->sendR, rblk_words(c), c->sendR, rblk_words(c), n);
-    if (nq || true) {
+    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, c->sendR, rblk_words(c), n);
+    {
         const dim3 grid(n * c->capT);
         if (c->db->d.compact) hipLaunchKernelGGL(k_shard_lookup<u32>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
                                                  c->sendR, (u32*)c->sendL, c->capL, c->err);
@@ -524,10 +523,10 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
         rc = shard_exchange_counts(c, served.data(), coming.data(), st); if (rc) return rc;
         for (u32 p = 0; p < n; ++p) { sbytes[p] = served[p] * c->locb; rbytes[p] = coming[p] * c->locb; mx = std::max(mx, coming[p]); }
         if (!alias) { rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
-        c->sent_locations = mx;
+        c->seen_locations = mx;
         capLx = c->capL;
         // learn the padded mode's block sizes: the largest count any rank saw this batch, plus a quarter
-        std::vector<u64> mine2(n, (c->sent_features << 32) | std::min<u64>(c->sent_locations, 0xFFFFFFFFull)), all2(n);
+        std::vector<u64> mine2(n, (c->seen_features << 32) | std::min<u64>(c->seen_locations, 0xFFFFFFFFull)), all2(n);
         rc = shard_exchange_counts(c, mine2.data(), all2.data(), st); if (rc) return rc;
         u64 gf = 0, gl = 0;
         for (u32 p = 0; p < n; ++p) { gf = std::max<u64>(gf, all2[p] >> 32); gl = std::max<u64>(gl, all2[p] & 0xFFFFFFFFull); }
