@@ -24,6 +24,20 @@ def cli_path():
     return os.path.join(_HERE, "mcq_query_cli")
 
 
+def mpi_cli_path():
+    """mcq_query_mpi (one process per GPU under mpiexec); built only where an MPI is installed (/opt/conda: MPICH)"""
+    return os.path.join(_HERE, "mcq_query_mpi")
+
+
+_MPI_ROOT = os.environ.get("MCQ_MPI_ROOT", "/opt/conda")
+_MPI_LIBS = ["libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0", "libgomp.so.1"]
+
+
+def mpi_lib_dir():
+    """private directory with links to libmpi and what it needs, so that conda's old libstdc++ is not picked up at run time"""
+    return os.path.join(_HERE, "_mpilib")
+
+
 def build_host(force=False, verbose=False):
     """libmcq_host.so (shard reader, taxonomy keys, classify; g++, no GPU) and the
     mcq_query_cli binary (links both libraries)."""
@@ -37,13 +51,36 @@ def build_host(force=False, verbose=False):
         subprocess.check_call(cmd)
     cli_src = os.path.join(_HERE, "csrc", "host", "mcq_query_cli.cpp")
     cli = cli_path()
-    if force or not os.path.exists(cli) or os.path.getmtime(cli) < max(os.path.getmtime(cli_src), os.path.getmtime(out),
-                                                                         os.path.getmtime(lib_path())):
+    if force or not os.path.exists(cli) or os.path.getmtime(cli) < max(os.path.getmtime(cli_src), os.path.getmtime(out), os.path.getmtime(lib_path()),
+                                                                         os.path.getmtime(os.path.join(_HERE, "csrc", "host", "mcq_cli_common.hpp"))):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "-std=c++14", "-O2", cli_src, "-o", cli, "-L" + _HERE, "-lmcq_hip", "-lmcq_host", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # the MPI program (multi-GPU host in C++): only where an MPI is installed
+    mpi_src = os.path.join(_HERE, "csrc", "host", "mcq_query_mpi.cpp")
+    common = os.path.join(_HERE, "csrc", "host", "mcq_cli_common.hpp")
+    mpi_h = os.path.join(_MPI_ROOT, "include", "mpi.h")
+    mpi_so = os.path.join(_MPI_ROOT, "lib", _MPI_LIBS[0])
+    if os.path.exists(mpi_h) and os.path.exists(mpi_so):
+        os.makedirs(mpi_lib_dir(), exist_ok=True)
+        for l in _MPI_LIBS:
+            dst = os.path.join(mpi_lib_dir(), l)
+            if not os.path.lexists(dst) and os.path.exists(os.path.join(_MPI_ROOT, "lib", l)):
+                os.symlink(os.path.join(_MPI_ROOT, "lib", l), dst)
+        mpi_cli = mpi_cli_path()
+        newest = max(os.path.getmtime(f) for f in (mpi_src, common, out, lib_path()))
+        if force or not os.path.exists(mpi_cli) or os.path.getmtime(mpi_cli) < newest:
+            rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+            # plain g++ (host code only; hipcc would take libmpi.so.12 for a source file)
+            cmd = ["g++", "-std=c++14", "-O2", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(_MPI_ROOT, "include"),
+                   mpi_src, "-o", mpi_cli, "-L" + _HERE, "-lmcq_hip", "-lmcq_host", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", mpi_so,
+                   "-Wl,-rpath-link," + os.path.join(_MPI_ROOT, "lib"), "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/_mpilib",
+                   "-Wl,-rpath," + os.path.join(rocm, "lib")]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
     return out
 
 

@@ -1,174 +1,20 @@
-// mcq_query_cli -- stand-in for `mpiexec -n P metacache query <db> r1.fq r2.fq -pairfiles ...`
-// (src/mode_query.cpp:404-458) around the engine: reads the reference's shard files, runs the per-read path on
-// the GPU through the C ABI, classifies on the host and writes what the reference writes to its -out file:
-//   * the parameter lines                      show_query_parameters    src/printing.cpp:40-113
-//   * "# TABLE_LAYOUT: ..."                    show_query_mapping_header src/classification.cpp:486-512, printing.cpp:243-300
-//   * "# <file1> + <file2>"                    src/querying.h:1337
-//   * one mapping line per read (pair)         show_query_mapping       src/classification.cpp:583-632
-//         taxon formats (rank:name default, -taxids, -taxids-only, -omit-ranks, -lineage)  show_taxon / show_lineage /
-//         show_no_taxon src/printing.cpp:117-201, :305-330;  -tophits list  show_matches src/printing.cpp:333-360
-//   * the summary                              show_summary             src/printing.cpp:622-641,
-//                                              show_taxon_statistics    src/printing.cpp:522-555
-// After sorting, the file equals the reference's byte for byte except for the measured values of the "# time:" and
-// "# speed:" lines (tests/test_gpu_cli.py).  Not reproduced: the reference prints nothing for a thread's chunk in which
-// no read was classified (src/querying.h:1091, :1129).
-//
-// usage: mcq_query_cli <dbprefix> <n_ranks> <r1.fq> <r2.fq|-> [-lowest R] [-highest R] [-maxcand N] [-hitmin N]
-//            [-hitdiff X] [-insertsize N] [-threads N] [-tophits] [-taxids] [-taxids-only] [-omit-ranks] [-lineage]
-//            [-mapped-only] [-nomap] [-noquirks] [-out FILE]
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <fstream>
-#include <iostream>
-#include <string>
-#include <vector>
-
-#include "../../../include/mcq.h"
-#include "../../../include/mcq_host.h"
-
-struct Rec { std::string header, seq; };
-
-// FASTA ('>') and FASTQ ('@') records; sequence may span lines in FASTA (src/sequence_io.cpp:122-285)
-static bool read_records(const std::string& path, std::vector<Rec>& out) {
-    std::ifstream is(path);
-    if (!is.good()) return false;
-    std::string line;
-    while (std::getline(is, line)) {
-        if (line.empty()) continue;
-        if (line[0] == '@') {
-            Rec r; r.header = line.substr(1);
-            std::getline(is, r.seq);
-            std::getline(is, line); std::getline(is, line);          // '+' and qualities
-            out.push_back(std::move(r));
-        } else if (line[0] == '>') {
-            Rec r; r.header = line.substr(1);
-            out.push_back(std::move(r));
-        } else if (!out.empty()) {
-            out.back().seq += line;
-        }
-    }
-    return true;
-}
-
-// taxon_print_mode (src/query_options.h:68-71)
-enum class Mode { rank_id, rank_name, rank_name_id, id, name, name_id };
-
-struct Out {
-    mcq_refdb* db;
-    Mode mode = Mode::rank_name;
-    uint32_t lowest = MCQ_RANK_SEQUENCE, highest = MCQ_RANK_DOMAIN;
-    bool lineage = false, tophits = false;
-    const char* comment = "# "; const char* none = "--"; const char* col = "\t|\t";
-
-    void taxon(std::ostream& os, uint32_t key) const {                       // show_taxon, src/printing.cpp:117-146
-        switch (mode) {
-            default:
-            case Mode::rank_name: os << mcq_rank_name(mcq_refdb_taxon_rank(db, key)) << ':';     // fall through
-            case Mode::name: os << mcq_refdb_taxon_name(db, key); break;
-            case Mode::rank_id: os << mcq_rank_name(mcq_refdb_taxon_rank(db, key)) << ':';       // fall through
-            case Mode::id: os << mcq_refdb_taxon_id(db, key); break;
-            case Mode::rank_name_id: os << mcq_rank_name(mcq_refdb_taxon_rank(db, key)) << ':';  // fall through
-            case Mode::name_id: os << mcq_refdb_taxon_name(db, key) << '(' << mcq_refdb_taxon_id(db, key) << ')'; break;
-        }
-    }
-    void no_taxon(std::ostream& os, uint32_t rank) const {                   // show_no_taxon, src/printing.cpp:151-176
-        switch (mode) {
-            default:
-            case Mode::rank_name: os << mcq_rank_name(rank) << ':';          // fall through
-            case Mode::name: os << none; break;
-            case Mode::rank_id: os << mcq_rank_name(rank) << ':';            // fall through
-            case Mode::id: os << 0; break;
-            case Mode::rank_name_id: os << mcq_rank_name(rank) << ':';       // fall through
-            case Mode::name_id: os << none << '(' << 0 << ')'; break;
-        }
-    }
-    // classification column: show_taxon(os, db, opt, tax), src/printing.cpp:305-330 (collapseUnclassified is on)
-    void best(std::ostream& os, uint32_t key) const {
-        if (key == MCQ_NO_TAXON || mcq_refdb_taxon_rank(db, key) > highest) {
-            if (mode == Mode::id) os << 0; else os << none;
-            return;
-        }
-        const uint32_t tr = mcq_refdb_taxon_rank(db, key);
-        const uint32_t rmin = lowest < tr ? tr : lowest, rmax = lineage ? highest : rmin;
-        for (uint32_t r = rmin; r <= rmax; ++r) {                           // show_lineage, src/printing.cpp:181-201
-            const uint32_t a = mcq_refdb_ancestor(db, key, r);
-            if (a != MCQ_NO_TAXON) taxon(os, a); else no_taxon(os, r);
-            if (r < rmax) os << ',';
-        }
-    }
-    void header_taxon(std::ostream& os) const {                              // show_taxon_header, src/printing.cpp:243-300
-        const uint32_t rmax = lineage ? highest : lowest;
-        for (uint32_t r = lowest; r <= rmax; ++r) {
-            const bool one = lowest == rmax;
-            switch (mode) {
-                default:
-                case Mode::rank_name: os << (one ? "rank" : mcq_rank_name(r)) << ':';       // fall through
-                case Mode::name: os << "taxname"; break;
-                case Mode::rank_id: os << (one ? "rank" : mcq_rank_name(r)) << ':';         // fall through
-                case Mode::id: os << "taxid"; break;
-                case Mode::rank_name_id: os << (one ? "rank" : mcq_rank_name(r)) << ':';    // fall through
-                case Mode::name_id: os << "taxname(taxid)"; break;
-            }
-            if (r < rmax) os << ',';
-        }
-    }
-};
+// mcq_query_cli -- `metacache query <db> r1.fq r2.fq -pairfiles ...` on one GPU: see mcq_cli_common.hpp for what is
+// written and which reference code each part stands in for.
+#include "mcq_cli_common.hpp"
 
 int main(int argc, char** argv) {
-    if (argc < 5) { std::fprintf(stderr, "usage: %s <dbprefix> <n_ranks> <r1> <r2|-> [options]\n", argv[0]); return 2; }
-    const std::string prefix = argv[1];
-    const uint32_t P = (uint32_t)std::atoi(argv[2]);
-    const std::string f1 = argv[3], f2 = argv[4];
-    uint32_t lowest = MCQ_RANK_SEQUENCE, highest = MCQ_RANK_DOMAIN, maxcand = 2, hitmin = 0, threads = 1;
-    float hitdiff = 1.0f; uint64_t insertsize = 0; bool quirks = true; std::string outfile;
-    bool show_ranks = true, taxids = false, taxids_only = false, lineage = false, tophits = false, mapped_only = false, nomap = false;
-    for (int i = 5; i < argc; ++i) {
-        std::string a = argv[i];
-        auto next = [&]() -> const char* { return (i + 1 < argc) ? argv[++i] : ""; };
-        if (a == "-lowest") { uint32_t r = mcq_rank_from_name(next()); if (r < MCQ_RANK_ROOT) lowest = r; }
-        else if (a == "-highest") { uint32_t r = mcq_rank_from_name(next()); if (r <= MCQ_RANK_ROOT) highest = r; }
-        else if (a == "-maxcand" || a == "-max-cand") maxcand = (uint32_t)std::atoi(next());
-        else if (a == "-hitmin") hitmin = (uint32_t)std::atoi(next());
-        else if (a == "-hitdiff") { hitdiff = (float)std::atof(next()); if (hitdiff > 1) hitdiff *= 0.01; }   // src/query_options.cpp:167-169
-        else if (a == "-insertsize") insertsize = std::strtoull(next(), nullptr, 10);
-        else if (a == "-threads") threads = (uint32_t)std::atoi(next());
-        else if (a == "-tophits" || a == "-top-hits") tophits = true;
-        else if (a == "-taxids" || a == "-taxid") taxids = true;
-        else if (a == "-taxids-only" || a == "-taxidsonly" || a == "-taxid-only") taxids_only = true;
-        else if (a == "-omit-ranks" || a == "-omitranks") show_ranks = false;
-        else if (a == "-lineage") lineage = true;
-        else if (a == "-mapped-only" || a == "-mappedonly") mapped_only = true;
-        else if (a == "-nomap" || a == "-no-map") nomap = true;
-        else if (a == "-noquirks") quirks = false;
-        else if (a == "-out") outfile = next();
-    }
-    if (lowest > highest) lowest = highest;
-    if (nomap && tophits) { nomap = false; mapped_only = true; }           // "showing hits changes the mapping mode", src/query_options.cpp:289-292
-
-    mcq_refdb* rdb = nullptr;
-    if (mcq_refdb_open(prefix.c_str(), P, &rdb)) { std::fprintf(stderr, "ABORT: %s\n", mcq_host_last_error()); return 1; }
-    mcq_refdb_info info; mcq_refdb_get_info(rdb, &info);
-    if (hitmin < 1) hitmin = mcq_default_hits_min(info.sketch_size);
-    std::vector<uint32_t> t2t(info.n_targets);
-    if (mcq_refdb_tgt2tax(rdb, lowest, t2t.data())) { std::fprintf(stderr, "ABORT: %s\n", mcq_host_last_error()); return 1; }
-
-    mcq_db_desc d; std::memset(&d, 0, sizeof(d));
-    d.k = info.k; d.sketch_size = info.q_sketch_size; d.winlen = info.q_winlen; d.winstride = info.q_winstride;
-    d.tgt_winstride = info.winstride; d.n_targets = info.n_targets; d.n_keys = info.n_keys; d.n_locs = info.n_locs;
-    d.keys = mcq_refdb_keys(rdb); d.list_off = mcq_refdb_list_off(rdb); d.locs = mcq_refdb_locs(rdb); d.tgt2tax = t2t.data();
-    d.n_shards = 1; d.shard_id = 0; d.flags = 0; d.device = 0;
-    static const uint64_t zero_off[1] = {0};
-    if (!d.list_off) d.list_off = zero_off;
+    Options p;
+    if (!parse_options(argc, argv, p)) return 2;
+    mcq_refdb* rdb = nullptr; std::vector<uint32_t> t2t; mcq_db_desc d; uint32_t hitmin = 0;
+    if (!open_database(p, &rdb, t2t, d, hitmin, 1, 0, 0)) return 1;
     mcq_db* edb = nullptr;
     if (mcq_db_create(&d, &edb)) { std::fprintf(stderr, "ABORT: %s\n", mcq_last_error()); return 1; }
 
     const auto t_start = std::chrono::steady_clock::now();                  // the reference times map_queries_to_targets, readers included (src/mode_query.cpp:130-132)
     std::vector<Rec> r1, r2;
-    if (!read_records(f1, r1)) { std::fprintf(stderr, "FAIL: can't open file %s\n", f1.c_str()); return 1; }
-    const bool paired = f2 != "-";
-    if (paired && !read_records(f2, r2)) { std::fprintf(stderr, "FAIL: can't open file %s\n", f2.c_str()); return 1; }
+    if (!read_records(p.f1, r1)) { std::fprintf(stderr, "FAIL: can't open file %s\n", p.f1.c_str()); return 1; }
+    const bool paired = p.paired();
+    if (paired && !read_records(p.f2, r2)) { std::fprintf(stderr, "FAIL: can't open file %s\n", p.f2.c_str()); return 1; }
     const size_t nq = paired ? std::min(r1.size(), r2.size()) : r1.size();
 
     std::string bases; std::vector<uint64_t> off{0};
@@ -178,93 +24,21 @@ int main(int argc, char** argv) {
     }
     mcq_ws* ws = nullptr;
     if (mcq_ws_create(edb, nq, bases.size() + 1, 0, &ws)) { std::fprintf(stderr, "ABORT: %s\n", mcq_last_error()); return 1; }
-    mcq_batch in; std::memset(&in, 0, sizeof(in)); in.n_seqs = off.size() - 1; in.bases = bases.data(); in.seq_off = off.data(); in.paired = paired ? 1 : 0; in.flags = 0;
-    mcq_query_opts qo; qo.max_cand = maxcand; qo.emulate_ranks = P; qo.insert_size_max = insertsize;
-    qo.flags = quirks ? MCQ_QUIRK_SEQ_DROP : 0;
-    std::vector<mcq_cand> cands(std::max<size_t>(1, nq) * maxcand);
+    mcq_batch in; std::memset(&in, 0, sizeof(in)); in.n_seqs = off.size() - 1; in.bases = bases.data(); in.seq_off = off.data(); in.paired = paired ? 1 : 0;
+    mcq_query_opts qo; qo.max_cand = p.maxcand; qo.emulate_ranks = p.P; qo.insert_size_max = p.insertsize;
+    qo.flags = p.quirks ? MCQ_QUIRK_SEQ_DROP : 0;
+    std::vector<mcq_cand> cands(std::max<size_t>(1, nq) * p.maxcand);
     std::vector<uint32_t> ncand(std::max<size_t>(1, nq));
     mcq_result res; res.cands = cands.data(); res.n_cand = ncand.data(); res.flags = 0;
     if (mcq_query(edb, ws, &in, &qo, &res, nullptr)) { std::fprintf(stderr, "FAIL: %s\n", mcq_last_error()); return 1; }
 
-    std::ofstream fout; if (!outfile.empty()) fout.open(outfile);
-    std::ostream& os = outfile.empty() ? std::cout : fout;
-    Out o; o.db = rdb; o.lowest = lowest; o.highest = highest; o.lineage = lineage; o.tophits = tophits;
-    if (taxids_only) o.mode = show_ranks ? Mode::rank_id : Mode::id;         // src/query_options.cpp:262-274
-    else if (taxids) o.mode = show_ranks ? Mode::rank_name_id : Mode::name_id;
-    else o.mode = show_ranks ? Mode::rank_name : Mode::name;
-    const char* cm = o.comment;
-
-    // ---- show_query_parameters (src/printing.cpp:40-113)
-    if (!nomap) {
-        os << cm << "Reporting per-read mappings (non-mapping lines start with '" << cm << "').\n";
-        if (lineage) os << cm << "The complete lineage will be reported starting with the lowest match.\n";
-        else os << cm << "Only the lowest matching rank will be reported.\n";
-    } else os << cm << "Per-Read mappings will not be shown.\n";
-    os << cm << "Classification will be constrained to ranks from '" << mcq_rank_name(lowest) << "' to '" << mcq_rank_name(highest) << "'.\n";
-    os << cm << "Classification hit threshold is " << hitmin << " per query\n";
-    os << cm << "At maximum " << maxcand << " classification candidates will be considered per query.\n";
-    if (paired) os << cm << "File based paired-end mode:\n" << cm << "  Reads from two consecutive files will be interleaved.\n"
-                   << cm << "  Max insert size considered " << insertsize << ".\n";
-    os << cm << "Using " << threads << " threads\n";
-    // ---- show_query_mapping_header (src/classification.cpp:486-512)
-    if (!nomap) {
-        os << cm << "TABLE_LAYOUT: query_header" << o.col;
-        if (tophits) os << "top_hits" << o.col;
-        o.header_taxon(os);
-        os << '\n';
-    }
-    os << cm << (paired ? f1 + " + " + f2 : f1) << '\n';                    // src/querying.h:1337
-
-    // ---- mapping lines + statistics (classification_statistics::assign, src/classification_statistics.h:69-78)
+    std::ofstream fout; if (!p.outfile.empty()) fout.open(p.outfile);
+    std::ostream& os = p.outfile.empty() ? std::cout : fout;
+    const Out o = make_out(rdb, p);
+    write_head(os, o, p, hitmin);
     uint64_t assigned[MCQ_RANK_NONE + 1] = {0};
-    for (size_t q = 0; q < nq; ++q) {
-        const uint32_t best = mcq_refdb_classify(rdb, reinterpret_cast<const uint32_t*>(&cands[q * maxcand]), ncand[q], hitmin, hitdiff, highest);
-        if (best == MCQ_NO_TAXON) ++assigned[MCQ_RANK_NONE];
-        else for (uint32_t r = mcq_refdb_taxon_rank(rdb, best); r <= MCQ_RANK_ROOT; ++r) ++assigned[r];
-        if (nomap || (mapped_only && best == MCQ_NO_TAXON)) continue;
-        const std::string& h = r1[q].header;
-        os << h.substr(0, h.find(' ')) << o.col;
-        if (tophits) {                                                       // show_matches, src/printing.cpp:333-360
-            for (uint32_t i = 0; i < ncand[q] && cands[q * maxcand + i].hits > 0; ++i) {
-                const mcq_cand& c = cands[q * maxcand + i];
-                if (i) os << ',';
-                const uint32_t key = c.tax;
-                if (lowest == MCQ_RANK_SEQUENCE) os << mcq_refdb_taxon_name(rdb, key);
-                else {
-                    const uint32_t a = mcq_refdb_taxon_rank(rdb, key) < lowest ? mcq_refdb_ancestor(rdb, key, lowest) : key;
-                    if (a != MCQ_NO_TAXON) os << mcq_refdb_taxon_id(rdb, a); else os << mcq_refdb_taxon_name(rdb, key);
-                }
-                os << ':' << c.hits;
-            }
-            os << o.col;
-        }
-        o.best(os, best);
-        os << '\n';
-    }
-
-    // ---- show_summary (src/printing.cpp:622-641) + show_taxon_statistics (:522-555)
-    const uint64_t total = assigned[MCQ_RANK_ROOT] + assigned[MCQ_RANK_NONE];
-    const uint64_t num_queries = paired ? 2 * total : total;                 // paired reads count twice (:626-627)
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-    os << cm << "queries: " << num_queries << '\n'
-       << cm << "time:    " << (long long)ms << " ms\n"
-       << cm << "speed:   " << num_queries / (ms / 60000.0) << " queries/min\n";
-    if (total > 0) {
-        if (assigned[MCQ_RANK_ROOT] < 1) os << "None of the input sequences could be classified.\n";
-        else {
-            if (assigned[MCQ_RANK_NONE] > 0)
-                os << cm << "unclassified: " << (100 * (assigned[MCQ_RANK_NONE] / double(total))) << "% (" << assigned[MCQ_RANK_NONE] << ")\n";
-            os << cm << "classified:\n";
-            static const uint32_t ranks[] = {0 /*sequence*/, 3 /*subspecies*/, 4 /*species*/, 6 /*genus*/, 10 /*family*/, 12 /*order*/,
-                                             14 /*class*/, 16 /*phylum*/, 18 /*kingdom*/, 19 /*domain*/, 20 /*root*/};
-            for (uint32_t r : ranks) {
-                if (assigned[r] == 0) continue;
-                std::string rn = mcq_rank_name(r);
-                rn.resize(11, ' ');
-                os << cm << "  " << rn << (100 * (assigned[r] / double(total))) << "% (" << assigned[r] << ")\n";
-            }
-        }
-    } else std::cerr << cm << "No valid query sequences found.\n";
+    for (size_t q = 0; q < nq; ++q) write_query(os, o, p, hitmin, r1[q].header, &cands[q * p.maxcand], ncand[q], assigned);
+    write_summary(os, o, p, assigned, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
     mcq_ws_destroy(ws); mcq_db_destroy(edb); mcq_refdb_close(rdb);
     return 0;
 }

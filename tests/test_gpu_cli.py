@@ -72,3 +72,41 @@ def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, tmp_p
         ref = f.read()
     mine = open(cwd / "out.txt").read()
     assert norm(mine) == norm(ref)
+
+
+@pytest.mark.parametrize("n_ranks,transport", [(1, "rccl"), (2, "mpi"), (3, "mpi")])
+def test_mpi_program_writes_the_references_out_file(n_ranks, transport, tmp_path):
+    """mcq_query_mpi -- the multi-GPU host in C++ under mpiexec, one hash-range shard of the table per rank, the sharded
+    path behind the C ABI -- writes the file the reference wrote under mpiexec -n 4 (emulate_ranks = 4, whatever the
+    number of GPU ranks).  2 and 3 ranks share the one GPU of the test box, their blocks travel through MPI_Alltoallv
+    (-transport mpi); 1 rank takes the RCCL path with a communicator of one (MCQ_SHARD_FORCE_RCCL)."""
+    import gzip
+    import re
+    import shutil
+    pkg = importlib.import_module("metacache-mpi_amd")
+    pkg.build_host()
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(pkg.mpi_cli_path()) or not os.path.exists(mpiexec):
+        pytest.skip("no MPI on this box")
+    fx = Fixture("mini", 4)
+    for fn, seqs in (("r1.fq", fx.r1), ("r2.fq", fx.r2)):
+        with open(tmp_path / fn, "w") as f:
+            for n, s in zip(fx.names, seqs):
+                f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
+    prefix = fx.shard_paths[0][: -len(".db_0")]
+    env = dict(os.environ, LD_LIBRARY_PATH=pkg.mpi_lib_dir() + ":" + os.environ.get("LD_LIBRARY_PATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if n_ranks == 1:
+        env["MCQ_SHARD_FORCE_RCCL"] = "1"
+    r = subprocess.run([mpiexec, "-n", str(n_ranks), pkg.mpi_cli_path(), prefix, "4", "r1.fq", "r2.fq", "-lowest", fx.q["lowest"],
+                        "-maxcand", str(fx.maxcand), "-hitmin", str(fx.hitmin), "-hitdiff", str(fx.q["hitdiff"]), "-threads", "2",
+                        "-tophits", "-transport", transport, "-out", "out.txt"],
+                       cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+
+    def norm(text):
+        text = re.sub(r"^# time:    .*$", "# time:    T ms", text, flags=re.M)
+        text = re.sub(r"^# speed:   .*$", "# speed:   S queries/min", text, flags=re.M)
+        return sorted(text.split("\n"))
+    with gzip.open(os.path.join(os.path.dirname(fx.shard_paths[0]), "cli_tophits.out.gz"), "rt") as f:
+        ref = f.read()
+    assert norm(open(tmp_path / "out.txt").read()) == norm(ref)
