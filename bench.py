@@ -202,17 +202,6 @@ def main():
     max_bases = max(int(o[-1].item()) for o in offsets)
     nq = B // 2 if paired else B
     sharded = None
-    if with_sharded:
-        sharded = eng.Shard(db_shard, world, rank, max_queries=nq, max_bases=max_bases, max_seqs=B)
-        if world > 1:
-            if a.backend == "nccl":
-                box = [eng.Shard.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                sharded.comm_rccl(box[0])
-            else:       # rehearsal on a box with one GPU: blocks through the host and gloo
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                from shard_exchange_gloo import make_gloo_exchange
-                sharded.set_exchange(make_gloo_exchange())
     ws = eng.Workspace(db, nq, max_bases) if with_fused else None
     cands = torch.zeros((nq, a.max_cand, 4), dtype=torch.int32, device=dev)
     ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
@@ -279,9 +268,43 @@ def main():
         kms, kn = ws.kernel_times()
         ws.timing(False)
 
+    def setup_sharded():
+        """creates the context and connects it; a failure on ANY rank skips the leg on every rank (returns the error text)"""
+        nonlocal sharded
+        err = None
+        try:
+            sharded = eng.Shard(db_shard, world, rank, max_queries=nq, max_bases=max_bases, max_seqs=B)
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, str(e)[:300])
+        if world > 1:               # nobody enters ncclCommInitRank unless everybody can
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                sharded = None
+                return err or "another rank failed to create its shard context"
+            try:
+                if a.backend == "nccl":
+                    box = [eng.Shard.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    sharded.comm_rccl(box[0])
+                else:       # rehearsal on a box with one GPU: blocks through the host and gloo
+                    sys.path.insert(0, os.path.join(ROOT, "tests"))
+                    from shard_exchange_gloo import make_gloo_exchange
+                    sharded.set_exchange(make_gloo_exchange())
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                sharded = None
+                return err or "another rank failed to connect its shard context"
+        elif err:
+            sharded = None
+        return err
+
     # ---- leg 2: sharded table + all-to-all exchange
     sharded_elapsed, sharded_error, sh_stats, sh_kms, sh_kn, sharded_ok = None, None, None, None, 0, None
-    if sharded is not None:
+    if with_sharded:
         # The exchange runs on real xGMI only in the driver's multi-GPU runs.  Should a rank fail inside it and leave the
         # others waiting in a collective, the watchdog prints the line of the leg already measured and ends every rank
         # with a non-zero status.
@@ -296,7 +319,10 @@ def main():
         dog = threading.Timer(a.sharded_timeout, give_up)
         dog.daemon = True
         dog.start()
+        sharded_error = setup_sharded()
         try:
+            if sharded is None:
+                raise RuntimeError(sharded_error or "no shard context")
             # the first batch of a context runs in the exact mode and learns the block sizes of the padded mode (host
             # round trips); it is an extra untimed step in front of the warmup
             step_sharded(0)
@@ -320,7 +346,7 @@ def main():
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 sharded_ok = bool(flag.item())
         except Exception as e:          # keep the line; the replicas leg stands
-            sharded_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+            sharded_error = sharded_error or "%s: %s" % (type(e).__name__, str(e)[:300])
         dog.cancel()
 
     def roofline(kind, ms3, n_batches, stats, elapsed):
