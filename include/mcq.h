@@ -304,7 +304,8 @@ int mcq_shard_set_exchange(mcq_shard* ctx, mcq_exchange_fn fn, void* user);
 int mcq_shard_query(mcq_shard* ctx, const mcq_batch* in, const mcq_query_opts* opt, mcq_result* out, void* stream,
                     uint32_t flags, const mcq_batch* next);
 /* as mcq_ws_sync; MCQ_E_CAPACITY also when a block of the exchange was too small since the last sync (repeat those
- * batches with MCQ_SHARD_EXACT)                                                                                      */
+ * batches with MCQ_SHARD_EXACT), or when a batch had more windows than cfg.max_bases was given for (no repeat helps:
+ * create the context for larger batches).  The flags of a `next` batch's S1 are reported with THAT batch.            */
 int mcq_shard_sync(mcq_shard* ctx, void* stream, mcq_stats* stats);
 /* block sizes of the padded mode (features / locations per peer); setting them skips the learning batch */
 int mcq_shard_set_caps(mcq_shard* ctx, uint64_t features_per_peer, uint64_t locations_per_peer);

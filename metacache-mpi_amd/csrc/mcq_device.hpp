@@ -120,9 +120,11 @@ struct ShardDev {
     u32 ends_stride;         // u32 words between two owners' list ends
     u32 tile_stride;         // u32 words between two owners' tile starts
     u64 capL;                // locations per peer block
+    u64 n_slots;             // entries of slot_pos (a batch with more windows than the context was sized for reads nothing beyond)
 };
 __device__ __forceinline__ void shard_fetch(const ShardDev& sh, u64 slot, u64& off, u32& len) {
     off = 0; len = 0;
+    if (slot >= sh.n_slots) return;          // (flagged by k_shard_sketch)
     const u32 sp = sh.slot_pos[slot];
     if (sp == MCQ_EMPTY) return;
     const u32 o = sp >> MCQ_SHARD_POS_BITS, pos = sp & ((1u << MCQ_SHARD_POS_BITS) - 1);

@@ -35,7 +35,7 @@
 // the owner's lookup skips such positions without a memory access.  chunk = the wave's expected share of an owner's
 // block / 8, so the filler stays below an eighth of the block and the atomics on one cursor at ~8 per wave.
 __global__ __launch_bounds__(256) void k_shard_sketch(DbDev db, BatchDev b, const u64* win_off, u32 n_ranks, u32 chunk,
-                                                      u32* sendF, u32 capF, u32* slot_pos, unsigned long long* feat_cnt, u32* err) {
+                                                      u32* sendF, u32 capF, u32* slot_pos, u64 n_slots, unsigned long long* feat_cnt, u32* err) {
     __shared__ u32 s_sk[4][128];
     __shared__ u32 s_res[4][2 * MCQ_SHARD_MAX_RANKS];
     const u32 lane = threadIdx.x & 63;
@@ -59,7 +59,12 @@ __global__ __launch_bounds__(256) void k_shard_sketch(DbDev db, BatchDev b, cons
             st_feat += m;
             const bool mine = lane < db.s;
             const u32 f = (mine && lane < m) ? sk[64 + lane] : MCQ_EMPTY;
-            const u32 slot = (u32)((w0 + j) * db.s) + lane;
+            const u64 slot0 = (w0 + j) * db.s;
+            if (slot0 + db.s > n_slots) {                    // more windows than the context was created for (max_bases)
+                if (lane == 0) atomicOr(err, 16u);
+                continue;
+            }
+            const u32 slot = (u32)slot0 + lane;
             const bool valid = f != MCQ_EMPTY;
             if (mine && !valid) slot_pos[slot] = MCQ_EMPTY;
             const u32 own = valid ? (u32)(((u64)tmh(f) * n_ranks) >> 32) : MCQ_EMPTY;
@@ -96,6 +101,9 @@ __global__ __launch_bounds__(256) void k_shard_sketch(DbDev db, BatchDev b, cons
     if (lane == 0 && st_feat) atomicAdd(feat_cnt, st_feat);
 }
 __global__ void k_shard_add_count(unsigned long long* dst, const unsigned long long* src) { atomicAdd(dst, *src); }
+// S1 flags its errors in a word of its buffer set (it may run on the side stream while an earlier batch's flags are read and
+// cleared); the query that consumes the set folds them into the word mcq_shard_sync reports
+__global__ void k_shard_fold_err(u32* err, const u32* s1_err) { if (*s1_err) atomicOr(err, *s1_err); }
 
 // ------------------------------------------------------------------ S2: owner side, lookup + gather
 // grid = n_ranks x tiles per block; workgroup (p, t) serves features [t*1024, +1024) of the block that came from rank p:
@@ -256,7 +264,7 @@ struct mcq_shard {
     u32 locb;
     ShardBuf sb[2]; int cur;              // double-buffered home side: the next batch's S1 runs under this batch's exchange
     u32* recvF; u32* sendR; u32* recvR; void* sendL; void* recvL;
-    u32* err; u32* err_host;              // device flag word, pinned copy
+    u32* err; u32* err_host;              // device flag words ([0] reported by sync, [1 + k] = S1 of buffer set k), pinned copy of [0]
     u32* cnt_dev; u32* cnt_host;          // staging of the exact mode's count exchanges (2 x n u64 on the device, n u32 / u64 pinned)
     hipStream_t side; hipEvent_t ev_prep[2], ev_done[2];
     bool prepared[2]; const void* prep_key[2][3];
@@ -364,7 +372,7 @@ extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, m
     SCHK(hipMalloc(&c->recvR, n * rblk_words(c) * 4));
     SCHK(hipMalloc(&c->sendL, n * capL * c->locb));
     SCHK(hipMalloc(&c->recvL, n * capL * c->locb));
-    SCHK(hipMalloc(&c->err, 4)); SCHK(hipMemset(c->err, 0, 4));
+    SCHK(hipMalloc(&c->err, 16)); SCHK(hipMemset(c->err, 0, 16));
     SCHK(hipHostMalloc(&c->err_host, 4));
     SCHK(hipMalloc(&c->cnt_dev, 4 * n * 8)); SCHK(hipHostMalloc(&c->cnt_host, 4 * n * 8));
     SCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
@@ -414,6 +422,7 @@ static int shard_prepare(mcq_shard* c, int k, const mcq_batch* in, hipStream_t s
     int rc = mcq_count_windows(c->db, in, b.win_off, st); if (rc) return rc;
     hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendF, fblk_words(c), c->n);
     HIPCHK(hipMemsetAsync(b.feat_cnt, 0, 8, st));
+    HIPCHK(hipMemsetAsync(c->err + 1 + k, 0, 4, st));
     BatchDev bd; rc = batch_dev(in, in->bases, in->seq_off, bd); if (rc) return rc;
     if (in->n_seqs) {
         const u32 grid = (u32)std::min<u64>((in->n_seqs + 3) / 4, 256ull * 8);
@@ -421,7 +430,7 @@ static int shard_prepare(mcq_shard* c, int k, const mcq_batch* in, hipStream_t s
         const u64 slots_guess = (in->n_seqs * 2) * c->db->d.s;       // ~2 windows per sequence; only a granularity, any value is correct
         const u32 chunk = (u32)std::min<u64>(4096, std::max<u64>(32, slots_guess / ((u64)c->n * grid * 4 * 8)));
         hipLaunchKernelGGL(k_shard_sketch, dim3(grid), dim3(256), 0, st, c->db->d, bd, (const u64*)b.win_off, c->n, chunk, b.sendF, c->capF,
-                           b.slot_pos, b.feat_cnt, c->err);
+                           b.slot_pos, c->max_slots, b.feat_cnt, c->err + 1 + k);
     }
     HIPCHK(hipGetLastError());
     return MCQ_OK;
@@ -463,6 +472,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     if (!was_prepared) { rc = shard_prepare(c, k, in, st); if (rc) return rc; }
     c->prepared[k] = false;
     ShardBuf& b = c->sb[k];
+    hipLaunchKernelGGL(k_shard_fold_err, dim3(1), dim3(1), 0, st, c->err, (const u32*)(c->err + 1 + k));
     HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
 
     // a rank's own blocks never travel: with one rank the owner side reads the home side's send buffers in place
@@ -543,7 +553,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     // ---- S3: home side, the fused kernels fed from the exchange
     ShardDev sh;
     sh.slot_pos = b.slot_pos; sh.ends = recvR + MCQ_SHARD_HDR + c->capT; sh.tile_base = recvR + MCQ_SHARD_HDR;
-    sh.win_off = b.win_off; sh.ends_stride = (u32)rblk_words(c); sh.tile_stride = (u32)rblk_words(c); sh.capL = c->capL;
+    sh.win_off = b.win_off; sh.ends_stride = (u32)rblk_words(c); sh.tile_stride = (u32)rblk_words(c); sh.capL = c->capL; sh.n_slots = c->max_slots;
     DbDev dbd = c->db->d; dbd.locs = recvL;
     BatchDev bd; rc = batch_dev(in, in->bases, in->seq_off, bd); if (rc) return rc;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
@@ -567,7 +577,7 @@ extern "C" int mcq_shard_sync(mcq_shard* c, void* stream, mcq_stats* stats) {
     const u32 e = *c->err_host;
     if (e) return fail(MCQ_E_CAPACITY, std::string("a block of the exchange was too small (") + ((e & 1) ? "features to an owner; " : "") +
                        ((e & 2) ? "features in the padded mode; " : "") + ((e & 4) ? "locations for a requester; " : "") +
-                       ((e & 8) ? "locations in the padded mode; " : "") + "): results of the batches since the last sync are incomplete -- "
+                       ((e & 8) ? "locations in the padded mode; " : "") + ((e & 16) ? "more windows than max_bases allows; " : "") + "): results of the batches since the last sync are incomplete -- "
                        "repeat them with MCQ_SHARD_EXACT or larger capacities");
     return rc;
 }

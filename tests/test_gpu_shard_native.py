@@ -108,6 +108,30 @@ def test_capacity_errors_are_reported(world1):
     oc, on = odb.query(r.cpu().numpy().tobytes(), ro.cpu().numpy().astype(np.uint64), False, max_cand=2, emulate_ranks=2, threads=8)
     _same(cands, ncand, oc, on, "exact mode after a capacity error")
     sh.close()
+    # a batch with more windows than max_bases was given for: reported, nothing written or read out of bounds
+    nl, Ll = 300, 6000
+    rl, rol, _ = synth.sample_reads(gb, goff, nl, Ll, 0.01, 0.002, seed=78)
+    cl = torch.zeros((nl, 2, 4), dtype=torch.int32, device=dev); ncl = torch.zeros(nl, dtype=torch.int32, device=dev)
+    sh2 = eng.Shard(db, 1, 0, max_queries=nl, max_bases=nl * Ll // 10, max_seqs=nl)
+    sh2.query(rl.data_ptr(), rol.data_ptr(), nl, False, cl.data_ptr(), ncl.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+    with pytest.raises(eng.McqError) as e:
+        sh2.sync(st)
+    assert e.value.code == eng.MCQ_E_CAPACITY and "max_bases" in str(e.value)
+    sh2.close()
+    # the S1 of a `next` batch that overflows its feature blocks: the error belongs to THAT batch (its flags are not cleared
+    # by the sync of the batch it was prepared under)
+    sh = eng.Shard(db, 1, 0, max_queries=n, max_bases=n * L, max_features_per_peer=8192)
+    small = 200
+    c2 = torch.zeros((small, 2, 4), dtype=torch.int32, device=dev); n2 = torch.zeros(small, dtype=torch.int32, device=dev)
+    sh.query(r.data_ptr(), ro.data_ptr(), small, False, c2.data_ptr(), n2.data_ptr(), max_cand=2, emulate_ranks=2, stream=st,
+             next_batch=(r.data_ptr(), ro.data_ptr(), n))
+    sh.sync(st)                                      # the small batch fits
+    _same(c2, n2, oc[:small], on[:small], "small batch before an overflowing prepared one")
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+    with pytest.raises(eng.McqError) as e:
+        sh.sync(st)
+    assert e.value.code == eng.MCQ_E_CAPACITY
+    sh.close()
 
 
 @pytest.mark.parametrize("paired,world,locs64", [(0, 2, 0), (1, 2, 1), (0, 4, 0)])
