@@ -300,7 +300,10 @@ int mcq_shard_set_exchange(mcq_shard* ctx, mcq_exchange_fn fn, void* user);
  * batch (largest count any rank saw, plus a quarter), its count inside it: the call only enqueues work, no host
  * round trip.  The first batch of a context, and any batch with MCQ_SHARD_EXACT, exchanges exact sizes after two
  * count exchanges through the host.  `next` (may be NULL): the batch of the following call, resident in device
- * memory -- its sketching is enqueued on a second stream now and runs under this batch's exchange.                   */
+ * memory and unchanged until that call -- its sketching is enqueued on a second stream now.  The exchanges and the
+ * owner-side lookups run on a third stream of the context, the reduce kernels on `stream` behind them: a caller that
+ * keeps calling without waiting has the next batch's exchanges and lookups under this batch's reduce kernels.
+ * `out` and the statistics are complete when `stream` is (mcq_shard_sync).                                           */
 int mcq_shard_query(mcq_shard* ctx, const mcq_batch* in, const mcq_query_opts* opt, mcq_result* out, void* stream,
                     uint32_t flags, const mcq_batch* next);
 /* as mcq_ws_sync; MCQ_E_CAPACITY also when a block of the exchange was too small since the last sync (repeat those

@@ -181,15 +181,15 @@ __global__ void k_max_win(const u64* locs, u64 n, u32* out) {
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-// exclusive scan of u64 array (single workgroup, used only at DB build)
+// exclusive scan of u64 array (single workgroup of 256 or 1024 threads)
 template <class InT>
 __global__ __launch_bounds__(1024) void k_scan_u64(const InT* in, u64* out, u64 n) {
     __shared__ u64 s_w[16];
     __shared__ u64 s_carry;
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (u64 base = 0; base < n; base += 1024) {
+    for (u64 base = 0; base < n; base += NT) {
         u64 i = base + tid;
         u64 v = (i < n) ? in[i] : 0, x = v;
         for (int d = 1; d < 64; d <<= 1) {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_scan_u64(const InT* in, u64* out, u64 
         u64 carry = s_carry;
         if (i < n) out[i] = carry + woff + x - v;
         __syncthreads();
-        if (tid == 1023) s_carry = carry + woff + x;
+        if (tid == NT - 1) s_carry = carry + woff + x;
         __syncthreads();
     }
     if (tid == 0) out[n] = s_carry;
@@ -216,11 +216,11 @@ template <class InT>
 __global__ __launch_bounds__(1024) void k_scan_tiles(const InT* in, u64* out, u64 n, u64* tile_sums) {
     __shared__ u64 s_w[16];
     __shared__ u64 s_carry;
-    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NT = blockDim.x;
     if (tid == 0) s_carry = 0;
     __syncthreads();
     const u64 t0 = (u64)blockIdx.x * MCQ_SCAN_TILE;
-    for (u64 base = t0; base < t0 + MCQ_SCAN_TILE; base += 1024) {
+    for (u64 base = t0; base < t0 + MCQ_SCAN_TILE; base += NT) {
         const u64 i = base + tid;
         u64 v = (i < n) ? in[i] : 0, x = v;
         for (int d = 1; d < 64; d <<= 1) { u64 t = __shfl_up(x, d, 64); if (lane >= (u32)d) x += t; }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const InT* in, u64* out, u6
         const u64 carry = s_carry;
         if (i < n) out[i] = carry + woff + x - v;
         __syncthreads();
-        if (tid == 1023) s_carry = carry + woff + x;
+        if (tid == NT - 1) s_carry = carry + woff + x;
         __syncthreads();
     }
     if (tid == 0) tile_sums[blockIdx.x] = s_carry;
@@ -1467,15 +1467,18 @@ __global__ __launch_bounds__(256) void k_fq_ranges(const char* text, u64 n, cons
 // ------------------------------------------------------------------ host helpers
 static u64 pow2ceil64(u64 x) { u64 p = 1; while (p < x) p <<= 1; return p; }
 
+// nt: threads per workgroup, 256 or 1024.  A 1024-thread workgroup needs 16 free wave slots on ONE CU at once: enqueued
+// beside a grid of smaller workgroups that fills the GPU (the sharded path's second stream) it waits until that grid has
+// drained; 256-thread workgroups slip in as the others retire.
 template <class InT>
-static int device_exclusive_scan(const InT* in, u64* out, u64 n, hipStream_t st) {
+static int device_exclusive_scan(const InT* in, u64* out, u64 n, hipStream_t st, u32 nt = 1024) {
     const u64 ntiles = (n + MCQ_SCAN_TILE - 1) / MCQ_SCAN_TILE;
-    if (ntiles <= 1) { hipLaunchKernelGGL(k_scan_u64<InT>, dim3(1), dim3(1024), 0, st, in, out, n); return MCQ_OK; }
+    if (ntiles <= 1) { hipLaunchKernelGGL(k_scan_u64<InT>, dim3(1), dim3(nt), 0, st, in, out, n); return MCQ_OK; }
     u64 *sums = nullptr, *offs = nullptr;
     HIPCHK(hipMallocAsync((void**)&sums, ntiles * 8, st));
     HIPCHK(hipMallocAsync((void**)&offs, (ntiles + 1) * 8, st));
-    hipLaunchKernelGGL(k_scan_tiles<InT>, dim3((u32)ntiles), dim3(1024), 0, st, in, out, n, sums);
-    hipLaunchKernelGGL(k_scan_u64<u64>, dim3(1), dim3(1024), 0, st, (const u64*)sums, offs, ntiles);
+    hipLaunchKernelGGL(k_scan_tiles<InT>, dim3((u32)ntiles), dim3(nt), 0, st, in, out, n, sums);
+    hipLaunchKernelGGL(k_scan_u64<u64>, dim3(1), dim3(nt), 0, st, (const u64*)sums, offs, ntiles);
     hipLaunchKernelGGL(k_scan_add, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, out, n, (const u64*)offs);
     HIPCHK(hipFreeAsync(sums, st));
     HIPCHK(hipFreeAsync(offs, st));
@@ -1842,6 +1845,8 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     if (shp) sh = *shp;
     const DbDev& D = dbd ? *dbd : db->d;
     const u64 want = (b.nq + 3) / 4;
+    // (sharded home side too: two to four times the resident workgroups, so that they retire all along beside the other
+    // streams' kernels, measured 1-7 % slower per batch than the resident grid)
     const u32 grid = grid_for(ws->cap_wave, want);
     LaunchTimer tm(ws, st);
     int rc = tm.begin(); if (rc) return rc;
@@ -2068,7 +2073,7 @@ extern "C" int mcq_count_windows(const mcq_db* db, const mcq_batch* in, uint64_t
     u64* cnt = nullptr;
     HIPCHK(hipMallocAsync((void**)&cnt, std::max<u64>(1, n) * 8, st));
     if (n) hipLaunchKernelGGL(k_count_windows, dim3((u32)((n + 255) / 256)), dim3(256), 0, st, in->seq_off, (in->flags & MCQ_BATCH_RANGES) ? 1u : 0u, n, db->d.winlen, db->d.winstride, cnt);
-    { int rcs = device_exclusive_scan<u64>((const u64*)cnt, win_off, n, st); if (rcs) return rcs; }
+    { int rcs = device_exclusive_scan<u64>((const u64*)cnt, win_off, n, st, 256); if (rcs) return rcs; }
     HIPCHK(hipFreeAsync(cnt, st));
     HIPCHK(hipGetLastError());
     return MCQ_OK;

@@ -110,7 +110,7 @@ __global__ void k_shard_fold_err(u32* err, const u32* s1_err) { if (*s1_err) ato
 // four probes in flight per thread, inclusive scan of the list lengths over the tile (feature order), one global
 // atomic per tile for its room in p's location block, then every wave copies the lists of its 64-feature groups.
 // R block of p: [0] = locations served to p so far (the cursor), [1] = features of p seen, then capT tile starts,
-// then capF list ends.
+// then capF list ends.  (One wave per 256-feature tile -- no barriers, no LDS -- measured 5 % slower per batch.)
 template <class KeyT>
 __global__ __launch_bounds__(256) void k_shard_lookup(DbDev db, u32 n_ranks, const u32* recvF, u32 capF, u32 capFx, u32 capT,
                                                       u32* sendR, KeyT* sendL, u64 capL, u32* err) {
@@ -249,11 +249,14 @@ static int rccl_load() {
     return fail(MCQ_E_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); } while (0)
 
 // ------------------------------------------------------------------ context
+#define MCQ_SHARD_SETS 3      // S1 of batch j+1 may start as soon as the S3 of batch j-2 is done, i.e. under S3 of j-1 and j
 struct ShardBuf {             // the device buffers of one batch in flight
     u32* sendF = nullptr;     // [n][HDR + capF]
     u32* slot_pos = nullptr;  // [max_slots]
     u64* win_off = nullptr;   // [max_seqs + 1]
     unsigned long long* feat_cnt = nullptr;   // features sketched (for the statistics)
+    u32* recvF = nullptr; u32* sendR = nullptr; u32* recvR = nullptr;       // [n][HDR + capF], [n][HDR + capT + capF] x 2
+    void* sendL = nullptr; void* recvL = nullptr;                           // [n][capL] locations
 };
 struct mcq_shard {
     const mcq_db* db; mcq_ws* ws;
@@ -262,12 +265,11 @@ struct mcq_shard {
     u32 capF, capT; u64 capL;             // block capacities (buffers)
     u32 capFx; u64 capLx;                 // what travels per peer in the padded mode (0 = not learned yet)
     u32 locb;
-    ShardBuf sb[2]; int cur;              // double-buffered home side: the next batch's S1 runs under this batch's exchange
-    u32* recvF; u32* sendR; u32* recvR; void* sendL; void* recvL;
+    ShardBuf sb[MCQ_SHARD_SETS]; int cur; // batches in flight, one buffer set each (round robin)
     u32* err; u32* err_host;              // device flag words ([0] reported by sync, [1 + k] = S1 of buffer set k), pinned copy of [0]
     u32* cnt_dev; u32* cnt_host;          // staging of the exact mode's count exchanges (2 x n u64 on the device, n u32 / u64 pinned)
-    hipStream_t side; hipEvent_t ev_prep[2], ev_done[2];
-    bool prepared[2]; const void* prep_key[2][3];
+    hipStream_t side, xs; hipEvent_t ev_prep[MCQ_SHARD_SETS], ev_done[MCQ_SHARD_SETS], ev_x[MCQ_SHARD_SETS], ev_in;
+    bool prepared[MCQ_SHARD_SETS]; const void* prep_key[MCQ_SHARD_SETS][3];
     // transport
     ncclComm_t comm; bool have_comm;
     mcq_exchange_fn xfn; void* xuser;
@@ -319,12 +321,17 @@ extern "C" int mcq_shard_destroy(mcq_shard* c) {
     if (!c) return MCQ_OK;
     (void)hipSetDevice(c->device);
     if (c->have_comm) (void)g_rccl.CommDestroy(c->comm);
-    for (auto& b : c->sb) { (void)hipFree(b.sendF); (void)hipFree(b.slot_pos); (void)hipFree(b.win_off); (void)hipFree(b.feat_cnt); }
-    (void)hipFree(c->recvF); (void)hipFree(c->sendR); (void)hipFree(c->recvR); (void)hipFree(c->sendL); (void)hipFree(c->recvL);
+    for (auto& b : c->sb) {
+        (void)hipFree(b.sendF); (void)hipFree(b.slot_pos); (void)hipFree(b.win_off); (void)hipFree(b.feat_cnt);
+        (void)hipFree(b.recvF); (void)hipFree(b.sendR); (void)hipFree(b.recvR); (void)hipFree(b.sendL); (void)hipFree(b.recvL);
+    }
     (void)hipFree(c->err); (void)hipHostFree(c->err_host); (void)hipFree(c->cnt_dev); (void)hipHostFree(c->cnt_host);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->xs) (void)hipStreamDestroy(c->xs);
     for (auto e : c->ev_prep) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_done) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev_x) if (e) (void)hipEventDestroy(e);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     (void)mcq_ws_destroy(c->ws);
     delete c;
     return MCQ_OK;
@@ -366,16 +373,19 @@ extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, m
         SCHK(hipMalloc(&b.slot_pos, std::max<u64>(1, max_slots) * 4));
         SCHK(hipMalloc(&b.win_off, (max_seqs + 1) * 8));
         SCHK(hipMalloc(&b.feat_cnt, 8));
+        SCHK(hipMalloc(&b.recvF, n * fblk_words(c) * 4));
+        SCHK(hipMalloc(&b.sendR, n * rblk_words(c) * 4));
+        SCHK(hipMalloc(&b.recvR, n * rblk_words(c) * 4));
+        SCHK(hipMalloc(&b.sendL, n * capL * c->locb));
+        SCHK(hipMalloc(&b.recvL, n * capL * c->locb));
     }
-    SCHK(hipMalloc(&c->recvF, n * fblk_words(c) * 4));
-    SCHK(hipMalloc(&c->sendR, n * rblk_words(c) * 4));
-    SCHK(hipMalloc(&c->recvR, n * rblk_words(c) * 4));
-    SCHK(hipMalloc(&c->sendL, n * capL * c->locb));
-    SCHK(hipMalloc(&c->recvL, n * capL * c->locb));
-    SCHK(hipMalloc(&c->err, 16)); SCHK(hipMemset(c->err, 0, 16));
+    SCHK(hipMalloc(&c->err, 4 * (1 + MCQ_SHARD_SETS))); SCHK(hipMemset(c->err, 0, 4 * (1 + MCQ_SHARD_SETS)));
     SCHK(hipHostMalloc(&c->err_host, 4));
     SCHK(hipMalloc(&c->cnt_dev, 4 * n * 8)); SCHK(hipHostMalloc(&c->cnt_host, 4 * n * 8));
     SCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    SCHK(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+    for (auto& e : c->ev_x) SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    SCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     for (auto& e : c->ev_prep) SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_done) SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 #undef SCHK
@@ -449,38 +459,21 @@ static int shard_exchange_counts(mcq_shard* c, const u64* mine_host, u64* theirs
     return MCQ_OK;
 }
 
-extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_query_opts* opt, mcq_result* out, void* stream,
-                               uint32_t flags, const mcq_batch* next) {
-    if (!c || !in || !opt || !out) return fail(MCQ_E_ARG, "null argument");
-    if (!(in->flags & MCQ_DEVICE_PTRS) || !(out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the sharded path takes device pointers");
-    if (next && !(next->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the sharded path takes device pointers");
-    OptDev od;
-    int rc = make_opt(opt, od); if (rc) return rc;
-    const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
-    if (nq > c->max_queries || in->n_seqs > c->max_seqs) return fail(MCQ_E_ARG, "batch larger than the context allows");
-    const bool exact = (flags & MCQ_SHARD_EXACT) || c->capFx == 0;
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
+// X1 + S2 + X2 of the batch whose S1 sits in buffer set k, on stream st.  exact: blocks travel at their exact sizes (two
+// count exchanges through the host, and the padded mode's block sizes are learned from them); else at the fixed sizes
+// capFx / capLx with the counts inside, nothing on the host.
+static bool shard_alias(const mcq_shard* c) { return c->n == 1 && !c->xfn && !c->have_comm; }
+static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
     const u32 n = c->n;
-    mcq_ws* ws = c->ws;
-
-    // ---- S1 (unless the previous call already ran it for this batch on the side stream)
-    int k = c->cur;
-    const bool was_prepared = c->prepared[k] && c->prep_key[k][0] == in->bases && c->prep_key[k][1] == in->seq_off &&
-                              c->prep_key[k][2] == (const void*)(uintptr_t)in->n_seqs;
-    if (c->prepared[k]) HIPCHK(hipStreamWaitEvent(st, c->ev_prep[k], 0));      // (a prepared batch that is not this one drains, then is overwritten)
-    if (!was_prepared) { rc = shard_prepare(c, k, in, st); if (rc) return rc; }
-    c->prepared[k] = false;
     ShardBuf& b = c->sb[k];
-    hipLaunchKernelGGL(k_shard_fold_err, dim3(1), dim3(1), 0, st, c->err, (const u32*)(c->err + 1 + k));
-    HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
-
+    u32* const err = c->err + 1 + k;
     // a rank's own blocks never travel: with one rank the owner side reads the home side's send buffers in place
-    const bool alias = n == 1 && !c->xfn && !c->have_comm;
-    u32* const recvF = alias ? b.sendF : c->recvF;
-    u32* const recvR = alias ? c->sendR : c->recvR;
-    void* const recvL = alias ? c->sendL : c->recvL;
+    const bool alias = shard_alias(c);
+    u32* const recvF = alias ? b.sendF : b.recvF;
+    u32* const recvR = alias ? b.sendR : b.recvR;
+    void* const recvL = alias ? b.sendL : b.recvL;
     std::vector<u64> sbytes(n), rbytes(n), cnt_mine(n), cnt_theirs(n);
+    int rc;
     // ---- X1: feature blocks to their owners
     u32 capFx = c->capFx; u64 capLx = c->capLx;
     if (exact) {
@@ -497,26 +490,14 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     }
     if (!alias) { rc = shard_exchange(c, b.sendF, fblk_words(c) * 4, sbytes.data(), recvF, fblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
 
-    // ---- the next batch's S1 on the side stream, into the other buffer set: it runs under this batch's exchange, lookup and
-    // reduce.  That set was last read by the reduce kernels of the previous batch (ev_done); the caller guarantees that the
-    // next batch's inputs are resident.
-    if (next && next->n_seqs <= c->max_seqs) {
-        const int k2 = k ^ 1;
-        HIPCHK(hipStreamWaitEvent(c->side, c->ev_done[k2], 0));
-        rc = shard_prepare(c, k2, next, c->side); if (rc) return rc;
-        HIPCHK(hipEventRecord(c->ev_prep[k2], c->side));
-        c->prepared[k2] = true;
-        c->prep_key[k2][0] = next->bases; c->prep_key[k2][1] = next->seq_off; c->prep_key[k2][2] = (const void*)(uintptr_t)next->n_seqs;
-    }
-
     // ---- S2: owner side
-    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, c->sendR, rblk_words(c), n);
+    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendR, rblk_words(c), n);
     {
         const dim3 grid(n * c->capT);
         if (c->db->d.compact) hipLaunchKernelGGL(k_shard_lookup<u32>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
-                                                 c->sendR, (u32*)c->sendL, c->capL, c->err);
+                                                 b.sendR, (u32*)b.sendL, c->capL, err);
         else                  hipLaunchKernelGGL(k_shard_lookup<u64>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
-                                                 c->sendR, (u64*)c->sendL, c->capL, c->err);
+                                                 b.sendR, (u64*)b.sendL, c->capL, err);
     }
     HIPCHK(hipGetLastError());
 
@@ -524,17 +505,16 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     if (exact) {
         // ends of the features each peer sent (counts known from X1), locations served to each peer (cursor word of its R block)
         for (u32 p = 0; p < n; ++p) { sbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_theirs[p]) * 4; rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_mine[p]) * 4; }
-        if (!alias) { rc = shard_exchange(c, c->sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
-        HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, c->sendR, rblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
+        if (!alias) { rc = shard_exchange(c, b.sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
+        HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, b.sendR, rblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         u64 mx = 0;
         std::vector<u64> served(n), coming(n);
         for (u32 p = 0; p < n; ++p) { served[p] = std::min<u64>(c->cnt_host[p], c->capL); mx = std::max(mx, served[p]); }
         rc = shard_exchange_counts(c, served.data(), coming.data(), st); if (rc) return rc;
         for (u32 p = 0; p < n; ++p) { sbytes[p] = served[p] * c->locb; rbytes[p] = coming[p] * c->locb; mx = std::max(mx, coming[p]); }
-        if (!alias) { rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
+        if (!alias) { rc = shard_exchange(c, b.sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
         c->seen_locations = mx;
-        capLx = c->capL;
         // learn the padded mode's block sizes: the largest count any rank saw this batch, plus a quarter
         std::vector<u64> mine2(n, (c->seen_features << 32) | std::min<u64>(c->seen_locations, 0xFFFFFFFFull)), all2(n);
         rc = shard_exchange_counts(c, mine2.data(), all2.data(), st); if (rc) return rc;
@@ -544,17 +524,59 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
         c->capLx = std::max<u64>(c->capLx, std::min<u64>(c->capL, gl + gl / 4 + 65536));
     } else {
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + capFx) * 4;
-        if (!alias) { rc = shard_exchange(c, c->sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
+        if (!alias) { rc = shard_exchange(c, b.sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = capLx * c->locb;
-        if (!alias) { rc = shard_exchange(c, c->sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
-        hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(64), 0, st, (const u32*)recvR, rblk_words(c), n, capLx, c->err);
+        if (!alias) { rc = shard_exchange(c, b.sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
+        hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(64), 0, st, (const u32*)recvR, rblk_words(c), n, capLx, err);
     }
+    return MCQ_OK;
+}
+
+extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_query_opts* opt, mcq_result* out, void* stream,
+                               uint32_t flags, const mcq_batch* next) {
+    if (!c || !in || !opt || !out) return fail(MCQ_E_ARG, "null argument");
+    if (!(in->flags & MCQ_DEVICE_PTRS) || !(out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the sharded path takes device pointers");
+    if (next && !(next->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the sharded path takes device pointers");
+    OptDev od;
+    int rc = make_opt(opt, od); if (rc) return rc;
+    const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
+    if (nq > c->max_queries || in->n_seqs > c->max_seqs) return fail(MCQ_E_ARG, "batch larger than the context allows");
+    const bool exact = (flags & MCQ_SHARD_EXACT) || c->capFx == 0;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    mcq_ws* ws = c->ws;
+
+    // Three streams, two buffer sets.  Per call:  xs (the context's own): X1, S2, X2 of this batch;  the caller's stream:
+    // S3 of this batch once xs is through;  side: S1 of the next batch.  The call only enqueues (padded mode), so the
+    // caller's following call puts the next batch's exchanges and lookups on xs while this batch's S3 still runs: S3 and S1
+    // (VALU-bound) share the CUs with the lookups (latency-bound) and with the copy engines / xGMI links of the exchanges.
+    const int k = c->cur;
+    ShardBuf& b = c->sb[k];
+    HIPCHK(hipStreamWaitEvent(c->xs, c->ev_done[k], 0));  // this set's exchange buffers were last read by the S3 of MCQ_SHARD_SETS calls ago
+    // ---- S1, unless the previous call already ran it for this batch on the side stream (its `next`)
+    const bool was_prepared = c->prepared[k] && c->prep_key[k][0] == in->bases && c->prep_key[k][1] == in->seq_off &&
+                              c->prep_key[k][2] == (const void*)(uintptr_t)in->n_seqs;
+    if (c->prepared[k]) HIPCHK(hipStreamWaitEvent(c->xs, c->ev_prep[k], 0));   // (a prepared batch that is not this one drains, then is overwritten)
+    c->prepared[k] = false;
+    if (!was_prepared) {                                  // S1 here: behind whatever the caller has enqueued (its inputs)
+        HIPCHK(hipEventRecord(c->ev_in, st));
+        HIPCHK(hipStreamWaitEvent(c->xs, c->ev_in, 0));
+        rc = shard_prepare(c, k, in, c->xs); if (rc) return rc;
+    }
+    // ---- X1, S2, X2
+    rc = shard_owner_round(c, k, c->xs, exact); if (rc) return rc;
+    HIPCHK(hipEventRecord(c->ev_x[k], c->xs));
+    HIPCHK(hipStreamWaitEvent(st, c->ev_x[k], 0));
 
     // ---- S3: home side, the fused kernels fed from the exchange
+    HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
+    hipLaunchKernelGGL(k_shard_fold_err, dim3(1), dim3(1), 0, st, c->err, (const u32*)(c->err + 1 + k));
+    const bool alias = shard_alias(c);
+    u32* const recvR = alias ? b.sendR : b.recvR;
     ShardDev sh;
     sh.slot_pos = b.slot_pos; sh.ends = recvR + MCQ_SHARD_HDR + c->capT; sh.tile_base = recvR + MCQ_SHARD_HDR;
     sh.win_off = b.win_off; sh.ends_stride = (u32)rblk_words(c); sh.tile_stride = (u32)rblk_words(c); sh.capL = c->capL; sh.n_slots = c->max_slots;
-    DbDev dbd = c->db->d; dbd.locs = recvL;
+    DbDev dbd = c->db->d; dbd.locs = alias ? b.sendL : b.recvL;
     BatchDev bd; rc = batch_dev(in, in->bases, in->seq_off, bd); if (rc) return rc;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
@@ -562,7 +584,18 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     hipLaunchKernelGGL(k_shard_add_count, dim3(1), dim3(1), 0, st, &ws->ctr->n_features, (const unsigned long long*)b.feat_cnt);
     HIPCHK(hipEventRecord(c->ev_done[k], st));            // this buffer set may be overwritten
     c->last_nq = nq;
-    c->cur = k ^ 1;
+    const int k2 = (k + 1) % MCQ_SHARD_SETS;
+    c->cur = k2;
+
+    // ---- S1 of the next batch on the side stream, into the next buffer set (last read by an earlier S3: ev_done); the
+    // caller guarantees that the next batch's inputs are resident and stay unchanged until its call
+    if (next && next->n_seqs <= c->max_seqs) {
+        HIPCHK(hipStreamWaitEvent(c->side, c->ev_done[k2], 0));
+        rc = shard_prepare(c, k2, next, c->side); if (rc) return rc;
+        HIPCHK(hipEventRecord(c->ev_prep[k2], c->side));
+        c->prepared[k2] = true;
+        c->prep_key[k2][0] = next->bases; c->prep_key[k2][1] = next->seq_off; c->prep_key[k2][2] = (const void*)(uintptr_t)next->n_seqs;
+    }
     return MCQ_OK;
 }
 
