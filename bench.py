@@ -484,6 +484,18 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches, offsets, (a.warmup + a.steps - 1) % nb,
                                            gc, gn, B, paired, bounded=world > 1)
         parity_ok = out["cpu_baseline"]["gpu_matches_cpu_on_first_batch"] is not False
+        ref_file = os.path.join(ROOT, "profiles", "r02_reference_at_scale.json")
+        if os.path.exists(ref_file) and world == 1 and n_species == 50 and not a.small:
+            # recorded, not measured in this run: the reference's own binary on this table (scripts/reference_at_scale.py)
+            with open(ref_file) as f:
+                rj = json.load(f)
+            out["cpu_baseline"]["reference_itself_recorded"] = {
+                "value": rj.get("reference_reads_per_s"), "unit": "reads/s", "cores": rj["reference_ranks"] * rj["threads_per_rank"],
+                "sample": "%d pairs of 2x150 bp on this table, mpiexec -n %d x %d threads, its own summary line" %
+                          (rj["pairs"], rj["reference_ranks"], rj["threads_per_rank"]),
+                "same_mapping_lines_as_the_engine": bool(rj.get("identical_mapping_lines") or rj.get("identical_after_sorting")),
+                "source": "profiles/r02_reference_at_scale.json (scripts/reference_at_scale.py on the GPU box; the reference's MPI "
+                          "query segfaults on single-end files, so pairs)"}
     if rank == 0:
         emit(out)
     rc = 0

@@ -1,14 +1,17 @@
 """mcq_query_cli end to end on the GPU: reference shard files + FASTQ pair in, mapping
 lines out; must equal what the reference CLI printed for the same inputs."""
 import importlib
+import json
 import os
 import subprocess
+import sys
 
 import pytest
 
 from golden_util import Fixture
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("tag,P", [("mini", 4), ("tie", 2), ("tie", 4), ("noanc", 2)])
@@ -110,3 +113,20 @@ def test_mpi_program_writes_the_references_out_file(n_ranks, transport, tmp_path
     with gzip.open(os.path.join(os.path.dirname(fx.shard_paths[0]), "cli_tophits.out.gz"), "rt") as f:
         ref = f.read()
     assert norm(open(tmp_path / "out.txt").read()) == norm(ref)
+
+
+REF_CLI = os.path.join(ROOT, "oracle", "_ref", "metacache_mpi")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CLI), reason="oracle/_ref/metacache_mpi (the reference itself, built in the build container) not present")
+def test_reference_itself_and_engine_cli_on_a_gpu_built_table(tmp_path):
+    """scripts/reference_at_scale.py at a size of seconds: a table built on the GPU, written as the reference's shard files,
+    queried by the reference (mpiexec -n 2, 8 threads each) and by mcq_query_cli with 65 536 read pairs: the same mapping
+    lines (the full-size run is profiles/r02_reference_at_scale.json)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "reference_at_scale.py"), "--species", "6", "--strains", "4",
+                        "--genome-min", "300000", "--genome-max", "500000", "--reads", "131072", "--query-limit", "1024",
+                        "--workdir", str(tmp_path / "w")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    res = json.loads(r.stdout[r.stdout.index("{"):])
+    assert res["mapping_lines"] == [65536, 65536]
+    assert res["identical_mapping_lines"] or res["identical_after_sorting"]
