@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--ranks", type=int, default=2, help="reference ranks (mpiexec -n), a power of two")
     ap.add_argument("--threads", type=int, default=8, help="-threads per reference rank")
+    ap.add_argument("--maxcand", type=int, default=2)
     ap.add_argument("--workdir", default="/tmp/mcq_refscale")
     ap.add_argument("--keep", action="store_true")
     a = ap.parse_args()
@@ -63,7 +64,7 @@ def main():
     P = a.ranks
     shutil.rmtree(a.workdir, ignore_errors=True)
     os.makedirs(a.workdir)
-    res = {"table": "%d species x %d strains" % (a.species, a.strains), "reference_ranks": P, "threads_per_rank": a.threads}
+    res = {"table": "%d species x %d strains" % (a.species, a.strains), "reference_ranks": P, "threads_per_rank": a.threads, "maxcand": a.maxcand}
 
     # ---- the table of bench.py (same generator, same seed), built on the GPU
     gb, goff, species = synth.make_genomes(a.species, a.strains, a.genome_min, a.genome_max, a.divergence, seed=3, device=dev)
@@ -119,7 +120,7 @@ def main():
     res["shard_files_written_s"] = round(time.time() - t0, 1)
     del key_of, rank_of
 
-    opts = ["-lowest", "species", "-maxcand", "2", "-hitmin", "4", "-hitdiff", "80", "-tophits", "-taxids-only", "-omit-ranks"]
+    opts = ["-lowest", "species", "-maxcand", str(a.maxcand), "-hitmin", "4", "-hitdiff", "80", "-tophits", "-taxids-only", "-omit-ranks"]
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "oracle", "_ref", "mpilib"))
 
     # ---- 1. the reference
