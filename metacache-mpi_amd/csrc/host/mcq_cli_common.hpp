@@ -128,6 +128,7 @@ struct Options {
     float hitdiff = 1.0f; uint64_t insertsize = 0; bool quirks = true;
     bool show_ranks = true, taxids = false, taxids_only = false, lineage = false, tophits = false, mapped_only = false, nomap = false;
     std::string transport = "rccl";      // mcq_query_mpi: rccl | mpi (blocks through the host and MPI_Alltoallv)
+    uint64_t batch = 1u << 19, batch_bases = 256u << 20;   // mcq_query_mpi: queries / bases per rank and batch
     bool paired() const { return f2 != "-"; }
 };
 
@@ -153,6 +154,8 @@ static bool parse_options(int argc, char** argv, Options& o) {
         else if (a == "-nomap" || a == "-no-map") o.nomap = true;
         else if (a == "-noquirks") o.quirks = false;
         else if (a == "-transport") o.transport = next();
+        else if (a == "-batch") o.batch = std::max<uint64_t>(1, std::strtoull(next(), nullptr, 10));
+        else if (a == "-batch-bases") o.batch_bases = std::max<uint64_t>(1024, std::strtoull(next(), nullptr, 10));
         else if (a == "-out") o.outfile = next();
     }
     if (o.lowest > o.highest) o.lowest = o.highest;

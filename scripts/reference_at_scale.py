@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--ranks", type=int, default=2, help="reference ranks (mpiexec -n), a power of two")
     ap.add_argument("--threads", type=int, default=8, help="-threads per reference rank")
     ap.add_argument("--maxcand", type=int, default=2)
+    ap.add_argument("--mpi-ranks", type=int, default=1, help="ranks of mcq_query_mpi (they share this box's GPU)")
     ap.add_argument("--workdir", default="/tmp/mcq_refscale")
     ap.add_argument("--keep", action="store_true")
     a = ap.parse_args()
@@ -141,6 +142,22 @@ def main():
     if p2.returncode != 0:
         print(p2.stdout[-3000:]); sys.exit("mcq_query_cli failed")
 
+    # ---- 3. the multi-GPU host (mcq_query_mpi: the feature-sharded path behind the C ABI) with the one GPU of this box:
+    # one rank, its blocks through RCCL (a communicator of one, MCQ_SHARD_FORCE_RCCL); with --mpi-ranks N > 1 the ranks
+    # share the GPU and exchange through MPI_Alltoallv
+    have_mpi_cli = os.path.exists(pkg.mpi_cli_path())
+    if have_mpi_cli:
+        env3 = dict(os.environ, LD_LIBRARY_PATH=pkg.mpi_lib_dir() + ":" + os.environ.get("LD_LIBRARY_PATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if a.mpi_ranks == 1:
+            env3["MCQ_SHARD_FORCE_RCCL"] = "1"
+        t0 = time.time()
+        p3 = subprocess.run(["/opt/conda/bin/mpiexec", "-n", str(a.mpi_ranks), pkg.mpi_cli_path(), "db", str(P), "reads_1.fa", "reads_2.fa",
+                             "-threads", str(a.threads), "-transport", "rccl" if a.mpi_ranks == 1 else "mpi", "-out", "ours_mpi.out"] + opts,
+                            cwd=a.workdir, env=env3, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        res["engine_mpi_wall_s"] = round(time.time() - t0, 1)
+        if p3.returncode != 0:
+            print(p3.stdout[-3000:]); sys.exit("mcq_query_mpi failed")
+
     def parse(path):
         lines, summary = [], {}
         with open(os.path.join(a.workdir, path)) as f:
@@ -159,6 +176,11 @@ def main():
     m = re.match(r"([0-9.e+]+)\s*queries/min", rs.get("speed", ""))
     if m:
         res["reference_reads_per_s"] = float(m.group(1)) / 60.0        # a pair counts as two (src/printing.cpp:626-627)
+    if have_mpi_cli:
+        ml, ms = parse("ours_mpi.out")
+        res["engine_mpi_summary"] = ms
+        res["engine_mpi_ranks"] = a.mpi_ranks
+        res["engine_mpi_identical_after_sorting"] = sorted(ml) == sorted(rl)
     res["mapping_lines"] = [len(rl), len(ol)]
     res["identical_mapping_lines"] = rl == ol
     if rl != ol:
@@ -172,7 +194,8 @@ def main():
     print(json.dumps(res, indent=1))
     if not a.keep:
         shutil.rmtree(a.workdir, ignore_errors=True)
-    sys.exit(0 if res["identical_mapping_lines"] or res.get("identical_after_sorting") else 1)
+    ok = (res["identical_mapping_lines"] or res.get("identical_after_sorting")) and res.get("engine_mpi_identical_after_sorting", True)
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":

@@ -77,11 +77,14 @@ def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, tmp_p
     assert norm(mine) == norm(ref)
 
 
-@pytest.mark.parametrize("n_ranks,transport", [(1, "rccl"), (2, "mpi"), (3, "mpi")])
-def test_mpi_program_writes_the_references_out_file(n_ranks, transport, tmp_path):
+@pytest.mark.parametrize("n_ranks,transport,extra", [(1, "rccl", []), (2, "mpi", []), (3, "mpi", []),
+                                                     (1, "rccl", ["-batch", "50"]),            # 4 batches, RCCL, padded after the first
+                                                     (2, "mpi", ["-batch", "16"]),             # 7 batches per rank
+                                                     (3, "mpi", ["-batch-bases", "6000"])])    # cut by bases: ranks differ in their batch counts
+def test_mpi_program_writes_the_references_out_file(n_ranks, transport, extra, tmp_path):
     """mcq_query_mpi -- the multi-GPU host in C++ under mpiexec, one hash-range shard of the table per rank, the sharded
     path behind the C ABI -- writes the file the reference wrote under mpiexec -n 4 (emulate_ranks = 4, whatever the
-    number of GPU ranks).  2 and 3 ranks share the one GPU of the test box, their blocks travel through MPI_Alltoallv
+    number of GPU ranks and however the reads are cut into batches).  2 and 3 ranks share the one GPU of the test box, their blocks travel through MPI_Alltoallv
     (-transport mpi); 1 rank takes the RCCL path with a communicator of one (MCQ_SHARD_FORCE_RCCL)."""
     import gzip
     import re
@@ -102,7 +105,7 @@ def test_mpi_program_writes_the_references_out_file(n_ranks, transport, tmp_path
         env["MCQ_SHARD_FORCE_RCCL"] = "1"
     r = subprocess.run([mpiexec, "-n", str(n_ranks), pkg.mpi_cli_path(), prefix, "4", "r1.fq", "r2.fq", "-lowest", fx.q["lowest"],
                         "-maxcand", str(fx.maxcand), "-hitmin", str(fx.hitmin), "-hitdiff", str(fx.q["hitdiff"]), "-threads", "2",
-                        "-tophits", "-transport", transport, "-out", "out.txt"],
+                        "-tophits", "-transport", transport, "-out", "out.txt"] + extra,
                        cwd=tmp_path, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
 
