@@ -300,6 +300,13 @@ def main():
                 return err or "another rank failed to connect its shard context"
         elif err:
             sharded = None
+        elif os.environ.get("MCQ_SHARD_FORCE_RCCL"):
+            # one rank, but its blocks through ncclSend / ncclRecv to itself (the engine's test hook): how the RCCL kernels
+            # share the GPU with the path's own kernels can be looked at on a box with one GPU
+            try:
+                sharded.comm_rccl(eng.Shard.unique_id())
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, str(e)[:300]); sharded = None
         return err
 
     # ---- leg 2: sharded table + all-to-all exchange
