@@ -19,7 +19,8 @@
 //
 // usage: mcq_query_cli <dbprefix> <n_ranks> <r1.fq> <r2.fq|-> [-lowest R] [-highest R] [-maxcand N] [-hitmin N]
 //            [-hitdiff X] [-insertsize N] [-threads N] [-tophits] [-taxids] [-taxids-only] [-omit-ranks] [-lineage]
-//            [-mapped-only] [-nomap] [-noquirks] [-out FILE]
+//            [-mapped-only] [-nomap] [-noquirks] [-out FILE] [-batch N] [-batch-bases N]
+// (-batch / -batch-bases: queries / bases per batch; the reads go through in batches, see mcq_query_cli.cpp)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>

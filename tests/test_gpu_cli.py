@@ -42,11 +42,12 @@ def test_cli_output_equals_reference(tag, P, tmp_path):
 
 VARIANTS = {"default": [], "tophits": ["-tophits"], "lineage": ["-tophits", "-taxids", "-lineage"],
             "idsonly": ["-tophits", "-taxids-only", "-omit-ranks", "-mapped-only"]}
+BATCHING = {"": [], "batch16": ["-batch", "16"], "bases5000": ["-batch-bases", "5000"]}      # how the CLI cuts the reads (mcq_query_pipelined)
 
 
 @pytest.mark.parametrize("tag,P", [("mini", 4), ("tie", 2)])
-@pytest.mark.parametrize("variant", sorted(VARIANTS))
-def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, tmp_path):
+@pytest.mark.parametrize("variant,batching", [(v, "") for v in sorted(VARIANTS)] + [("tophits", "batch16"), ("tophits", "bases5000")])
+def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, batching, tmp_path):
     """the whole -out file -- parameter lines, TABLE_LAYOUT, mapping lines in the default rank:name layout and the
     other layouts, the summary with its statistics (src/printing.cpp:622-641, :522-555; src/classification.cpp:583-632)
     -- against the file the reference wrote under mpiexec -n P (tests/golden/*/P*/cli_*.out.gz); compared sorted (the
@@ -63,7 +64,7 @@ def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, tmp_p
                 f.write("@%s\n%s\n+\n%s\n" % (n, s, "I" * len(s)))
     prefix = fx.shard_paths[0][: -len(".db_0")]
     r = subprocess.run([pkg.cli_path(), prefix, str(P), "r1.fq", "r2.fq", "-lowest", fx.q["lowest"], "-maxcand", str(fx.maxcand),
-                        "-hitmin", str(fx.hitmin), "-hitdiff", str(fx.q["hitdiff"]), "-threads", "2", "-out", "out.txt"] + VARIANTS[variant],
+                        "-hitmin", str(fx.hitmin), "-hitdiff", str(fx.q["hitdiff"]), "-threads", "2", "-out", "out.txt"] + VARIANTS[variant] + BATCHING[batching],
                        cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
 
