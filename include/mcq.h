@@ -325,6 +325,11 @@ int mcq_shard_kernel_times(mcq_shard* ctx, double* ms /* [3] */, uint64_t* n_bat
  * flags = MCQ_DEVICE_PTRS | MCQ_BATCH_RANGES: the bases are read in place, never copied.  */
 int mcq_fastq_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs,
                     uint64_t* n_seqs_out, void* stream);
+/* the same for FASTA text with every sequence on ONE line (2 lines per record: what read files in FASTA look like; the
+ * reference's fasta_reader also joins sequences that span lines, src/sequence_io.cpp:122-200: such files -- genomes --
+ * go through a host reader, their bases are not contiguous in the text)                                             */
+int mcq_fasta_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs,
+                    uint64_t* n_seqs_out, void* stream);
 
 /* ---- row f2: building the table from reference sequences on the GPU -----------------
  * Replaces the build-side loop add_all_window_sketches (src/sketch_database.h:1079-1097) with

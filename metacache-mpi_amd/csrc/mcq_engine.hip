@@ -1433,8 +1433,9 @@ __global__ __launch_bounds__(256) void k_fq_count(const char* text, u64 n, u64* 
     __syncthreads();
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_c;
 }
+// L: lines per record (4: FASTQ; 2: FASTA with the sequence on one line); the sequence is the record's second line
 __global__ __launch_bounds__(256) void k_fq_ranges(const char* text, u64 n, const u64* tile_off, u64 n_tiles, u64* ranges, u64 max_seqs,
-                                                   u64* n_seqs_out) {
+                                                   u64* n_seqs_out, u32 L) {
     __shared__ u32 s_w[4];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 base = (u64)blockIdx.x * MCQ_FQ_TILE + (u64)tid * 16;
@@ -1450,16 +1451,17 @@ __global__ __launch_bounds__(256) void k_fq_ranges(const char* text, u64 n, cons
         const u32 j = (u32)__builtin_ctz(mask);
         mask &= mask - 1;
         const u64 p = base + j;
-        const u64 rec = line >> 2;
+        const u64 rec = L == 4 ? line >> 2 : line >> 1;
+        const u32 li = (u32)(line & (L - 1));
         if (rec < max_seqs) {
-            if ((line & 3) == 0) ranges[2 * rec] = p + 1;
-            else if ((line & 3) == 1) ranges[2 * rec + 1] = p;
+            if (li == 0) ranges[2 * rec] = p + 1;
+            else if (li == 1) ranges[2 * rec + 1] = p;
         }
         ++line;
     }
     if (blockIdx.x == 0 && tid == 0) {
         const u64 total = tile_off[n_tiles];
-        u64 ns = (total + 2) / 4;                               // records whose sequence line is complete
+        u64 ns = total >= 2 ? (total - 2) / L + 1 : 0;          // records whose sequence line is complete
         *n_seqs_out = ns < max_seqs ? ns : max_seqs;
     }
 }
@@ -2263,8 +2265,16 @@ extern "C" int mcq_bucket_features(const uint32_t* features, uint64_t n, uint32_
 }
 
 // ------------------------------------------------------------------ row f4 entry point
+static int text_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs, uint64_t* n_seqs_out, void* stream, u32 L);
 extern "C" int mcq_fastq_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs,
                                uint64_t* n_seqs_out, void* stream) {
+    return text_index(text, n_bytes, seq_ranges, max_seqs, n_seqs_out, stream, 4);
+}
+extern "C" int mcq_fasta_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs,
+                               uint64_t* n_seqs_out, void* stream) {
+    return text_index(text, n_bytes, seq_ranges, max_seqs, n_seqs_out, stream, 2);
+}
+static int text_index(const char* text, uint64_t n_bytes, uint64_t* seq_ranges, uint64_t max_seqs, uint64_t* n_seqs_out, void* stream, u32 L) {
     if (!seq_ranges || !n_seqs_out || (n_bytes && !text)) return fail(MCQ_E_ARG, "null argument");
     hipStream_t st = (hipStream_t)stream;
     const u64 n_tiles = std::max<u64>(1, (n_bytes + MCQ_FQ_TILE - 1) / MCQ_FQ_TILE);
@@ -2274,7 +2284,7 @@ extern "C" int mcq_fastq_index(const char* text, uint64_t n_bytes, uint64_t* seq
     HIPCHK(hipMallocAsync((void**)&off, (n_tiles + 1) * 8, st));
     hipLaunchKernelGGL(k_fq_count, dim3((u32)n_tiles), dim3(256), 0, st, text, n_bytes, cnt);
     int rc = device_exclusive_scan<u64>((const u64*)cnt, off, n_tiles, st); if (rc) return rc;
-    hipLaunchKernelGGL(k_fq_ranges, dim3((u32)n_tiles), dim3(256), 0, st, text, n_bytes, (const u64*)off, n_tiles, seq_ranges, max_seqs, n_seqs_out);
+    hipLaunchKernelGGL(k_fq_ranges, dim3((u32)n_tiles), dim3(256), 0, st, text, n_bytes, (const u64*)off, n_tiles, seq_ranges, max_seqs, n_seqs_out, L);
     HIPCHK(hipFreeAsync(cnt, st)); HIPCHK(hipFreeAsync(off, st));
     HIPCHK(hipGetLastError());
     return MCQ_OK;

@@ -115,6 +115,7 @@ def lib():
         L.mcq_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Batch),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_fastq_index.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.mcq_fasta_index.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
         L.mcq_build_table.argtypes = [C.POINTER(BuildDesc), C.POINTER(C.c_void_p)]
         L.mcq_db_build.argtypes = [C.POINTER(BuildDesc), C.POINTER(C.c_void_p)]
         L.mcq_table_info.argtypes = [C.c_void_p] + [C.c_void_p] * 6
@@ -484,6 +485,11 @@ class Table:
 def fastq_index(text_ptr, n_bytes, ranges_ptr, max_seqs, n_seqs_ptr, stream=None):
     """raw FASTQ text in HBM -> (begin,end) ranges of the sequence lines (device buffers)"""
     _chk(lib().mcq_fastq_index(text_ptr, n_bytes, ranges_ptr, max_seqs, n_seqs_ptr, stream))
+
+
+def fasta_index(text_ptr, n_bytes, ranges_ptr, max_seqs, n_seqs_ptr, stream=None):
+    """the same for FASTA text with one sequence line per record"""
+    _chk(lib().mcq_fasta_index(text_ptr, n_bytes, ranges_ptr, max_seqs, n_seqs_ptr, stream))
 
 
 def owner(feature, n_shards):

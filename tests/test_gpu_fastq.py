@@ -112,3 +112,30 @@ def test_index_of_unaligned_text_and_odd_bytes(shift):
     exp = _py_ranges(text)
     assert int(n.item()) == len(exp) == len(recs)
     assert ranges.cpu().numpy()[: 2 * len(exp)].reshape(-1, 2).tolist() == [list(x) for x in exp]
+
+
+@pytest.mark.parametrize("final", [True, False])
+def test_two_line_fasta_index_matches_line_parser(final):
+    """mcq_fasta_index: '>' header line + one sequence line per record"""
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(9)
+    seqs = ["".join(rng.choice(list("ACGTNacgt"), int(rng.integers(1, 300)))) for _ in range(2500)]
+    text = "".join(">read%d description\n%s\n" % (i, s) for i, s in enumerate(seqs))
+    if not final:
+        text = text[:-1] + ""                                   # last sequence line without its newline: not a complete record
+    tb = torch.from_numpy(np.frombuffer(text.encode(), dtype=np.uint8).copy()).to(dev)
+    cap = len(seqs) + 3
+    ranges = torch.zeros(2 * cap, dtype=torch.int64, device=dev)
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    eng.fasta_index(tb.data_ptr(), tb.numel(), ranges.data_ptr(), cap, n.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    lines, pos, exp = text.split("\n"), 0, []
+    for i, ln in enumerate(lines):
+        if i % 2 == 1 and i < len(lines) - 1:
+            exp.append([pos, pos + len(ln)])
+        pos += len(ln) + 1
+    assert int(n.item()) == len(exp) == (len(seqs) if final else len(seqs) - 1)
+    assert ranges.cpu().numpy()[: 2 * len(exp)].reshape(-1, 2).tolist() == exp
+    got = [text[a:b] for a, b in exp]
+    assert got == seqs[: len(exp)]
