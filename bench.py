@@ -22,6 +22,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -71,7 +72,38 @@ def parse():
     ap.add_argument("--distinct-batches", type=int, default=0, help="0 = one per step (capped by memory)")
     ap.add_argument("--no-pcie-leg", action="store_true")
     ap.add_argument("--packed-input", action="store_true", help="experiment: the resident batches in the MCQ_BATCH_PACKED form (c2 / paired, fused leg)")
+    ap.add_argument("--loc-format", default="auto", choices=["auto", "fields32", "fields64", "gw"],
+                    help="location words of the table: auto = what mcq_db_create picks (32-bit bit fields if they fit, else the 32-bit "
+                         "global window index, else 64 bit); gw / fields64 force a form (fields32 = auto, fails the run if it does not fit)")
+    ap.add_argument("--bucket-bytes", type=int, default=0, choices=[0, 16, 64], help="table layout: 0 = per table (mean list length), 16 / 64 force it")
+    ap.add_argument("--contigs", type=int, default=1, help="split every genome into this many targets (RefSeq assemblies: many sequences per genome)")
+    ap.add_argument("--long-genome-mbp", type=float, default=0.0,
+                    help="add one genome of this many Mbp (>= 14.9 Mbp = 2^17 windows: with >= 2^15 targets the (target, window) "
+                         "fields no longer fit 32 bits, as on RefSeq)")
     return ap.parse_args()
+
+
+def arm_watchdog(seconds, last_words, exit_code):
+    """Ends the process `seconds` from now with `exit_code`, whatever happens: last_words() (prints the line of what has
+    been measured so far) may fail or hang in a library -- os._exit still runs.  Returns the timer (cancel() disarms it).
+    Never restarts or re-executes anything: a process that touched the GPU just ends."""
+    def give_up():
+        try:
+            last_words()
+        except BaseException as e:          # noqa: BLE001 -- nothing may keep the exit from happening
+            try:
+                sys.stderr.write("[bench watchdog] could not print the fallback line: %r\n" % (e,))
+            except Exception:
+                pass
+        finally:
+            try:
+                sys.stderr.flush()
+            finally:
+                os._exit(exit_code)
+    t = threading.Timer(seconds, give_up)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def spawn_ranks(a):
@@ -154,6 +186,10 @@ def main():
     t_setup = time.time()
     gen_bases, gen_off, species = synth.make_genomes(n_species, a.strains, a.genome_min, a.genome_max,
                                                      a.divergence, seed=3, device=dev)
+    if a.long_genome_mbp > 0:
+        gen_bases, gen_off, species = synth.add_genome(gen_bases, gen_off, species, int(a.long_genome_mbp * 1e6), seed=4)
+    if a.contigs > 1:
+        gen_off, species = synth.split_targets(gen_off, species, a.contigs, keep_last_whole=a.long_genome_mbp > 0)
     # table built on the GPU through the C ABI (mcq_build_table, csrc/mcq_build.hip)
     torch.cuda.empty_cache()            # the builder allocates with hipMalloc, outside torch's cache
     t_build = time.time()
@@ -163,14 +199,22 @@ def main():
     t_build = time.time() - t_build
     sp32 = species.to(torch.int32).contiguous()
 
+    dbflags = {"auto": 0, "fields32": 0, "fields64": eng.MCQ_DB_LOCS_64, "gw": eng.MCQ_DB_LOCS_GW}[a.loc_format] | \
+              {0: 0, 16: eng.MCQ_DB_SLOTS_16, 64: eng.MCQ_DB_BUCKETS_64}[a.bucket_bytes]
+
     def make_db(n_shards=1, shard_id=0):
-        return eng.Database(None, None, None, None, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0,
+        return eng.Database(None, None, None, None, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0, flags=dbflags,
                             device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr,
                                              tgt2tax=sp32.data_ptr(), n_keys=table.n_keys, n_locs=table.n_locs,
                                              n_targets=sp32.numel()))
     # full table (fused single-GPU path / replicas) and/or this rank's hash-range shard
     db = make_db() if with_fused else None
     db_shard = make_db(world, rank) if with_sharded else None
+    db_layout = (db or db_shard).layout()
+    db_layout.pop("gw_offsets", None)
+    db_layout["loc_format"] = {eng.MCQ_LOC_FIELDS64: "fields64", eng.MCQ_LOC_FIELDS32: "fields32", eng.MCQ_LOC_GLOBAL_WINDOW: "global_window"}[db_layout["loc_format"]]
+    if a.loc_format == "fields32" and db_layout["loc_format"] != "fields32":
+        sys.exit("--loc-format fields32: the (target, window) fields of this table do not fit 32 bits (the handle chose %s)" % db_layout["loc_format"])
     n_keys, n_locs, n_targets = table.n_keys, table.n_locs, species.numel()
     keys, list_off, locs = (None, None, None)
     want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and (world == 1 or n_locs <= 600_000_000)
@@ -243,11 +287,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed(step):
-        """W untimed steps, then exactly K steps between barrier+synchronize; max over ranks."""
+    def timed(step, on_start=None):
+        """W untimed steps, then exactly K steps between barrier+synchronize; max over ranks.  on_start runs after the
+        warm-up (the per-kernel event timing is switched on there: its averages cover the timed steps only)."""
         for i in range(a.warmup):
             step(i)
         barrier()
+        if on_start is not None:
+            on_start()
         t0 = time.perf_counter()
         for i in range(a.steps):
             step(a.warmup + i)
@@ -262,99 +309,13 @@ def main():
     # ---- leg 1: fused kernel on the full table: THE path at N=1; "replicas only" (reads split, no collective) at N>1
     fused_elapsed, st, kms, kn = None, None, None, 0
     if with_fused:
-        ws.timing(True)
-        fused_elapsed = timed(step_fused)
+        fused_elapsed = timed(step_fused, lambda: ws.timing(True))
         st = ws.sync()
         kms, kn = ws.kernel_times()
         ws.timing(False)
 
-    def setup_sharded():
-        """creates the context and connects it; a failure on ANY rank skips the leg on every rank (returns the error text)"""
-        nonlocal sharded
-        err = None
-        try:
-            sharded = eng.Shard(db_shard, world, rank, max_queries=nq, max_bases=max_bases, max_seqs=B)
-        except Exception as e:
-            err = "%s: %s" % (type(e).__name__, str(e)[:300])
-        if world > 1:               # nobody enters ncclCommInitRank unless everybody can
-            flag = torch.tensor([1 if err else 0], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()):
-                sharded = None
-                return err or "another rank failed to create its shard context"
-            try:
-                if a.backend == "nccl":
-                    box = [eng.Shard.unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(box, src=0)
-                    sharded.comm_rccl(box[0])
-                else:       # rehearsal on a box with one GPU: blocks through the host and gloo
-                    sys.path.insert(0, os.path.join(ROOT, "tests"))
-                    from shard_exchange_gloo import make_gloo_exchange
-                    sharded.set_exchange(make_gloo_exchange())
-            except Exception as e:
-                err = "%s: %s" % (type(e).__name__, str(e)[:300])
-            flag = torch.tensor([1 if err else 0], dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()):
-                sharded = None
-                return err or "another rank failed to connect its shard context"
-        elif err:
-            sharded = None
-        elif os.environ.get("MCQ_SHARD_FORCE_RCCL"):
-            # one rank, but its blocks through ncclSend / ncclRecv to itself (the engine's test hook): how the RCCL kernels
-            # share the GPU with the path's own kernels can be looked at on a box with one GPU
-            try:
-                sharded.comm_rccl(eng.Shard.unique_id())
-            except Exception as e:
-                err = "%s: %s" % (type(e).__name__, str(e)[:300]); sharded = None
-        return err
-
-    # ---- leg 2: sharded table + all-to-all exchange
+    # (state of the sharded leg; roofline() / make_line() are defined BEFORE that leg so that its watchdog can print a line)
     sharded_elapsed, sharded_error, sh_stats, sh_kms, sh_kn, sharded_ok = None, None, None, None, 0, None
-    if with_sharded:
-        # The exchange runs on real xGMI only in the driver's multi-GPU runs.  Should a rank fail inside it and leave the
-        # others waiting in a collective, the watchdog prints the line of the leg already measured and ends every rank
-        # with a non-zero status.
-        import threading
-
-        def give_up():
-            if rank == 0 and fused_elapsed is not None:
-                emit(make_line("replicas" if world > 1 else "single", None,
-                               "watchdog: sharded leg did not finish within %d s" % a.sharded_timeout))
-            sys.stderr.write("[bench rank %d] sharded leg timed out; exiting\n" % rank); sys.stderr.flush()
-            os._exit(EXIT_SHARDED_FAILED)
-        dog = threading.Timer(a.sharded_timeout, give_up)
-        dog.daemon = True
-        dog.start()
-        sharded_error = setup_sharded()
-        try:
-            if sharded is None:
-                raise RuntimeError(sharded_error or "no shard context")
-            # the first batch of a context runs in the exact mode and learns the block sizes of the padded mode (host
-            # round trips); it is an extra untimed step in front of the warmup
-            step_sharded(0)
-            sharded.sync(stream)
-            sharded.timing(True)
-            sharded_elapsed = timed(step_sharded)
-            sh_stats = sharded.sync(stream)
-            sh_kms, sh_kn = sharded.kernel_times()
-            sharded.timing(False)
-            sh_stats["exchange_block_features_locations"] = list(sharded.caps())
-            if with_fused:
-                # same batch through the fused kernel on the replicated table: bit-identical results expected on every rank
-                last = a.warmup + a.steps - 1
-                step_fused(last)
-                torch.cuda.synchronize(dev)
-                okn = bool(torch.equal(ncand, ncand_s))
-                m = torch.arange(a.max_cand, device=dev)[None, :] < ncand[:, None]
-                okc = bool(torch.equal(cands[m], cands_s[m]))
-                flag = torch.tensor([1 if (okn and okc) else 0], dtype=torch.int32)
-                if world > 1:
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                sharded_ok = bool(flag.item())
-        except Exception as e:          # keep the line; the replicas leg stands
-            sharded_error = sharded_error or "%s: %s" % (type(e).__name__, str(e)[:300])
-        dog.cancel()
 
     def roofline(kind, ms3, n_batches, stats, elapsed):
         names = KERNELS[kind]
@@ -413,7 +374,8 @@ def main():
                 "reads_total": total_reads, "db_keys": n_keys, "db_locations": n_locs,
                 "db_hbm_bytes": (db_shard if mode == "sharded" else db).bytes(),
                 "db_scaling": "fixed" if (world == 1 or a.db_fixed) else "%d species per GPU: the table grows with N, and with it the locations per read" % a.species,
-                "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "distinct_batches": nb,
+                "emulate_ranks": a.emulate_ranks, "max_cand": a.max_cand, "P_x_M": a.emulate_ranks * a.max_cand, "distinct_batches": nb,
+                "db_targets": n_targets, "db_layout": db_layout,
                 "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
                                 "sharded": "feature table hash-range-sharded over %d GPU(s), features to their owners and hits back (%s)" %
                                            (world, "device copy" if world == 1 else ("RCCL send/recv groups" if a.backend == "nccl" else "host-staged gloo rehearsal"))}[mode],
@@ -436,6 +398,87 @@ def main():
         elif kn:
             out["roofline"] = roofline("fused", kms, kn, st, fused_elapsed)
         return out
+
+    def setup_sharded():
+        """creates the context and connects it; a failure on ANY rank skips the leg on every rank (returns the error text)"""
+        nonlocal sharded
+        err = None
+        try:
+            sharded = eng.Shard(db_shard, world, rank, max_queries=nq, max_bases=max_bases, max_seqs=B)
+        except Exception as e:
+            err = "%s: %s" % (type(e).__name__, str(e)[:300])
+        if world > 1:               # nobody enters ncclCommInitRank unless everybody can
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                sharded = None
+                return err or "another rank failed to create its shard context"
+            try:
+                if a.backend == "nccl":
+                    box = [eng.Shard.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    sharded.comm_rccl(box[0])
+                else:       # rehearsal on a box with one GPU: blocks through the host and gloo
+                    sys.path.insert(0, os.path.join(ROOT, "tests"))
+                    from shard_exchange_gloo import make_gloo_exchange
+                    sharded.set_exchange(make_gloo_exchange())
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, str(e)[:300])
+            flag = torch.tensor([1 if err else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                sharded = None
+                return err or "another rank failed to connect its shard context"
+        elif err:
+            sharded = None
+        elif os.environ.get("MCQ_SHARD_FORCE_RCCL"):
+            # one rank, but its blocks through ncclSend / ncclRecv to itself (the engine's test hook): how the RCCL kernels
+            # share the GPU with the path's own kernels can be looked at on a box with one GPU
+            try:
+                sharded.comm_rccl(eng.Shard.unique_id())
+            except Exception as e:
+                err = "%s: %s" % (type(e).__name__, str(e)[:300]); sharded = None
+        return err
+
+    # ---- leg 2: sharded table + all-to-all exchange
+    if with_sharded:
+        # The exchange runs on real xGMI only in the driver's multi-GPU runs.  Should a rank fail inside it and leave the
+        # others waiting in a collective, the watchdog prints the line of the leg already measured and ends every rank
+        # with a non-zero status.
+        def last_words():
+            if rank == 0 and fused_elapsed is not None:
+                emit(make_line("replicas" if world > 1 else "single", None,
+                               "watchdog: sharded leg did not finish within %d s" % a.sharded_timeout))
+            sys.stderr.write("[bench rank %d] sharded leg timed out; exiting\n" % rank)
+        dog = arm_watchdog(a.sharded_timeout, last_words, EXIT_SHARDED_FAILED)
+        sharded_error = setup_sharded()
+        try:
+            if sharded is None:
+                raise RuntimeError(sharded_error or "no shard context")
+            # the first batch of a context runs in the exact mode and learns the block sizes of the padded mode (host
+            # round trips); it is an extra untimed step in front of the warmup
+            step_sharded(0)
+            sharded.sync(stream)
+            sharded_elapsed = timed(step_sharded, lambda: sharded.timing(True))
+            sh_stats = sharded.sync(stream)
+            sh_kms, sh_kn = sharded.kernel_times()
+            sharded.timing(False)
+            sh_stats["exchange_block_features_locations"] = list(sharded.caps())
+            if with_fused:
+                # same batch through the fused kernel on the replicated table: bit-identical results expected on every rank
+                last = a.warmup + a.steps - 1
+                step_fused(last)
+                torch.cuda.synchronize(dev)
+                okn = bool(torch.equal(ncand, ncand_s))
+                m = torch.arange(a.max_cand, device=dev)[None, :] < ncand[:, None]
+                okc = bool(torch.equal(cands[m], cands_s[m]))
+                flag = torch.tensor([1 if (okn and okc) else 0], dtype=torch.int32)
+                if world > 1:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                sharded_ok = bool(flag.item())
+        except Exception as e:          # keep the line; the replicas leg stands
+            sharded_error = sharded_error or "%s: %s" % (type(e).__name__, str(e)[:300])
+        dog.cancel()
 
     out = make_line(mode, sharded_elapsed, sharded_error)
     if a.stop_stage:

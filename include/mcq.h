@@ -66,8 +66,17 @@ enum {
                                    -remove-overpopulated-features (src/mode_build.cpp:847-1074): a feature whose
                                    per-rank location counts (after the per-rank limit) sum to more than
                                    max_locs - 1 is removed from every rank                                  */
-    MCQ_DB_LOCS_64 = 0x200u     /* mcq_db_desc.flags: keep 64-bit locations in HBM even when
-                                   (tgt,win) would fit the compact 32-bit form           */
+    MCQ_DB_LOCS_64 = 0x200u,    /* mcq_db_desc.flags: keep 64-bit locations in HBM even when
+                                   (tgt,win) would fit a 32-bit form                     */
+    MCQ_DB_LOCS_GW = 0x2000u,   /* mcq_db_desc.flags: 32-bit locations in the global-window form (first window of the
+                                   target + window) even when the two bit fields would fit 32 bits.  Without either
+                                   flag the handle picks: bit fields (tgt << wb) | win if they fit 32 bits, else the
+                                   global-window form if the table has fewer than 2^32 - 1 windows (any table the
+                                   reference can hold below ~485 Gbp, src/config.h:54-67), else 64-bit words  */
+    MCQ_DB_SLOTS_16 = 0x4000u,  /* mcq_db_desc.flags: 16-B slots, every list behind the slot array           */
+    MCQ_DB_BUCKETS_64 = 0x8000u /* mcq_db_desc.flags: 64-B buckets, lists of up to 14 (7) locations inside them.
+                                   Without either flag the layout follows the table: buckets while the mean list has
+                                   at most 4 locations, slots beyond                  */
 };
 
 /* Database description = the union of the reference's P shard tables
@@ -98,11 +107,15 @@ typedef struct {
     const uint32_t* tgt2tax;    /* [n_targets]                                        */
     uint32_t n_shards;          /* >= 1                                               */
     uint32_t shard_id;
-    uint32_t flags;             /* MCQ_DEVICE_PTRS, MCQ_DB_LOCS_64                    */
+    uint32_t flags;             /* MCQ_DEVICE_PTRS, MCQ_DB_LOCS_64 / _GW, MCQ_DB_SLOTS_16 / MCQ_DB_BUCKETS_64 */
     int32_t  device;            /* HIP device ordinal                                 */
     uint32_t loc_win_bits;      /* 0 = derive from the data.  Shards built from different
                                    data must agree on the location format: pass the bit width
                                    of the largest window id of the WHOLE database          */
+    const uint32_t* tgt_windows; /* [n_targets] windows of every target (the reference's taxon `windows` field of the
+                                   owning rank, src/taxonomy.h:326-335), or NULL = 1 + the largest window id found in
+                                   `locs`.  Only the global-window form reads it; shards that are created from
+                                   different subsets of the locations must all pass it (same location words everywhere) */
 } mcq_db_desc;
 
 /* One batch of sequences: bases[seq_off[i] .. seq_off[i+1]) is sequence i (ASCII,
@@ -211,7 +224,8 @@ int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t* win_off,
  *   list_src is not NULL it also receives where each list starts in the shard, so that
  *   mcq_lookup_gather need not probe again.
  * mcq_lookup_gather: concatenates the lists at out_off[i] in the handle's NATIVE location
- *   width: mcq_db_loc_bytes() = 4 ((tgt << mcq_db_win_bits()) | win) or 8 ((tgt << 32) | win).
+ *   width: mcq_db_loc_bytes() = 4 ((tgt << mcq_db_win_bits()) | win, or the global window index: mcq_db_layout_get)
+ *   or 8 ((tgt << 32) | win).
  *   The native width is what travels between GPUs.                                     */
 int mcq_lookup_count(const mcq_db* db, const uint32_t* features, uint64_t n_features,
                      uint32_t* list_len, uint64_t* list_src, void* stream);
@@ -220,6 +234,21 @@ int mcq_lookup_gather(const mcq_db* db, const uint32_t* features, uint64_t n_fea
                       const uint64_t* out_off /* [n_features+1] */, void* out_locs, void* stream);
 uint32_t mcq_db_loc_bytes(const mcq_db* db);
 uint32_t mcq_db_win_bits(const mcq_db* db);
+/* what a handle was built as (chosen per table by mcq_db_create) */
+enum { MCQ_LOC_FIELDS64 = 0, MCQ_LOC_FIELDS32 = 1, MCQ_LOC_GLOBAL_WINDOW = 2 };
+typedef struct {
+    uint32_t loc_bytes;         /* 4 or 8                                                                */
+    uint32_t loc_format;        /* MCQ_LOC_*: (tgt << 32) | win, (tgt << win_bits) | win, or gw_offsets[tgt] + win */
+    uint32_t win_bits;
+    uint32_t bucket_bytes;      /* 64 (lists of up to 14 / 7 locations inside the bucket) or 16           */
+    uint32_t slots_per_key;     /* 4 or 2: load factor <= 0.25 / 0.5                                      */
+    uint64_t n_slots, n_keys, n_locs;   /* of this shard                                                  */
+    uint64_t n_ext_locs;        /* locations behind the slot array                                        */
+    uint64_t n_windows;         /* global-window form: windows of the whole database                      */
+    uint64_t bytes;             /* = mcq_db_bytes                                                         */
+    const uint32_t* gw_offsets; /* device, [n_targets + 1]; NULL unless MCQ_LOC_GLOBAL_WINDOW             */
+} mcq_db_layout;
+int mcq_db_layout_get(const mcq_db* db, mcq_db_layout* out);
 /* mcq_assemble: home side, after the lists came back.  List i (list_len[i] native-width
  *   locations, consecutive in src_locs) belongs to feature slot src_slot[i] of the batch's
  *   [window][sketch_size] feature array.  Produces the per-query segments mcq_reduce takes:
@@ -347,7 +376,7 @@ typedef struct {
     uint32_t emulate_ranks;       /* P of the build being reproduced (0 = 1)                  */
     uint32_t max_locs;            /* per (feature, rank); 0 = 254                             */
     uint32_t n_shards, shard_id;  /* mcq_db_build: as in mcq_db_desc                          */
-    uint32_t flags;               /* MCQ_DEVICE_PTRS, MCQ_DB_LOCS_64, MCQ_BUILD_REMOVE_OVERPOPULATED */
+    uint32_t flags;               /* MCQ_DEVICE_PTRS, MCQ_BUILD_REMOVE_OVERPOPULATED; mcq_db_build: MCQ_DB_LOCS_* and the layout flags too */
     int32_t device;
 } mcq_build_desc;
 

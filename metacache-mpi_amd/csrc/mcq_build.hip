@@ -355,7 +355,7 @@ extern "C" int mcq_db_build(const mcq_build_desc* d, mcq_db** out) {
     c.k = d->k; c.sketch_size = d->sketch_size; c.winlen = d->winlen; c.winstride = d->winstride; c.tgt_winstride = d->winstride;
     c.n_targets = d->n_targets; c.n_keys = T->n_keys; c.n_locs = T->n_locs;
     c.keys = T->keys; c.list_off = T->list_off; c.locs = T->locs; c.tgt2tax = t2t;
-    c.n_shards = d->n_shards ? d->n_shards : 1; c.shard_id = d->shard_id; c.flags = MCQ_DEVICE_PTRS | (d->flags & MCQ_DB_LOCS_64); c.device = d->device;
+    c.n_shards = d->n_shards ? d->n_shards : 1; c.shard_id = d->shard_id; c.flags = MCQ_DEVICE_PTRS | (d->flags & (MCQ_DB_LOCS_64 | MCQ_DB_LOCS_GW | MCQ_DB_SLOTS_16 | MCQ_DB_BUCKETS_64)); c.device = d->device;
     int rc = mcq_db_create(&c, out);
     if (rc != MCQ_OK) g_berr = mcq_last_error();
     (void)hipFree(t2t);

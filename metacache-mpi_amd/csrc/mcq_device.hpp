@@ -32,19 +32,76 @@ namespace mcq {
 
 // ------------------------------------------------------------------ structures
 struct DbDev {
-    const uint4* slots;      // 64-B buckets, 4 uint4 each: {key, len, 14 words}; key == MCQ_EMPTY: unused.  A list of up to
-                             // 14 compact (7 wide) locations sits in the bucket itself, a longer one behind the buckets:
-                             // words 2,3 = its offset there
+    const uint4* slots;      // buckets of 64 B (4 uint4: {key, len, 14 words}) or 16 B ({key, len, offset lo, hi}); key == MCQ_EMPTY:
+                             // unused.  In a 64-B bucket a list of up to 14 compact (7 wide) locations sits in the bucket itself;
+                             // any other list behind the buckets: words 2,3 = its offset there.  The layout is chosen per table
+                             // (mcq_db_create): short lists -> 64-B buckets, long lists / large tables -> 16-B slots
     u32 slot_mask;           // nslots - 1 (power of two)
+    u32 bsh;                 // log2(uint4 per bucket): 2 (64-B buckets) or 0 (16-B slots)
+    u32 inl;                 // longest list that lives in its bucket: 14 / 7 (64-B buckets, compact / wide), 0 (16-B slots)
+    u32 inl_first;           // index of a bucket's first inline location, in location units relative to the bucket
+    u64 ext0;                // first location behind the buckets, in location units relative to `locs`
     const void* locs;        // base of all lists = the bucket array itself (the long lists follow it in the same allocation):
-                             // u64 (tgt<<32)|win, or u32 (tgt<<wb)|win when `compact`
-    u32 wb;                  // window-id bits inside a location word (32 for u64 locations)
-    u32 compact;
+                             // u64 (tgt<<32)|win, or a 32-bit word when `compact`: (tgt<<wb)|win, or (gw) the global window
+                             // index gw_off[tgt] + win
+    u32 wb;                  // window-id bits inside a location word (32 for u64 locations; unused with gw)
+    u32 compact;             // 32-bit location words
+    u32 gw;                  // 32-bit location = global window index: for tables whose (target, window) space does not fit
+                             // 32 bits as two fields (RefSeq scale: >= 2^15 sequences, chromosomes of >= 2^17 windows)
+    u32 gw_shift;            // gw_blk has one entry per 2^gw_shift windows
+    const u32* gw_off;       // [n_targets + 1] first global window of every target
+    const u32* gw_blk;       // [(n_windows >> gw_shift) + 2] target that holds window b << gw_shift
     const u32* tgt2tax;
     u32 n_targets;
     u32 k, s, winlen, winstride, tgt_winstride;
     u32 magic_stride, magic_tgt_stride;   // floor(2^32 / stride): udiv_magic
 };
+
+// ---- location formats -----------------------------------------------------------------------------------------------
+// Everything behind the gather works on location words that sort like (target, window) and needs of a word k only
+//   tbeg(k)  the smallest word of k's target (so: same target <=> prev >= tbeg(k) for prev <= k; window = k - tbeg(k))
+//   tgt(k)   the target id (for the run heads only: taxon key and virtual rank).
+// LocShift: two bit fields, (tgt << wb) | win, 32- or 64-bit words -- both are shifts.
+// LocGW:    the global window index of the build (first window of the target + window): one 32-bit word for any table
+//           of fewer than 2^32 - 1 windows (485 Gbp at the default stride), whatever the number of targets.  The target
+//           comes from two small tables: gw_blk[k >> shift] brackets it (a block of 2^shift windows rarely holds more
+//           than one target's start: then a short binary search over gw_off), gw_off[t] is tbeg.  Both tables are sized
+//           to stay in L2 (<= 1 MB + 4 B per target); a lookup is two dependent L2 loads per DISTINCT location of a read.
+template <class KeyT>
+struct LocShift {
+    u32 wb;
+    __device__ __forceinline__ KeyT tbeg(KeyT k) const { return k & ~((((KeyT)1) << wb) - 1); }
+    __device__ __forceinline__ u32 tgt(KeyT k) const { return (u32)(k >> wb); }
+    __device__ __forceinline__ void locate(KeyT k, u32& t, KeyT& tb) const { t = tgt(k); tb = tbeg(k); }
+};
+struct LocGW {
+    const u32* __restrict__ off; const u32* __restrict__ blk; u32 shift;
+    __device__ __forceinline__ void locate(u32 k, u32& t, u32& tb) const {
+        const u32 b = k >> shift;
+        u32 lo = blk[b], hi = blk[b + 1];                // the target of k lies in [lo, hi]
+        u32 o = off[lo];
+        while (lo < hi) {                                // several targets start inside the block
+            const u32 mid = (lo + hi + 1) >> 1;
+            const u32 om = off[mid];
+            if (om <= k) { lo = mid; o = om; } else hi = mid - 1;
+        }
+        t = lo; tb = o;
+    }
+    __device__ __forceinline__ u32 tbeg(u32 k) const { u32 t, tb; locate(k, t, tb); return tb; }
+    __device__ __forceinline__ u32 tgt(u32 k) const { u32 t, tb; locate(k, t, tb); return t; }
+};
+template <class KeyT, bool GW> struct LocOf { typedef LocShift<KeyT> type; };
+template <> struct LocOf<u32, true> { typedef LocGW type; };
+template <class KeyT, bool GW>
+__device__ __forceinline__ typename LocOf<KeyT, GW>::type loc_format(const DbDev& db) {
+    if constexpr (GW) { LocGW f; f.off = db.gw_off; f.blk = db.gw_blk; f.shift = db.gw_shift; return f; }
+    else { LocShift<KeyT> f; f.wb = db.wb; return f; }
+}
+// smallest word of a window range of `numWindows` windows that ends at k (never below the target's first word)
+template <class KeyT>
+__device__ __forceinline__ KeyT range_low(KeyT k, KeyT tb, u32 numWindows) {
+    return (k - tb >= (KeyT)numWindows) ? k - (KeyT)(numWindows - 1) : tb;
+}
 
 struct BatchDev {
     const char* bases;       // ASCII, or (packed) the u32 words of MCQ_BATCH_PACKED
@@ -557,15 +614,15 @@ __device__ __forceinline__ u32 wave_sketch_b(const BatchDev& b, u64 at, u32 n, u
 // have, the bucket IS the list: its locations are in the same 64-B sector the probe has just brought in, so the gather
 // that follows hits the cache instead of fetching a second random sector (r01: 55 sectors per read, 29 of them list
 // heads).  off = index of the list's first location relative to db.locs, in location units, for both kinds of list.
+// Two layouts, chosen per table (mcq_db_create): 64-B buckets with inline lists while lists are short (a third fewer HBM
+// requests per read on a 2 Gbp table), 16-B slots {key, len, offset} with every list behind the slot array once they are
+// not (>= 10 Gbp: most lists do not fit a bucket any more, and the 64-B array costs +27 GB and 1-3 % time).
 #define MCQ_BUCKET_BYTES 64u
-__device__ __forceinline__ uint4 bucket_head(const DbDev& db, u32 idx) { return db.slots[(u64)idx * (MCQ_BUCKET_BYTES / 16)]; }
-// locations per bucket unit / inline capacity / first inline location, by location width (compact: 4 B, else 8 B)
-__device__ __host__ __forceinline__ u32 bucket_units(u32 compact) { return 8u << compact; }
-__device__ __host__ __forceinline__ u32 bucket_inline_max(u32 compact) { return 7u << compact; }
+__device__ __forceinline__ uint4 bucket_head(const DbDev& db, u32 idx) { return db.slots[(u64)idx << db.bsh]; }
 __device__ __forceinline__ void bucket_list(const DbDev& db, u32 idx, const uint4& sl, u64& off, u32& len) {
     len = sl.y;
-    off = len <= bucket_inline_max(db.compact) ? (u64)idx * bucket_units(db.compact) + (1u << db.compact)
-                                                : (((u64)db.slot_mask + 1) << (3 + db.compact)) + (((u64)sl.w << 32) | sl.z);
+    off = len <= db.inl ? ((u64)idx << (db.bsh + 1 + db.compact)) + db.inl_first          // 16 B = 2 wide / 4 compact locations
+                        : db.ext0 + (((u64)sl.w << 32) | sl.z);
 }
 __device__ __forceinline__ void probe(const DbDev& db, u32 f, u64& off, u32& len) {
     len = 0; off = 0;
@@ -805,14 +862,13 @@ __device__ __forceinline__ void bitonic_sort_block(KeyT* buf, u32 n2p, u32 npad,
 // search: hits(j) = j - lower_bound(tgt, win_j - numWindows + 1) + 1.  The run's best is
 // the maximum of (hits, -j): folded with an LDS atomic max into H[first entry of the run].
 //   H[j0] = (hits << JB) | (JMASK - jbest) for run heads, 0 elsewhere.
-template <class KeyT, class HT, int JB, class Sync>
-__device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32 numWindows, u32 wb, u32 tid, u32 G,
+template <class KeyT, class HT, int JB, class LF, class Sync>
+__device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32 numWindows, const LF& lf, u32 tid, u32 G,
                                               u32* s_w /* G / 64 + 1 words of LDS */, Sync sync) {
     // The head of an entry's run: last run start at or before it -- a ballot of run starts inside the wave, the last
     // start of the earlier waves through s_w, of the earlier chunks through s_w[nwv] (all as index + 1, 0 = none).
     // The lower bound is then searched inside [head, j] only: runs are a few entries long.
     const HT JMASK = ((HT)1 << JB) - 1;
-    const KeyT winmask = (((KeyT)1) << wb) - 1;
     const u32 lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = G >> 6;
     for (u32 j = tid; j < T; j += G) H[j] = 0;
     if (tid == 0) s_w[nwv] = 0;
@@ -822,7 +878,8 @@ __device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32
         const bool valid = j < T;
         const KeyT key = buf[valid ? j : T - 1];
         const KeyT prev = buf[(valid && j > 0) ? j - 1 : 0];
-        const bool head = valid && (j == 0 || (prev >> wb) != (key >> wb));
+        const KeyT tb = lf.tbeg(key);
+        const bool head = valid && (j == 0 || prev < tb);
         const u64 hb = __ballot(head);
         const u32 wbase = base + wv * 64;
         const u32 mylast = hb ? wbase + (63u - (u32)__builtin_clzll(hb)) + 1 : 0u;
@@ -832,8 +889,7 @@ __device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32
         for (u32 w = 0; w < wv; ++w) { const u32 x = s_w[w]; before = x ? x : before; }
         const u64 le = hb & ((2ull << lane) - 1);
         const u32 myhead = le ? wbase + (63u - (u32)__builtin_clzll(le)) : before - 1;
-        const u32 win = (u32)(key & winmask);
-        const KeyT lowkey = (key & ~winmask) | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+        const KeyT lowkey = range_low<KeyT>(key, tb, numWindows);
         u32 lo = myhead, hi = valid ? j : myhead;
         while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
         if (valid) atomicMax(&H[myhead], ((HT)(j - lo + 1) << JB) | (JMASK - (HT)j));
@@ -846,9 +902,8 @@ __device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32
 // Wave version (T <= 2^JB, packed into u32): the head of an entry's run comes
 // from a ballot of run starts in its 64-chunk (carried across chunks), and the single
 // binary search is confined to [head, j].
-template <class KeyT, int JB = 9>
-__device__ __forceinline__ void sweep_targets_wave(const KeyT* buf, u32* H, u32 T, u32 numWindows, u32 wb, u32 lane) {
-    const KeyT winmask = (((KeyT)1) << wb) - 1;
+template <class KeyT, int JB = 9, class LF>
+__device__ __forceinline__ void sweep_targets_wave(const KeyT* buf, u32* H, u32 T, u32 numWindows, const LF& lf, u32 lane) {
     for (u32 j = lane; j < T; j += 64) H[j] = 0;
     wave_sync();
     u32 carry_head = 0;
@@ -857,11 +912,11 @@ __device__ __forceinline__ void sweep_targets_wave(const KeyT* buf, u32* H, u32 
         const bool valid = j < T;
         const KeyT key = buf[valid ? j : T - 1];
         const KeyT prev = buf[(valid && j > 0) ? j - 1 : 0];
-        const bool head = valid && (j == 0 || (prev >> wb) != (key >> wb));
+        const KeyT tb = lf.tbeg(key);
+        const bool head = valid && (j == 0 || prev < tb);
         const u64 le = __ballot(head) & ((2ull << lane) - 1);
         const u32 myhead = le ? base + (63u - (u32)__builtin_clzll(le)) : carry_head;
-        const u32 win = (u32)(key & winmask);
-        const KeyT lowkey = (key & ~winmask) | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+        const KeyT lowkey = range_low<KeyT>(key, tb, numWindows);
         u32 lo = myhead, hi = valid ? j : myhead;
         while (lo < hi) { u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
         if (valid) atomicMax(&H[myhead], ((j - lo + 1) << JB) | (((1u << JB) - 1) - j));
@@ -900,9 +955,9 @@ __device__ __forceinline__ u32 wave_incl_max_dpp(u32 v) {
 // first range reaching the maximum ends at the same key as in the multiset sweep (the maximum over
 // the copies of one key is at its last copy; earlier keys still win ties).  Entry indices are now
 // indices of distinct keys: a monotone relabelling, so every later tie-break is unchanged.
+template <class LF>
 __device__ __forceinline__ void sweep_targets_weighted(const u32* SK, const u32* WP, u32* H, u32 D, u32 numWindows,
-                                                       u32 wb, u32 lane) {
-    const u32 winmask = (1u << wb) - 1;
+                                                       const LF& lf, u32 lane) {
     for (u32 j = lane; j < D; j += 64) H[j] = 0;
     wave_sync();
     u32 carry_head = 0;
@@ -911,11 +966,11 @@ __device__ __forceinline__ void sweep_targets_weighted(const u32* SK, const u32*
         const bool valid = j < D;
         const u32 key = SK[valid ? j : D - 1];
         const u32 prev = SK[(valid && j > 0) ? j - 1 : 0];
-        const bool head = valid && (j == 0 || (prev >> wb) != (key >> wb));
+        const u32 tb = lf.tbeg(key);
+        const bool head = valid && (j == 0 || prev < tb);
         const u64 le = __ballot(head) & ((2ull << lane) - 1);
         const u32 myhead = le ? base + (63u - (u32)__builtin_clzll(le)) : carry_head;
-        const u32 win = key & winmask;
-        const u32 lowkey = (key & ~winmask) | ((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+        const u32 lowkey = range_low<u32>(key, tb, numWindows);
         u32 lo = myhead, hi = valid ? j : myhead;
         while (lo < hi) { u32 mid = (lo + hi) >> 1; if (SK[mid] < lowkey) lo = mid + 1; else hi = mid; }
         if (valid) {
@@ -931,18 +986,18 @@ __device__ __forceinline__ void sweep_targets_weighted(const u32* SK, const u32*
 // multiplicity sums) and a narrow window range: distinct keys of one target have distinct windows, so the range
 // ending at an entry reaches back over at most numWindows - 1 predecessors -- checked with wave_shr:1 shifts
 // instead of a binary search through LDS.  numWindows <= 8.
-__device__ __forceinline__ void sweep_targets_regs(u32 k, u32 incl, u32* H, u32 D, u32 numWindows, u32 wb, u32 lane) {
-    const u32 winmask = (1u << wb) - 1;
+template <class LF>
+__device__ __forceinline__ void sweep_targets_regs(u32 k, u32 incl, u32* H, u32 D, u32 numWindows, const LF& lf, u32 lane) {
     H[lane] = 0;
     wave_sync();
     const bool valid = lane < D;
     asm("s_nop 1" : "+v"(k));                     // k may come straight out of an asm sort block (DPP read hazard)
     const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)k, 0x138, 0xF, 0xF, false);      // wave_shr:1
-    const bool head = valid && (lane == 0 || (prev >> wb) != (k >> wb));
+    const u32 tb = lf.tbeg(valid ? k : bcast(k, 0));      // (padding lanes look up a real word)
+    const bool head = valid && (lane == 0 || prev < tb);
     const u64 le = __ballot(head) & ((2ull << lane) - 1);
     const u32 myhead = le ? 63u - (u32)__builtin_clzll(le) : 0u;
-    const u32 win = k & winmask;
-    const u32 lowkey = (k & ~winmask) | ((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+    const u32 lowkey = range_low<u32>(k, tb, numWindows);
     u32 cnt = 0, kk = k;
     bool ok = valid;
     for (u32 i = 1; i < numWindows; ++i) {
@@ -957,17 +1012,16 @@ __device__ __forceinline__ void sweep_targets_regs(u32 k, u32 incl, u32* H, u32 
 }
 
 // window range [beg,end] of the best candidate whose packed word is hv (run head j0 irrelevant)
-template <class KeyT, class HT, int JB>
-__device__ __forceinline__ void best_range(const KeyT* buf, HT hv, u32 numWindows, u32 wb, u32& beg, u32& end) {
+template <class KeyT, class HT, int JB, class LF>
+__device__ __forceinline__ void best_range(const KeyT* buf, HT hv, u32 numWindows, const LF& lf, u32& beg, u32& end) {
     const HT JMASK = ((HT)1 << JB) - 1;
-    const KeyT winmask = (((KeyT)1) << wb) - 1;
     const u32 j = (u32)(JMASK - (hv & JMASK));
     const KeyT key = buf[j];
-    const u32 win = (u32)(key & winmask);
-    const KeyT lowkey = (key & ~winmask) | (KeyT)((u64)win + 1 > numWindows ? win + 1 - numWindows : 0u);
+    const KeyT tb = lf.tbeg(key);
+    const KeyT lowkey = range_low<KeyT>(key, tb, numWindows);
     u32 lo = 0, hi = j;
     while (lo < hi) { u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
-    beg = (u32)(buf[lo] & winmask); end = win;
+    beg = (u32)(buf[lo] - tb); end = (u32)(key - tb);
 }
 
 // ------------------------------------------------------------------ rows 10-11: top lists in lanes
@@ -1004,9 +1058,9 @@ __device__ __forceinline__ u64 wave_max(u64 v) {
     return v;
 }
 
-template <class KeyT, class HT, int JB>
+template <class KeyT, class HT, int JB, class LF>
 __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& opt, const OutDev& out,
-                                               const KeyT* buf, HT* H, u32 T, u32 numWindows, u32 wb,
+                                               const KeyT* buf, HT* H, u32 T, u32 numWindows, const LF& lf,
                                                u64 q, u32 lane) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
@@ -1031,7 +1085,7 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
         const u32 k = base + lane;
         HT cv = (k < nheads) ? H[k] : 0;
         const u32 jb = (u32)(JMASK - (cv & JMASK));
-        const u32 tgt = (u32)(buf[cv ? jb : 0] >> wb);
+        const u32 tgt = lf.tgt(buf[cv ? jb : 0]);
         u32 ctax = MCQ_EMPTY;
         if (cv != 0 && tgt < db.n_targets) ctax = db.tgt2tax[tgt];
         if (ctax == MCQ_EMPTY) cv = 0;
@@ -1079,7 +1133,7 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
     const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lhv != 0));
     if (lane < n) {
         u32 beg = 0, end = 0;
-        if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, wb, beg, end);
+        if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, lf, beg, end);
         uint4 v; v.x = Ltax; v.y = (u32)(Lhv >> JB); v.z = beg; v.w = end;
         u32 ln = lane;
         asm volatile("" : "+v"(ln));               // keeps (cands + 16 * lane) from being hoisted out of the query loop and spilled
@@ -1093,9 +1147,9 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
 // final write of list 0: one round of the tree at a time -- its edges touch disjoint ranks, so every receiver
 // selects from receiver-list ++ sender-list in the same M rounds (positions decide ties).  One wave; mx, wt:
 // 64 words of LDS each.
-template <class KeyT, class HT, int JB>
+template <class KeyT, class HT, int JB, class LF>
 __device__ __forceinline__ u32 fold_lists_write(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* buf,
-                                                u32 Ltax, HT Lhv, u32 numWindows, u32 wb, u64 q, u32 lane, u32* mx, u32* wt) {
+                                                u32 Ltax, HT Lhv, u32 numWindows, const LF& lf, u64 q, u32 lane, u32* mx, u32* wt) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const u32 rl = lane / seg, li = lane - rl * seg;
     const bool lslot = (li < M) && (rl < P);
@@ -1137,7 +1191,7 @@ __device__ __forceinline__ u32 fold_lists_write(const DbDev& db, const OptDev& o
     const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lhv != 0));
     if (lane < n) {
         u32 beg = 0, end = 0;
-        if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, wb, beg, end);
+        if (P == 1) best_range<KeyT, HT, JB>(buf, Lhv, numWindows, lf, beg, end);
         uint4 v; v.x = Ltax; v.y = (u32)(Lhv >> JB); v.z = beg; v.w = end;
         u32 ln = lane;
         asm volatile("" : "+v"(ln));               // keeps (cands + 16 * lane) from being hoisted out of the query loop and spilled
@@ -1152,9 +1206,9 @@ __device__ __forceinline__ u32 fold_lists_write(const DbDev& db, const OptDev& o
 // round is one ds_max per candidate into the word of its rank instead of a DPP reduction per rank: all P
 // ranks advance in the same round (M rounds per 64 candidates instead of P x M), and a round costs a dozen
 // VALU instructions.  scr: 128 words of this wave's LDS segment (scr[0..64) maxima, scr[64..128) winner taxa).
-template <int JB = 9>
+template <int JB = 9, class LF>
 __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev& opt, const OutDev& out,
-                                                   const u32* buf, u32* H, u32 T, u32 numWindows, u32 wb,
+                                                   const u32* buf, u32* H, u32 T, u32 numWindows, const LF& lf,
                                                    u64 q, u32 lane, u32* scr) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
@@ -1180,7 +1234,7 @@ __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev
         const u32 k = base + lane;
         u32 cv = (k < nheads) ? H[k] : 0;
         const u32 jb = JMASK - (cv & JMASK);
-        const u32 tgt = buf[cv ? jb : 0] >> wb;
+        const u32 tgt = lf.tgt(buf[cv ? jb : 0]);
         u32 ctax = MCQ_EMPTY;
         if (cv != 0 && tgt < db.n_targets) ctax = db.tgt2tax[tgt];
         if (ctax == MCQ_EMPTY) cv = 0;
@@ -1206,7 +1260,7 @@ __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev
         Ltax = Ntax; Lhv = Nhv;
     }
 
-    return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, wb, q, lane, mx, wt);
+    return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, lf, q, lane, mx, wt);
 }
 
 // ---- rows 10-11, all run heads at once (raw-sort paths: several hundred heads) -------------------------
@@ -1215,9 +1269,9 @@ __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev
 // into the word of its rank, the winners publish their taxa, every candidate of a winning taxon retires.  The
 // closed form is the same (first M distinct taxa by hits descending, position ascending); the taxon keys of all
 // heads are loaded in one go.  scr: 128 words of LDS.
-template <int JB, int NC>
+template <int JB, int NC, class LF>
 __device__ __forceinline__ u32 topk_all_lds(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* buf,
-                                            const u32* H, u32 nheads, u32 numWindows, u32 wb, u64 q, u32 lane, u32* scr) {
+                                            const u32* H, u32 nheads, u32 numWindows, const LF& lf, u64 q, u32 lane, u32* scr) {
     static_assert(JB <= 10, "hits << JB stays below bit 26");
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
@@ -1230,7 +1284,7 @@ __device__ __forceinline__ u32 topk_all_lds(const DbDev& db, const OptDev& opt, 
         if ((u32)(c * 64) >= nheads) continue;               // wave-uniform
         const u32 k = c * 64 + lane;
         const u32 v = (k < nheads) ? H[k] : 0;
-        const u32 tgt = buf[v ? JMASK - (v & JMASK) : 0] >> wb;
+        const u32 tgt = lf.tgt(buf[v ? JMASK - (v & JMASK) : 0]);
         if (v != 0 && tgt < db.n_targets) ctax[c] = db.tgt2tax[tgt];
         const u32 cr = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
         cv[c] = v | (cr << 26);
@@ -1256,7 +1310,7 @@ __device__ __forceinline__ u32 topk_all_lds(const DbDev& db, const OptDev& opt, 
         for (int c = 0; c < NC; ++c) if (cv[c] != 0 && ctax[c] == wt[cv[c] >> 26]) cv[c] = 0;
         wave_sync();
     }
-    return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, wb, q, lane, mx, wt);
+    return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, lf, q, lane, mx, wt);
 }
 
 // ---- rows 10-11 for the workgroup kernels ----------------------------------------------------------
@@ -1313,9 +1367,9 @@ __device__ __forceinline__ u32 fold_lists_block(const OptDev& opt, const OutDev&
 }
 
 // BIG (a separate instantiation of the workgroup kernels, so that the usual one carries none of it): OptDev::big
-template <class KeyT, class HT, int JB, bool BIG, class Sync>
+template <class KeyT, class HT, int JB, bool BIG, class LF, class Sync>
 __device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* B, HT* H,
-                                          u32 T, u32 numWindows, u32 wb, u64 q, u32 tid, u32 NTB,
+                                          u32 T, u32 numWindows, const LF& lf, u64 q, u32 tid, u32 NTB,
                                           TopkBlockScratch<HT>* scr, u32* bl, Sync sync) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
@@ -1328,7 +1382,7 @@ __device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, co
         for (u32 j = tid; j < T; j += NTB) {
             const HT v = H[j];
             if (v == 0) continue;
-            const u32 tgt = (u32)(B[j] >> wb);
+            const u32 tgt = lf.tgt(B[j]);
             const u32 tax = tgt < db.n_targets ? db.tgt2tax[tgt] : MCQ_EMPTY;
             if (tax == MCQ_EMPTY) { H[j] = 0; continue; }
             const u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
@@ -1338,7 +1392,7 @@ __device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, co
         for (u32 j = tid; j < T; j += NTB) {
             const HT v = H[j];
             if (v == 0) continue;
-            const u32 tgt = (u32)(B[j] >> wb);
+            const u32 tgt = lf.tgt(B[j]);
             const u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
             if (v == scr->mx[r]) scr->wt[r] = db.tgt2tax[tgt];       // packed words are unique: one winner per rank
         }
@@ -1346,7 +1400,7 @@ __device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, co
         for (u32 j = tid; j < T; j += NTB) {
             const HT v = H[j];
             if (v == 0) continue;
-            const u32 tgt = (u32)(B[j] >> wb);
+            const u32 tgt = lf.tgt(B[j]);
             const u32 r = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
             if (db.tgt2tax[tgt] == scr->wt[r]) H[j] = 0;            // every head of the winner's taxon retires
         }
@@ -1358,7 +1412,7 @@ __device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, co
     }
     if constexpr (big) return fold_lists_block(opt, out, bl, q, tid, NTB, sync);
     u32 n = 0;
-    if (tid < 64) n = fold_lists_write<KeyT, HT, JB>(db, opt, out, B, scr->ltax[tid], scr->lhv[tid], numWindows, wb, q, tid, scr->fmx, scr->fwt);
+    if (tid < 64) n = fold_lists_write<KeyT, HT, JB>(db, opt, out, B, scr->ltax[tid], scr->lhv[tid], numWindows, lf, q, tid, scr->fmx, scr->fwt);
     return n;
 }
 

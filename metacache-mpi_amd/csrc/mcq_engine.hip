@@ -67,7 +67,10 @@ struct mcq_db {
     u64 n_keys_local, n_locs_local;
     uint4* slots;             // one allocation: the buckets, then the lists too long for a bucket
     u32* tgt2tax;
+    u32* gw_off; u32* gw_blk; // global-window form: first window of every target, block -> target (see LocGW)
     u32 n_shards, shard_id;
+    u32 bucket_bytes, slots_per_key;
+    u64 n_ext, n_windows;
     u64 bytes;
 };
 
@@ -119,27 +122,34 @@ __global__ void k_fill_slots(uint4* slots, u64 n_uint4) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_uint4; i += stride) slots[i] = make_uint4(MCQ_EMPTY, 0, 0, 0);
 }
 
-// one thread per key: claim a bucket with CAS on the key word, then fill it: length, and either the list itself
-// (up to 14 compact / 7 wide locations) or the offset of the list among the long ones (ext_off)
+// location (tgt << 32) | win of the public form -> the handle's native word: bit fields (tgt << wb) | win, or, with gw_off, the
+// global window index gw_off[tgt] + win
 template <class KeyT>
-__global__ void k_insert_keys(uint4* slots, u32 mask, const u32* keys, const u64* list_off, const u64* own_len, const u64* ext_off,
-                              const u64* locs, u64 n_keys, u32 wb) {
+__device__ __forceinline__ KeyT loc_native(u64 l, u32 wb, const u32* __restrict__ gw_off) {
+    if (sizeof(KeyT) == 4 && gw_off) return (KeyT)(gw_off[(u32)(l >> 32)] + (u32)l);
+    return (KeyT)(((l >> 32) << wb) | (l & 0xFFFFFFFFull));
+}
+// one thread per key: claim a bucket with CAS on the key word, then fill it: length, and either the list itself
+// (64-B buckets: up to 14 compact / 7 wide locations) or the offset of the list among the long ones (ext_off).
+// bq = uint4 per bucket (4 or 1); inl = longest inline list (0 with 16-B slots)
+template <class KeyT>
+__global__ void k_insert_keys(uint4* slots, u32 mask, u32 bq, u32 inl, const u32* keys, const u64* list_off, const u64* own_len, const u64* ext_off,
+                              const u64* locs, u64 n_keys, u32 wb, const u32* gw_off) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_keys) return;
     const u32 len = (u32)own_len[i];
     if (len == 0) return;                                 // foreign or empty
     const u32 key = keys[i];
-    constexpr u32 INL = (MCQ_BUCKET_BYTES - 8) / sizeof(KeyT);
     u32 idx = tmh(key) & mask;
     while (true) {
-        u32* w = reinterpret_cast<u32*>(&slots[(u64)idx * (MCQ_BUCKET_BYTES / 16)]);
+        u32* w = reinterpret_cast<u32*>(&slots[(u64)idx * bq]);
         const u32 prev = atomicCAS(w, MCQ_EMPTY, key);
         if (prev == MCQ_EMPTY) {
             w[1] = len;
-            if (len <= INL) {
+            if (len <= inl) {
                 KeyT* dst = reinterpret_cast<KeyT*>(w + 2);
                 const u64 src = list_off[i];
-                for (u32 t = 0; t < len; ++t) { const u64 l = locs[src + t]; dst[t] = (KeyT)(((l >> 32) << wb) | (l & 0xFFFFFFFFull)); }
+                for (u32 t = 0; t < len; ++t) dst[t] = loc_native<KeyT>(locs[src + t], wb, gw_off);
             } else { const u64 b = ext_off[i]; w[2] = (u32)b; w[3] = (u32)(b >> 32); }
             return;
         }
@@ -154,22 +164,56 @@ __global__ void k_owned_len(const u32* keys, const u64* list_off, u64 n_keys, u3
     u32 own = (u32)(((u64)tmh(keys[i]) * n_shards) >> 32);
     const u64 len = (own == shard_id) ? (list_off[i + 1] - list_off[i]) : 0;
     out_len[i] = len;
-    ext_len[i] = len > inline_max ? len : 0;
+    if (ext_len) ext_len[i] = len > inline_max ? len : 0;
+}
+// owned non-empty keys and owned locations of the whole key array (two u64 counters)
+__global__ void k_owned_totals(const u64* own_len, u64 n_keys, unsigned long long* totals) {
+    unsigned long long k = 0, l = 0;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride) { const u64 v = own_len[i]; k += v > 0; l += v; }
+    for (int d = 32; d > 0; d >>= 1) { k += __shfl_xor(k, d, 64); l += __shfl_xor(l, d, 64); }
+    if ((threadIdx.x & 63) == 0 && l) { atomicAdd(&totals[0], k); atomicAdd(&totals[1], l); }
+}
+__global__ void k_ext_len(const u64* own_len, u64 n_keys, u32 inline_max, u64* ext_len) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_keys) { const u64 len = own_len[i]; ext_len[i] = len > inline_max ? len : 0; }
 }
 
 // copy the owned long lists behind the buckets
 template <class KeyT>
-__global__ void k_copy_lists(const u64* list_off, const u64* ext_off, const u64* locs, KeyT* out, u64 n_keys, u32 wb) {
+__global__ void k_copy_lists(const u64* list_off, const u64* ext_off, const u64* locs, KeyT* out, u64 n_keys, u32 wb, const u32* gw_off) {
     // one wave per key, grid-stride (the grid is bounded: total threads must stay < 2^32)
     const u32 lane = threadIdx.x & 63;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 key = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; key < n_keys; key += nwaves) {
         u64 b = ext_off[key], n = ext_off[key + 1] - b, src = list_off[key];
-        for (u64 t = lane; t < n; t += 64) {
-            u64 l = locs[src + t];
-            out[b + t] = (KeyT)(((l >> 32) << wb) | (l & 0xFFFFFFFFull));
-        }
+        for (u64 t = lane; t < n; t += 64) out[b + t] = loc_native<KeyT>(locs[src + t], wb, gw_off);
     }
+}
+
+// ---- global-window form: extents of the targets, offsets, block table
+// ext[t] = 1 + largest window id of target t among the locations (a racy read first: the maximum only grows, and most
+// locations lose against it without an atomic)
+__global__ void k_tgt_extent(const u64* locs, u64 n, u32 n_targets, u32* ext) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 l = locs[i];
+        const u32 t = (u32)(l >> 32), w = (u32)l;
+        if (t < n_targets && w != 0xFFFFFFFFu && *reinterpret_cast<volatile const u32*>(&ext[t]) <= w) atomicMax(&ext[t], w + 1);
+    }
+}
+// gw_blk[b] = last target t with gw_off[t] <= b << shift (targets without windows are skipped)
+__global__ void k_gw_blocks(const u32* gw_off, u32 n_targets, u32 shift, u64 n_blk, u32* blk) {
+    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blk) return;
+    const u64 w = b << shift;
+    u32 lo = 0, hi = n_targets ? n_targets - 1 : 0;
+    while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if ((u64)gw_off[mid] <= w) lo = mid; else hi = mid - 1; }
+    blk[b] = lo;
+}
+__global__ void k_u64_to_u32(const u64* in, u32* out, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (u32)in[i];
 }
 
 // largest window id over all locations (decides whether locations fit 32 bits)
@@ -248,9 +292,10 @@ __device__ __forceinline__ u32 pow2ceil(u32 x) { return x <= 1 ? 1u : 1u << (32 
 
 template <class KeyT> __device__ __forceinline__ KeyT key_pad() { return ~(KeyT)0; }
 // location word -> the public (tgt << 32) | win form
-template <class KeyT> __device__ __forceinline__ u64 key_expand(KeyT k, u32 wb) {
-    const KeyT winmask = (((KeyT)1) << wb) - 1;
-    return ((u64)(k >> wb) << 32) | (u64)(k & winmask);
+template <class KeyT, class LF> __device__ __forceinline__ u64 key_expand(KeyT k, const LF& lf) {
+    u32 t; KeyT tb;
+    lf.locate(k, t, tb);
+    return ((u64)t << 32) | (u64)(k - tb);
 }
 
 // Gather E*64 list elements into registers: r[e] = element e*64 + lane of the concatenated lists.
@@ -344,13 +389,14 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 #define MCQ_DEDUP_MAX_D 256u
 #endif
 #ifdef MCQ_TOPK_DPP        // tuning knob: DPP reductions per rank instead of LDS maxima for all ranks at once
-#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_fold_write<u32, u32, 9>(db, opt, out, sk, h, D, nw, wb, q, lane)
+#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, lf, q, lane) topk_fold_write<u32, u32, 9>(db, opt, out, sk, h, D, nw, lf, q, lane)
 #else
-#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, wb, q, lane) topk_dedup(db, opt, out, sk, h, D, nw, wb, q, lane)
+#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, lf, q, lane) topk_dedup(db, opt, out, sk, h, D, nw, lf, q, lane)
 #endif
 // top lists of the dedup path: more than 64 distinct keys (two to four rounds of 64 run heads) take all heads at once
+template <class LF>
 __device__ __forceinline__ u32 topk_dedup(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* sk, u32* H, u32 D,
-                                          u32 numWindows, u32 wb, u64 q, u32 lane) {
+                                          u32 numWindows, const LF& lf, u64 q, u32 lane) {
 #ifndef MCQ_TOPK_DEDUP_CHUNKED                                      // tuning knob (A/B)
     if (D > 64) {
         u32 nheads = 0;
@@ -362,10 +408,10 @@ __device__ __forceinline__ u32 topk_dedup(const DbDev& db, const OptDev& opt, co
             nheads += (u32)__builtin_popcountll(hm);
         }
         wave_sync();
-        return topk_all_lds<9, 4>(db, opt, out, sk, H, nheads, numWindows, wb, q, lane, H + 256);
+        return topk_all_lds<9, 4>(db, opt, out, sk, H, nheads, numWindows, lf, q, lane, H + 256);
     }
 #endif
-    return topk_fold_write_lds(db, opt, out, sk, H, D, numWindows, wb, q, lane, H + 256);
+    return topk_fold_write_lds(db, opt, out, sk, H, D, numWindows, lf, q, lane, H + 256);
 }
 __device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 23; }
 __device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 256; }
@@ -522,9 +568,9 @@ __device__ __forceinline__ void window_span(const DbDev& db, const ReadGeom& g, 
 // leave the last 128 of the CAP hit words free, those serve the LDS maxima of topk_all_lds (up to CAP / 2 heads at
 // once, all virtual ranks in the same round) or topk_fold_write_lds (64 heads at a time), else the DPP reductions per
 // rank and 64 heads.
-template <int JB, int CAP>
+template <int JB, int CAP, class LF>
 __device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* buf, u32* hits,
-                                          u32 T, u32 numWindows, u64 q, u32 lane) {
+                                          u32 T, u32 numWindows, const LF& lf, u64 q, u32 lane) {
     u32 nheads = 0;
     for (u32 base = 0; base < T; base += 64) {                      // in place: writes trail reads
         const u32 j = base + lane;
@@ -537,11 +583,11 @@ __device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, co
 #ifndef MCQ_TOPK_CHUNKED                                            // tuning knob (A/B): M rounds per 64 heads only
     constexpr int NC = CAP / 128;                                   // register budget: 2 words per 64 heads
     if (nheads <= 64u * NC)
-        return topk_all_lds<JB, NC>(db, opt, out, buf, hits, nheads, numWindows, db.wb, q, lane, hits + (CAP - 128));
+        return topk_all_lds<JB, NC>(db, opt, out, buf, hits, nheads, numWindows, lf, q, lane, hits + (CAP - 128));
 #endif
     if (nheads <= (u32)CAP - 128u)
-        return topk_fold_write_lds<JB>(db, opt, out, buf, hits, nheads, numWindows, db.wb, q, lane, hits + (CAP - 128));
-    return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, nheads, numWindows, db.wb, q, lane);
+        return topk_fold_write_lds<JB>(db, opt, out, buf, hits, nheads, numWindows, lf, q, lane, hits + (CAP - 128));
+    return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, nheads, numWindows, lf, q, lane);
 }
 
 #ifndef MCQ_WAVE_OCC
@@ -549,24 +595,28 @@ __device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, co
 #endif
 // match-list tap of the wave kernels (TAP instantiations only: mcq_debug_matches): the sorted match list of a query
 // as rows 7-8 define it, written out from whichever form the path holds it in
-template <class KeyT>
-__device__ __forceinline__ void tap_sorted(const DebugDev& dbg, const KeyT* buf, u32 T, u32 wb, u64 q, u32 lane) {
-    for (u32 t = lane; t < T; t += 64) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(buf[t], wb);
+template <class KeyT, class LF>
+__device__ __forceinline__ void tap_sorted(const DebugDev& dbg, const KeyT* buf, u32 T, const LF& lf, u64 q, u32 lane) {
+    for (u32 t = lane; t < T; t += 64) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(buf[t], lf);
 }
 // ... from the distinct sorted keys SK[0..D) and the inclusive sums WP of their multiplicities
-__device__ __forceinline__ void tap_distinct(const DebugDev& dbg, const u32* SK, const u32* WP, u32 D, u32 wb, u64 q, u32 lane) {
+template <class LF>
+__device__ __forceinline__ void tap_distinct(const DebugDev& dbg, const u32* SK, const u32* WP, u32 D, const LF& lf, u64 q, u32 lane) {
     for (u32 j = lane; j < D; j += 64) {
-        const u64 v = key_expand<u32>(SK[j], wb);
+        const u64 v = key_expand<u32>(SK[j], lf);
         for (u32 c = j ? WP[j - 1] : 0u; c < WP[j]; ++c) dbg.matches[dbg.match_off[q] + c] = v;
     }
 }
 
 // SH (feature-sharded path, home rank): the same kernel, but the probe results of a query's feature slots come from the
 // exchange (shard_fetch) instead of sketch + probe, and db.locs is the received location buffer.
-template <class KeyT, int LCAP, bool TAP = false, bool SH = false>
+// GW: 32-bit locations in the global-window form (LocGW), else bit fields (LocShift)
+template <class KeyT, int LCAP, bool TAP = false, bool SH = false, bool GW = false>
 __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                     CountersDev* ctr, u32* ovf_list, int force_block, DebugDev dbg, ShardDev sh) {
     static_assert(LCAP == 512, "wave path: 8 keys per lane at most, entry index packed into 9 bits");
+    static_assert(!GW || sizeof(KeyT) == 4, "the global-window form is a 32-bit word");
+    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db);
     __shared__ KeyT s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
@@ -675,11 +725,11 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                 if (D != ~1u) D = dedup_finish(D, buf, hits, lane, k1, incl1);
                 if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
-                    if constexpr (TAP) { if (dbg.mode == 2) tap_distinct(dbg, dedup_sk(hits), dedup_wp(hits), D, db.wb, q, lane); }
-                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
-                    else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
+                    if constexpr (TAP) { if (dbg.mode == 2) tap_distinct(dbg, dedup_sk(hits), dedup_wp(hits), D, lf, q, lane); }
+                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
+                    else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
                     if (stop == 5) { if (buf[lane] == 0x12345u) out.ncand[q] = 1; wave_sync(); continue; }
-                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, q, lane);
+                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, q, lane);
                     wave_sync();
                     continue;
                 }
@@ -695,11 +745,11 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         else               gather_sort_store<KeyT, 8>(db, buf, hits, T, pos, len, off, lane, stop);
         wave_sync();
         if (stop == 3 || stop == 4) { if (buf[lane] == (KeyT)0x1234) out.ncand[q] = 1; continue; }
-        if constexpr (TAP) { if (dbg.mode == 2) tap_sorted<KeyT>(dbg, buf, T, db.wb, q, lane); }
-        sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
+        if constexpr (TAP) { if (dbg.mode == 2) tap_sorted<KeyT>(dbg, buf, T, lf, q, lane); }
+        sweep_targets_wave<KeyT>(buf, hits, T, numWindows, lf, lane);
         if (stop == 5) { if (hits[lane] == 0x12345u) out.ncand[q] = 1; continue; }
-        if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, q, lane);
-        else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, lf, q, lane);
+        else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
         wave_sync();
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, b.nq);
@@ -720,10 +770,11 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 #ifndef MCQ_WAVE16_OCC
 #define MCQ_WAVE16_OCC 4        // waves per SIMD it is compiled for: 5 fit the LDS, but then 10 VGPRs spill (+30 % time)
 #endif
-template <bool TAP = false, bool SH = false>
+template <bool TAP = false, bool SH = false, bool GW = false>
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                                       CountersDev* ctr, u32* ovf_list, DebugDev dbg, ShardDev sh) {
     constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
+    const typename LocOf<u32, GW>::type lf = loc_format<u32, GW>(db);
     __shared__ u32 s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
@@ -805,10 +856,10 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             else               D = gather2_dedup_insert<8>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
             D = dedup_finish(D, buf, hits, lane, k1, incl1);
             if (D != ~0u) {
-                if constexpr (TAP) { if (dbg.mode == 2) tap_distinct(dbg, dedup_sk(hits), dedup_wp(hits), D, db.wb, q, lane); }
-                if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, buf, D, numWindows, db.wb, lane);
-                else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, db.wb, lane);
-                st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), buf, D, numWindows, db.wb, q, lane);
+                if constexpr (TAP) { if (dbg.mode == 2) tap_distinct(dbg, dedup_sk(hits), dedup_wp(hits), D, lf, q, lane); }
+                if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, buf, D, numWindows, lf, lane);
+                else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, lf, lane);
+                st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), buf, D, numWindows, lf, q, lane);
                 wave_sync();
                 continue;
             }
@@ -822,9 +873,9 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             for (int e = 0; e < 16; ++e) buf[e * 64 + lane] = r[e];
         }
         wave_sync();
-        if constexpr (TAP) { if (dbg.mode == 2) tap_sorted<u32>(dbg, buf, T, db.wb, q, lane); }
-        sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
-        st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, q, lane);
+        if constexpr (TAP) { if (dbg.mode == 2) tap_sorted<u32>(dbg, buf, T, lf, q, lane); }
+        sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, lf, lane);
+        st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
         wave_sync();
     }
     if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
@@ -863,9 +914,9 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
 // Tail of the workgroup path: fill B[0..n2p) through `load(t)`, sort, sweep, top lists.
 // HT/JB: packed (hits << JB | index) word of the sweep: u32 with JB = 13 when the list fits the workgroup's LDS
 // (<= 8192 entries, hits <= 8192), u64 with JB = 32 in global scratch
-template <class KeyT, class HT, int JB, bool BIG, class Fill>
+template <class KeyT, class HT, int JB, bool BIG, class LF, class Fill>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
-                                           KeyT* B, HT* H, u32 T, u32 numWindows, u32 wb, u64 q, u32 tid,
+                                           KeyT* B, HT* H, u32 T, u32 numWindows, const LF& lf, u64 q, u32 tid,
                                            const DebugDev& dbg, u32* biglist, Fill fill) {
     const u32 n2p = pow2ceil(T), NTB = blockDim.x;
 #ifdef MCQ_SORT_PAD_FULL                                       // tuning knob (A/B): the whole power-of-two network
@@ -878,11 +929,11 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
     __syncthreads();
     bitonic_sort_block(B, n2p, npad, tid, NTB, [] { __syncthreads(); });
     if (dbg.mode == 2) {
-        for (u32 t = tid; t < T; t += NTB) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], wb);
+        for (u32 t = tid; t < T; t += NTB) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], lf);
     }
     __shared__ TopkBlockScratch<HT> s_topk;
-    sweep_targets<KeyT, HT, JB>(B, H, T, numWindows, wb, tid, NTB, s_topk.fmx, [] { __syncthreads(); });
-    const u32 n = topk_block<KeyT, HT, JB, BIG>(db, opt, out, B, H, T, numWindows, wb, q, tid, NTB, &s_topk, biglist, [] { __syncthreads(); });
+    sweep_targets<KeyT, HT, JB>(B, H, T, numWindows, lf, tid, NTB, s_topk.fmx, [] { __syncthreads(); });
+    const u32 n = topk_block<KeyT, HT, JB, BIG>(db, opt, out, B, H, T, numWindows, lf, q, tid, NTB, &s_topk, biglist, [] { __syncthreads(); });
     if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
     __syncthreads();
 }
@@ -891,10 +942,11 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
 // 32-bit keys: 8192 x (4 + 4) B = 64 KB of LDS and 64 VGPRs, so two 1024-thread workgroups share a CU -- the phases
 // of a query are serialised by workgroup barriers, and the second workgroup fills the gaps (+45 % on 8 kb reads;
 // <4096, 512> with four per CU is slower: 15 % of those reads then sort in global scratch).
-template <class KeyT, int LCAPB, int NT, bool BIG = false, bool SH = false>
+template <class KeyT, int LCAPB, int NT, bool BIG = false, bool SH = false, bool GW = false>
 __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                       CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg, ShardDev sh) {
     static_assert(LCAPB <= 8192, "packed sweep word: 13 index bits");
+    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db);
     constexpr u32 NW16 = NT / 64;
     __shared__ KeyT s_buf[LCAPB];
     __shared__ u32 s_hits[LCAPB];
@@ -1018,8 +1070,8 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             }
         };
         // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
-        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, s_biglist, fill);
-        else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, s_biglist, fill);
+        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
+        else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
     }
 }
 
@@ -1145,9 +1197,10 @@ __device__ __forceinline__ void load_sort_store(KeyT* buf, const KeyT* src, u32 
     for (int e = 0; e < E; ++e) buf[e * 64 + lane] = r[e];
 }
 
-template <class KeyT, int LCAP>
+template <class KeyT, int LCAP, bool GW = false>
 __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, u32* ovf_list,
                                                      u64 nq, const u64* loc_off, const KeyT* locs, const u32* query_len) {
+    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db);
     __shared__ KeyT s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
@@ -1183,9 +1236,9 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
                 else               D = load_dedup_insert<8>(src, buf, hits, T, lane);
                 D = dedup_finish(D, reinterpret_cast<u32*>(buf), hits, lane, k1, incl1);
                 if (D != ~0u) {
-                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
-                    else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, lane);
-                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, db.wb, q, lane);
+                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
+                    else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
+                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, q, lane);
                     wave_sync();
                     continue;
                 }
@@ -1197,9 +1250,9 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         else if (T <= 256) load_sort_store<KeyT, 4>(buf, locs + b0, T, lane);
         else               load_sort_store<KeyT, 8>(buf, locs + b0, T, lane);
         wave_sync();
-        sweep_targets_wave<KeyT>(buf, hits, T, numWindows, db.wb, lane);
-        if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, q, lane);
-        else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, db.wb, q, lane);
+        sweep_targets_wave<KeyT>(buf, hits, T, numWindows, lf, lane);
+        if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, lf, q, lane);
+        else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
         wave_sync();
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, nq);
@@ -1207,9 +1260,11 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
 }
 
 // second wave stage of the staged path (see k_query_wave16): 513..1024 locations, 16 keys per lane
+template <bool GW = false>
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
                                                                        u64 nq, const u64* loc_off, const u32* locs, const u32* query_len) {
     constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
+    const typename LocOf<u32, GW>::type lf = loc_format<u32, GW>(db);
     __shared__ u32 s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
@@ -1229,16 +1284,17 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db,
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         load_sort_store<u32, 16>(buf, locs + b0, T, lane);
         wave_sync();
-        sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, db.wb, lane);
-        st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, q, lane);
+        sweep_targets_wave<u32, JB>(buf, hits, T, numWindows, lf, lane);
+        st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
         wave_sync();
     }
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
 }
 
-template <class KeyT, int LCAPB, bool BIG = false>
+template <class KeyT, int LCAPB, bool BIG = false, bool GW = false>
 __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
                                                        ScratchDev sc, const u64* loc_off, const KeyT* locs, const u32* query_len) {
+    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db);
     __shared__ KeyT s_buf[LCAPB];
     __shared__ u32 s_hits[LCAPB];
     __shared__ u32 s_biglist[BIG ? 2 * MCQ_BIGLIST_MAX : 1];
@@ -1262,8 +1318,8 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         auto fill = [&](KeyT* B) { for (u32 t = tid; t < T; t += 1024) B[t] = locs[b0 + t]; };
         // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
-        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, db.wb, q, tid, dbg, s_biglist, fill);
-        else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, db.wb, q, tid, dbg, s_biglist, fill);
+        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
+        else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
     }
 }
 
@@ -1582,9 +1638,12 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
         d_keys = t_keys; d_off = t_off; d_locs = t_locs;
     }
 
-    // compact locations: (tgt << wb) | win in 32 bits when target and window ids fit
+    // ---- location format: 32-bit bit fields (tgt << wb) | win when target and window ids fit; else the 32-bit global
+    // window index (any table of fewer than 2^32 - 1 windows); else 64-bit words
     const u32 TB = 256;
-    u32 wb = 32, compact = 0;
+    u32 wb = 32, compact = 0, gw = 0;
+    u32 *d_gwoff = nullptr, *d_gwblk = nullptr; u32 gw_shift = 0; u64 n_windows = 0;
+    if ((desc->flags & MCQ_DB_LOCS_64) && (desc->flags & MCQ_DB_LOCS_GW)) return fail(MCQ_E_ARG, "MCQ_DB_LOCS_64 and MCQ_DB_LOCS_GW exclude each other");
     if (!(desc->flags & MCQ_DB_LOCS_64)) {
         u32* d_mw = nullptr; u32 maxwin = 0;
         HIPCHK(tmp.alloc((void**)&d_mw, 4));
@@ -1595,69 +1654,127 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
         u32 maxtgt = desc->n_targets ? desc->n_targets - 1 : 0;
         u32 tgtbits = 1; while (tgtbits < 32 && (maxtgt >> tgtbits)) ++tgtbits;
         if (desc->loc_win_bits > winbits) winbits = desc->loc_win_bits;
-        if (winbits + tgtbits <= 32 && winbits <= 31 &&
+        if (!(desc->flags & MCQ_DB_LOCS_GW) && winbits + tgtbits <= 32 && winbits <= 31 &&
             ((((u64)maxtgt << winbits) | maxwin) < 0xFFFFFFFFull)) { compact = 1; wb = winbits; }
+        else if (desc->n_targets) {
+            // global-window form: windows per target (given, or 1 + the largest window id among the locations), offsets
+            const u32 nt = desc->n_targets;
+            u32* d_ext = nullptr; u64* d_off64 = nullptr;
+            HIPCHK(tmp.alloc((void**)&d_ext, (u64)nt * 4));
+            HIPCHK(tmp.alloc((void**)&d_off64, ((u64)nt + 1) * 8));
+            if (desc->tgt_windows) HIPCHK(hipMemcpy(d_ext, desc->tgt_windows, (u64)nt * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+            else {
+                HIPCHK(hipMemset(d_ext, 0, (u64)nt * 4));
+                if (nl) hipLaunchKernelGGL(k_tgt_extent, dim3(2048), dim3(256), 0, 0, d_locs, nl, nt, d_ext);
+            }
+            { int rcs = device_exclusive_scan<u32>(d_ext, d_off64, nt, 0); if (rcs) return rcs; }
+            HIPCHK(hipMemcpy(&n_windows, d_off64 + nt, 8, hipMemcpyDeviceToHost));
+            if (n_windows < 0xFFFFFFFFull) {
+                compact = 1; gw = 1; wb = 0;
+                // block table: at most 2^18 entries (1 MB: stays in L2), at least 64 windows per block
+                gw_shift = 6; while ((n_windows >> gw_shift) > (1ull << 18)) ++gw_shift;
+                const u64 n_blk = (n_windows >> gw_shift) + 2;
+                HIPCHK(hipMalloc(&d_gwoff, ((u64)nt + 1) * 4));
+                hipLaunchKernelGGL(k_u64_to_u32, dim3((u32)((nt + 1 + TB - 1) / TB)), dim3(TB), 0, 0, (const u64*)d_off64, d_gwoff, (u64)nt + 1);
+                if (hipMalloc(&d_gwblk, n_blk * 4) != hipSuccess) { (void)hipFree(d_gwoff); return fail(MCQ_E_HIP, "hipMalloc of the window block table failed"); }
+                hipLaunchKernelGGL(k_gw_blocks, dim3((u32)((n_blk + TB - 1) / TB)), dim3(TB), 0, 0, (const u32*)d_gwoff, nt, gw_shift, n_blk, d_gwblk);
+            } else if (desc->flags & MCQ_DB_LOCS_GW) return fail(MCQ_E_UNSUPPORTED, "MCQ_DB_LOCS_GW: the table has 2^32 - 1 windows or more");
+        }
     }
     const u64 locsz = compact ? 4 : 8;
-
-    // owned list lengths; offsets of the lists that do not fit a bucket
-    u64 *d_len = nullptr, *d_ext = nullptr, *d_new = nullptr;
-    HIPCHK(tmp.alloc((void**)&d_len, std::max<u64>(1, nk) * 8));
-    HIPCHK(tmp.alloc((void**)&d_ext, std::max<u64>(1, nk) * 8));
-    HIPCHK(tmp.alloc((void**)&d_new, (nk + 1) * 8));
-    if (nk) hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id,
-                               bucket_inline_max(compact), d_len, d_ext);
-    { int rcs = device_exclusive_scan<u64>(d_ext, d_new, nk, 0); if (rcs) return rcs; }
-    u64 nl_ext = 0;
-    HIPCHK(hipMemcpy(&nl_ext, d_new + nk, 8, hipMemcpyDeviceToHost));
-    // owned non-empty keys (for the table size) and owned locations -- counted on the host from the lengths
-    u64 nk_local = 0, nl_local = 0;
-    {
-        std::vector<u64> h_len(nk);
-        if (nk) HIPCHK(hipMemcpy(h_len.data(), d_len, nk * 8, hipMemcpyDeviceToHost));
-        for (u64 i = 0; i < nk; ++i) { nk_local += h_len[i] > 0; nl_local += h_len[i]; }
-    }
-    // load factor <= 0.25 (43 % of a read's features are not in the table, and every step of a linear probe is a new
-    // 64-B sector) while the buckets stay below 48 GB, else <= 0.5; MCQ_SLOTS_PER_KEY overrides
-    u64 slots_per_key = (pow2ceil64(nk_local * 4) * MCQ_BUCKET_BYTES <= (48ull << 30)) ? 4 : 2;
-    if (const char* e = getenv("MCQ_SLOTS_PER_KEY")) slots_per_key = std::max<u64>(1, strtoull(e, nullptr, 10));   // tuning knob
-    const u64 nslots = std::max<u64>(1024, pow2ceil64(nk_local * slots_per_key));
-    if (nslots > (1ull << 32)) { return fail(MCQ_E_UNSUPPORTED, "table too large"); }
-
     mcq_db* db = new mcq_db();
     memset(db, 0, sizeof(*db));
     db->device = desc->device; db->n_shards = n_shards; db->shard_id = desc->shard_id;
-    db->n_keys_local = nk_local; db->n_locs_local = nl_local; db->nslots = nslots;
-    const u64 table_bytes = nslots * MCQ_BUCKET_BYTES + std::max<u64>(1, nl_ext) * locsz;
+    db->gw_off = d_gwoff; db->gw_blk = d_gwblk;           // (released by mcq_db_destroy from here on)
 #define DBCHK(expr) HIPCHK_OR(expr, (void)mcq_db_destroy(db))
-    DBCHK(hipMalloc(&db->slots, table_bytes));
+#define DBRC(expr) do { int rc_ = (expr); if (rc_) { (void)mcq_db_destroy(db); return rc_; } } while (0)
+
+    // owned list lengths, owned non-empty keys and locations
+    u64 *d_len = nullptr, *d_ext = nullptr, *d_new = nullptr; unsigned long long* d_tot = nullptr;
+    DBCHK(tmp.alloc((void**)&d_len, std::max<u64>(1, nk) * 8));
+    DBCHK(tmp.alloc((void**)&d_tot, 16));
+    DBCHK(hipMemset(d_tot, 0, 16));
+    if (nk) {
+        hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id, 0u, d_len, (u64*)nullptr);
+        hipLaunchKernelGGL(k_owned_totals, dim3(1024), dim3(TB), 0, 0, (const u64*)d_len, nk, d_tot);
+    }
+    unsigned long long tot[2] = {0, 0};
+    DBCHK(hipMemcpy(tot, d_tot, 16, hipMemcpyDeviceToHost));
+    const u64 nk_local = tot[0], nl_local = tot[1];
+
+    // ---- layout, per table.  64-B buckets hold a list of up to 14 (7) locations next to its key -- in the sector the
+    // probe has just brought in -- and pay with 64 B per slot; worth it while most lists are that short (2 Gbp: mean
+    // 2.9 locations per key).  On larger tables (>= 10 Gbp: mean >= 4.9) most lists sit behind the array anyway, and
+    // the r01 layout -- 16-B slots, every list behind them -- is 27-30 GB smaller and 1-3 % faster (profiles/r02_db_scale.txt).
+    u32 bucket_bytes = (nk_local == 0 || (double)nl_local / (double)nk_local <= 4.0) ? 64u : 16u;
+    if (desc->flags & MCQ_DB_SLOTS_16) bucket_bytes = 16;
+    if (desc->flags & MCQ_DB_BUCKETS_64) bucket_bytes = 64;
+    if (const char* e = getenv("MCQ_BUCKET_BYTES")) { const int v = atoi(e); if (v == 16 || v == 64) bucket_bytes = (u32)v; }   // tuning knob
+    const u32 inl = bucket_bytes == 64 ? (compact ? 14u : 7u) : 0u;
+    DBCHK(tmp.alloc((void**)&d_ext, std::max<u64>(1, nk) * 8));
+    DBCHK(tmp.alloc((void**)&d_new, (nk + 1) * 8));
+    if (nk) hipLaunchKernelGGL(k_ext_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, (const u64*)d_len, nk, inl, d_ext);
+    DBRC(device_exclusive_scan<u64>(d_ext, d_new, nk, 0));
+    u64 nl_ext = 0;
+    DBCHK(hipMemcpy(&nl_ext, d_new + nk, 8, hipMemcpyDeviceToHost));
+
+    // load factor <= 0.25 (43 % of a read's features are not in the table, and every step of a linear probe is a new
+    // sector) while the slot array stays below 48 GB and a third of the free memory, else <= 0.5 -- also when the
+    // allocation at 0.25 fails.  MCQ_SLOTS_PER_KEY overrides.
+    size_t mem_free = 0, mem_total = 0;
+    DBCHK(hipMemGetInfo(&mem_free, &mem_total));
+    const u64 ext_bytes = std::max<u64>(1, nl_ext) * locsz;
+    u64 slots_per_key = 4;
+    { const u64 b4 = pow2ceil64(nk_local * 4) * bucket_bytes; if (b4 > (48ull << 30) || b4 + ext_bytes > mem_free / 3) slots_per_key = 2; }
+    bool spk_forced = false;
+    if (const char* e = getenv("MCQ_SLOTS_PER_KEY")) { slots_per_key = std::max<u64>(1, strtoull(e, nullptr, 10)); spk_forced = true; }   // tuning knob
+    u64 nslots = 0, table_bytes = 0;
+    for (;;) {
+        nslots = std::max<u64>(1024, pow2ceil64(nk_local * slots_per_key));
+        if (nslots > (1ull << 32)) { (void)mcq_db_destroy(db); return fail(MCQ_E_UNSUPPORTED, "table too large"); }
+        table_bytes = nslots * bucket_bytes + ext_bytes;
+        const hipError_t e = hipMalloc(&db->slots, table_bytes);
+        if (e == hipSuccess) break;
+        (void)hipGetLastError();
+        db->slots = nullptr;
+        if (slots_per_key > 2 && !spk_forced) { slots_per_key = 2; continue; }
+        (void)mcq_db_destroy(db);
+        return fail(MCQ_E_HIP, std::string("hipMalloc of the table (") + std::to_string(table_bytes >> 20) + " MiB): " + hipGetErrorString(e));
+    }
+    db->n_keys_local = nk_local; db->n_locs_local = nl_local; db->nslots = nslots;
+    db->bucket_bytes = bucket_bytes; db->slots_per_key = (u32)slots_per_key; db->n_ext = nl_ext; db->n_windows = n_windows;
     DBCHK(hipMalloc(&db->tgt2tax, std::max<u32>(1, desc->n_targets) * 4));
     if (desc->n_targets)
         DBCHK(hipMemcpy(db->tgt2tax, desc->tgt2tax, (u64)desc->n_targets * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-    const u64 n_uint4 = nslots * (MCQ_BUCKET_BYTES / 16);
+    const u32 bq = bucket_bytes / 16;
+    const u64 n_uint4 = nslots * bq;
     hipLaunchKernelGGL(k_fill_slots, dim3((u32)std::min<u64>((n_uint4 + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, db->slots, n_uint4);
     if (nk) {
         const dim3 ig((u32)((nk + TB - 1) / TB));
-        if (compact) hipLaunchKernelGGL(k_insert_keys<u32>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), d_keys, d_off, (const u64*)d_len, (const u64*)d_new, d_locs, nk, wb);
-        else         hipLaunchKernelGGL(k_insert_keys<u64>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), d_keys, d_off, (const u64*)d_len, (const u64*)d_new, d_locs, nk, 32u);
+        if (compact) hipLaunchKernelGGL(k_insert_keys<u32>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), bq, inl, d_keys, d_off, (const u64*)d_len, (const u64*)d_new, d_locs, nk, wb, (const u32*)d_gwoff);
+        else         hipLaunchKernelGGL(k_insert_keys<u64>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), bq, inl, d_keys, d_off, (const u64*)d_len, (const u64*)d_new, d_locs, nk, 32u, (const u32*)nullptr);
         DBCHK(hipGetLastError());
-        char* ext = reinterpret_cast<char*>(db->slots) + nslots * MCQ_BUCKET_BYTES;
+        char* ext = reinterpret_cast<char*>(db->slots) + nslots * bucket_bytes;
         const dim3 cg((u32)std::min<u64>((nk * 64 + TB - 1) / TB, 1u << 20));
-        if (compact) hipLaunchKernelGGL(k_copy_lists<u32>, cg, dim3(TB), 0, 0, d_off, (const u64*)d_new, d_locs, (u32*)ext, nk, wb);
-        else         hipLaunchKernelGGL(k_copy_lists<u64>, cg, dim3(TB), 0, 0, d_off, (const u64*)d_new, d_locs, (u64*)ext, nk, 32u);
+        if (compact) hipLaunchKernelGGL(k_copy_lists<u32>, cg, dim3(TB), 0, 0, d_off, (const u64*)d_new, d_locs, (u32*)ext, nk, wb, (const u32*)d_gwoff);
+        else         hipLaunchKernelGGL(k_copy_lists<u64>, cg, dim3(TB), 0, 0, d_off, (const u64*)d_new, d_locs, (u64*)ext, nk, 32u, (const u32*)nullptr);
         DBCHK(hipGetLastError());
     }
     DBCHK(hipDeviceSynchronize());
 #undef DBCHK
+#undef DBRC
 
     db->d.slots = db->slots; db->d.slot_mask = (u32)(db->nslots - 1); db->d.locs = db->slots;
+    db->d.bsh = bucket_bytes == 64 ? 2u : 0u; db->d.inl = inl; db->d.inl_first = compact ? 2u : 1u;
+    db->d.ext0 = nslots * bucket_bytes / locsz;
     db->d.wb = wb; db->d.compact = compact;
+    db->d.gw = gw; db->d.gw_shift = gw_shift; db->d.gw_off = d_gwoff; db->d.gw_blk = d_gwblk;
     db->d.tgt2tax = db->tgt2tax; db->d.n_targets = desc->n_targets;
     db->d.k = desc->k; db->d.s = desc->sketch_size; db->d.winlen = desc->winlen; db->d.winstride = desc->winstride;
     db->d.tgt_winstride = desc->tgt_winstride ? desc->tgt_winstride : desc->winstride;
     db->d.magic_stride = (u32)std::min<u64>((1ull << 32) / db->d.winstride, 0xFFFFFFFFull);
     db->d.magic_tgt_stride = (u32)std::min<u64>((1ull << 32) / db->d.tgt_winstride, 0xFFFFFFFFull);
-    db->bytes = table_bytes + (u64)desc->n_targets * 4;
+    db->bytes = table_bytes + (u64)desc->n_targets * 4 + (gw ? ((u64)desc->n_targets + 1) * 4 + ((n_windows >> gw_shift) + 2) * 4 : 0);
     *out = db;
     return MCQ_OK;
 }
@@ -1665,7 +1782,7 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
 extern "C" int mcq_db_destroy(mcq_db* db) {
     if (!db) return MCQ_OK;
     (void)hipSetDevice(db->device);
-    (void)hipFree(db->slots); (void)hipFree(db->tgt2tax);
+    (void)hipFree(db->slots); (void)hipFree(db->tgt2tax); (void)hipFree(db->gw_off); (void)hipFree(db->gw_blk);
     delete db;
     return MCQ_OK;
 }
@@ -1694,10 +1811,12 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     if (const char* e = getenv("MCQ_BLOCK_WGS")) ws->n_block_wgs = std::max(1, atoi(e));      // tuning knob
     ws->ev_used = new std::vector<TimedLaunch>();
     ws->ev_free = new std::vector<TimedLaunch>();
-    ws->cap_wave = db->d.compact ? resident_blocks(k_query_wave<u32, 512, false, false>, 256, db->device)
-                                 : resident_blocks(k_query_wave<u64, 512, false, false>, 256, db->device);
-    ws->cap_wave16 = resident_blocks(k_query_wave16<false, false>, 256, db->device);
-    ws->cap_reduce16 = resident_blocks(k_reduce_wave16, 256, db->device);
+    ws->cap_wave = db->d.gw ? resident_blocks(k_query_wave<u32, 512, false, false, true>, 256, db->device)
+                 : db->d.compact ? resident_blocks(k_query_wave<u32, 512, false, false, false>, 256, db->device)
+                                 : resident_blocks(k_query_wave<u64, 512, false, false, false>, 256, db->device);
+    ws->cap_wave16 = db->d.gw ? resident_blocks(k_query_wave16<false, false, true>, 256, db->device)
+                              : resident_blocks(k_query_wave16<false, false, false>, 256, db->device);
+    ws->cap_reduce16 = db->d.gw ? resident_blocks(k_reduce_wave16<true>, 256, db->device) : resident_blocks(k_reduce_wave16<false>, 256, db->device);
     const u64 nb = (u64)ws->n_block_wgs;
 #define WSCHK(expr) HIPCHK_OR(expr, (void)mcq_ws_destroy(ws))
     WSCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
@@ -1853,24 +1972,33 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     LaunchTimer tm(ws, st);
     int rc = tm.begin(); if (rc) return rc;
     const bool tap = dbg.mode != 0;     // mcq_debug_matches: the instantiations that also write the sorted match lists
-#define MCQ_LAUNCH_WAVE(KT, TAPV, SHV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV, SHV>), dim3(grid), dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg, sh)
-    if (shp)                { if (db->d.compact) MCQ_LAUNCH_WAVE(u32, false, true); else MCQ_LAUNCH_WAVE(u64, false, true); }
-    else if (db->d.compact) { if (tap) MCQ_LAUNCH_WAVE(u32, true, false); else MCQ_LAUNCH_WAVE(u32, false, false); }
-    else                    { if (tap) MCQ_LAUNCH_WAVE(u64, true, false); else MCQ_LAUNCH_WAVE(u64, false, false); }
+    const bool gw = db->d.gw != 0;      // 32-bit locations in the global-window form: the GW instantiations
+#define MCQ_LAUNCH_WAVE(KT, TAPV, SHV, GWV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV, SHV, GWV>), dim3(grid), dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg, sh)
+#define MCQ_LAUNCH_WAVE32(TAPV, SHV) do { if (gw) MCQ_LAUNCH_WAVE(u32, TAPV, SHV, true); else MCQ_LAUNCH_WAVE(u32, TAPV, SHV, false); } while (0)
+    if (shp)                { if (db->d.compact) MCQ_LAUNCH_WAVE32(false, true); else MCQ_LAUNCH_WAVE(u64, false, true, false); }
+    else if (db->d.compact) { if (tap) MCQ_LAUNCH_WAVE32(true, false); else MCQ_LAUNCH_WAVE32(false, false); }
+    else                    { if (tap) MCQ_LAUNCH_WAVE(u64, true, false, false); else MCQ_LAUNCH_WAVE(u64, false, false, false); }
+#undef MCQ_LAUNCH_WAVE32
 #undef MCQ_LAUNCH_WAVE
     rc = tm.mark(); if (rc) return rc;
     if (db->d.compact) {   // second wave stage (back queue); no queue for 64-bit keys
         const dim3 g16(grid_for(ws->cap_wave16, want));
-        if (shp)      hipLaunchKernelGGL((k_query_wave16<false, true>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh);
-        else if (tap) hipLaunchKernelGGL((k_query_wave16<true, false>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh);
-        else          hipLaunchKernelGGL((k_query_wave16<false, false>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh);
+#define MCQ_LAUNCH_WAVE16(TAPV, SHV) do { \
+        if (gw) hipLaunchKernelGGL((k_query_wave16<TAPV, SHV, true>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh); \
+        else    hipLaunchKernelGGL((k_query_wave16<TAPV, SHV, false>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh); } while (0)
+        if (shp)      MCQ_LAUNCH_WAVE16(false, true);
+        else if (tap) MCQ_LAUNCH_WAVE16(true, false);
+        else          MCQ_LAUNCH_WAVE16(false, false);
+#undef MCQ_LAUNCH_WAVE16
     }
     rc = tm.mark(); if (rc) return rc;
-#define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV, SHV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV, SHV>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, D, b, od, o, ws->ctr, \
+#define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV, SHV, GWV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV, SHV, GWV>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, D, b, od, o, ws->ctr, \
                                                              (const u32*)ws->ovf_list, ws->sc, dbg, sh)
-#define MCQ_LAUNCH_BLOCK2(KT, LC, NTH, SHV) do { if (od.big) MCQ_LAUNCH_BLOCK(KT, LC, NTH, true, SHV); else MCQ_LAUNCH_BLOCK(KT, LC, NTH, false, SHV); } while (0)
-    if (db->d.compact) { if (shp) MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, true); else MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, false); }
-    else               { if (shp) MCQ_LAUNCH_BLOCK2(u64, kLcapBlock, 1024, true); else MCQ_LAUNCH_BLOCK2(u64, kLcapBlock, 1024, false); }
+#define MCQ_LAUNCH_BLOCK2(KT, LC, NTH, SHV, GWV) do { if (od.big) MCQ_LAUNCH_BLOCK(KT, LC, NTH, true, SHV, GWV); else MCQ_LAUNCH_BLOCK(KT, LC, NTH, false, SHV, GWV); } while (0)
+#define MCQ_LAUNCH_BLOCK32(SHV) do { if (gw) MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, SHV, true); else MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, SHV, false); } while (0)
+    if (db->d.compact) { if (shp) MCQ_LAUNCH_BLOCK32(true); else MCQ_LAUNCH_BLOCK32(false); }
+    else               { if (shp) MCQ_LAUNCH_BLOCK2(u64, kLcapBlock, 1024, true, false); else MCQ_LAUNCH_BLOCK2(u64, kLcapBlock, 1024, false, false); }
+#undef MCQ_LAUNCH_BLOCK32
 #undef MCQ_LAUNCH_BLOCK2
 #undef MCQ_LAUNCH_BLOCK
     rc = tm.end(); if (rc) return rc;
@@ -1997,7 +2125,9 @@ extern "C" int mcq_ws_wait(mcq_ws* ws, uint64_t ticket) {
     if (!ws || !ws->pipe.ready) return fail(MCQ_E_ARG, "no pipelined call on this workspace");
     auto& p = ws->pipe;
     if (ticket >= p.issued) return fail(MCQ_E_ARG, "unknown ticket");
-    if (ticket + 2 < p.issued) return MCQ_OK;              // a later call on the same staging set has already waited for it
+    // s_out is in order: the event of a later call on the same staging set is recorded behind this ticket's copy, so waiting
+    // for whatever was recorded last on it covers the ticket (a device-side hipStreamWaitEvent of a later call is NOT a
+    // host wait: the header promises that the results are in `out` when this returns)
     HIPCHK(hipSetDevice(ws->device));
     HIPCHK(hipEventSynchronize(p.ev_out[ticket & 1]));
     return MCQ_OK;
@@ -2103,6 +2233,17 @@ extern "C" int mcq_sketch(const mcq_db* db, const mcq_batch* in, const uint64_t*
 
 extern "C" uint32_t mcq_db_loc_bytes(const mcq_db* db) { return db && db->d.compact ? 4u : 8u; }
 extern "C" uint32_t mcq_db_win_bits(const mcq_db* db) { return db ? db->d.wb : 32u; }
+extern "C" int mcq_db_layout_get(const mcq_db* db, mcq_db_layout* out) {
+    if (!db || !out) return fail(MCQ_E_ARG, "null argument");
+    memset(out, 0, sizeof(*out));
+    out->loc_bytes = db->d.compact ? 4u : 8u;
+    out->loc_format = db->d.gw ? MCQ_LOC_GLOBAL_WINDOW : db->d.compact ? MCQ_LOC_FIELDS32 : MCQ_LOC_FIELDS64;
+    out->win_bits = db->d.wb; out->bucket_bytes = db->bucket_bytes; out->slots_per_key = db->slots_per_key;
+    out->n_slots = db->nslots; out->n_keys = db->n_keys_local; out->n_locs = db->n_locs_local; out->n_ext_locs = db->n_ext;
+    out->n_windows = db->n_windows; out->bytes = db->bytes;
+    out->gw_offsets = db->gw_off;
+    return MCQ_OK;
+}
 
 extern "C" int mcq_lookup_count(const mcq_db* db, const uint32_t* features, uint64_t n_features,
                                 uint32_t* list_len, uint64_t* list_src, void* stream) {
@@ -2177,17 +2318,19 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     const u32 grid = (u32)std::min<u64>((n_queries + 3) / 4, 256ull * 24);     // measured: 1.07 ms vs 1.25 ms at the resident 8 per CU
     LaunchTimer tm(ws, st);
     rc = tm.begin(); if (rc) return rc;
+#define MCQ_REDUCE32(GWV) do { \
+        hipLaunchKernelGGL((k_reduce_wave<u32, kLcapWave, GWV>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list, \
+                           n_queries, loc_off, (const u32*)locs, query_len); \
+        rc = tm.mark(); if (rc) return rc; \
+        hipLaunchKernelGGL(k_reduce_wave16<GWV>, dim3(grid_for(ws->cap_reduce16, (n_queries + 3) / 4)), dim3(256), 0, st, db->d, od, o, ws->ctr, \
+                           (const u32*)ws->ovf_list, n_queries, loc_off, (const u32*)locs, query_len); \
+        rc = tm.mark(); if (rc) return rc; \
+        if (od.big) hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, true, GWV>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr, \
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len); \
+        else        hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, false, GWV>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr, \
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len); } while (0)
     if (db->d.compact) {
-        hipLaunchKernelGGL((k_reduce_wave<u32, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
-                           n_queries, loc_off, (const u32*)locs, query_len);
-        rc = tm.mark(); if (rc) return rc;
-        hipLaunchKernelGGL(k_reduce_wave16, dim3(grid_for(ws->cap_reduce16, (n_queries + 3) / 4)), dim3(256), 0, st, db->d, od, o, ws->ctr,
-                           (const u32*)ws->ovf_list, n_queries, loc_off, (const u32*)locs, query_len);
-        rc = tm.mark(); if (rc) return rc;
-        if (od.big) hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, true>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
-                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len);
-        else        hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, false>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
-                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len);
+        if (db->d.gw) MCQ_REDUCE32(true); else MCQ_REDUCE32(false);
     } else {
         hipLaunchKernelGGL((k_reduce_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
                            n_queries, loc_off, (const u64*)locs, query_len);
@@ -2198,6 +2341,7 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
         else        hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, false>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
                                        (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
     }
+#undef MCQ_REDUCE32
     rc = tm.end(); if (rc) return rc;
     HIPCHK(hipGetLastError());
     return MCQ_OK;

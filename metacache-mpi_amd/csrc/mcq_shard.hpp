@@ -211,10 +211,16 @@ __global__ void k_shard_zero_headers(u32* blocks, u64 stride, u32 n_ranks) {
     const u32 i = threadIdx.x;
     if (i < n_ranks) for (u32 k = 0; k < MCQ_SHARD_HDR; ++k) blocks[(u64)i * stride + k] = 0;
 }
-// home side after X2: a peer that served more locations than a block carries has truncated this rank's lists
-__global__ void k_shard_check(const u32* recvR, u64 rblk, u32 n_ranks, u64 capLx, u32* err) {
+// home side after X2, in both modes: the reads that lose data belong to THIS rank, so the loss is flagged here and not only
+// on the owner that noticed it.  A peer that served more locations than the block that travelled carries (capLx: the padded
+// size, or the buffer's capacity in the exact mode) has truncated this rank's lists (bit 8); positions this rank handed
+// out beyond what a feature block carries (capFx; the header word is the cursor of its reservations) never reached their
+// owner (bit 2: the same test the owner makes on the header it received).
+__global__ void k_shard_check(const u32* recvR, u64 rblk, const u32* sendF, u64 fblk, u32 n_ranks, u64 capLx, u32 capFx, u32* err) {
     const u32 i = threadIdx.x;
-    if (i < n_ranks && (u64)recvR[(u64)i * rblk] > capLx) atomicOr(err, 8u);
+    if (i >= n_ranks) return;
+    if ((u64)recvR[(u64)i * rblk] > capLx) atomicOr(err, 8u);
+    if (sendF[(u64)i * fblk] > capFx) atomicOr(err, 2u);
 }
 
 // ------------------------------------------------------------------ transports
@@ -527,8 +533,10 @@ static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
         if (!alias) { rc = shard_exchange(c, b.sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = capLx * c->locb;
         if (!alias) { rc = shard_exchange(c, b.sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
-        hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(64), 0, st, (const u32*)recvR, rblk_words(c), n, capLx, err);
     }
+    // what this rank lost, flagged on this rank (exact mode: the buffers' capacities; padded mode: the sizes that travelled)
+    hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(64), 0, st, (const u32*)recvR, rblk_words(c), (const u32*)b.sendF, fblk_words(c), n,
+                       exact ? c->capL : capLx, exact ? c->capF : capFx, err);
     return MCQ_OK;
 }
 

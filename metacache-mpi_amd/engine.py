@@ -16,6 +16,10 @@ MCQ_BATCH_RANGES = 8             # seq_off = (begin,end) pairs into `bases` (dev
 MCQ_BATCH_PACKED = 0x10          # bases in the packed form of mcq_pack_bases (3 bits per base)
 MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-query path
 MCQ_DB_LOCS_64 = 0x200           # Database(flags=...): keep 64-bit locations
+MCQ_DB_LOCS_GW = 0x2000          # Database(flags=...): 32-bit locations in the global-window form
+MCQ_DB_SLOTS_16 = 0x4000         # Database(flags=...): 16-B slots, every list behind the slot array
+MCQ_DB_BUCKETS_64 = 0x8000       # Database(flags=...): 64-B buckets with inline lists
+MCQ_LOC_FIELDS64, MCQ_LOC_FIELDS32, MCQ_LOC_GLOBAL_WINDOW = 0, 1, 2
 MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000   # Table / Database.build: -remove-overpopulated-features
 MCQ_FORCE_RAW_SORT = 0x400       # debug: wave path without the de-duplicating pass
 MCQ_NO_WAVE16 = 0x800            # debug: 513..1024 locations take the workgroup path, not the second wave stage
@@ -34,7 +38,16 @@ class DbDesc(C.Structure):
                 ("tgt_winstride", C.c_uint32), ("n_targets", C.c_uint32), ("n_keys", C.c_uint64), ("n_locs", C.c_uint64),
                 ("keys", C.c_void_p), ("list_off", C.c_void_p), ("locs", C.c_void_p), ("tgt2tax", C.c_void_p),
                 ("n_shards", C.c_uint32), ("shard_id", C.c_uint32), ("flags", C.c_uint32), ("device", C.c_int32),
-                ("loc_win_bits", C.c_uint32)]
+                ("loc_win_bits", C.c_uint32), ("tgt_windows", C.c_void_p)]
+
+
+class DbLayout(C.Structure):
+    _fields_ = [("loc_bytes", C.c_uint32), ("loc_format", C.c_uint32), ("win_bits", C.c_uint32), ("bucket_bytes", C.c_uint32),
+                ("slots_per_key", C.c_uint32), ("n_slots", C.c_uint64), ("n_keys", C.c_uint64), ("n_locs", C.c_uint64),
+                ("n_ext_locs", C.c_uint64), ("n_windows", C.c_uint64), ("bytes", C.c_uint64), ("gw_offsets", C.c_void_p)]
+
+    def as_dict(self):
+        return {k: (getattr(self, k) or 0) for k, _ in self._fields_}
 
 
 class BuildDesc(C.Structure):
@@ -111,6 +124,7 @@ def lib():
         L.mcq_lookup_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_db_loc_bytes.restype = C.c_uint32; L.mcq_db_loc_bytes.argtypes = [C.c_void_p]
         L.mcq_db_win_bits.restype = C.c_uint32; L.mcq_db_win_bits.argtypes = [C.c_void_p]
+        L.mcq_db_layout_get.argtypes = [C.c_void_p, C.POINTER(DbLayout)]
         L.mcq_bucket_features.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mcq_assemble.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(Batch),
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -155,9 +169,10 @@ class Database:
     of the reference's sketch_database: built from the union of its shard tables."""
 
     def __init__(self, keys, list_off, locs, tgt2tax, k=16, sketch_size=16, winlen=128, winstride=113,
-                 tgt_winstride=0, n_shards=1, shard_id=0, device=0, device_ptrs=None, flags=0, loc_win_bits=0):
+                 tgt_winstride=0, n_shards=1, shard_id=0, device=0, device_ptrs=None, flags=0, loc_win_bits=0, tgt_windows=None):
         """keys/list_off/locs/tgt2tax: numpy arrays (host) -- or, with device_ptrs=dict(
-        keys=ptr, list_off=ptr, locs=ptr, tgt2tax=ptr, n_keys=, n_locs=, n_targets=), raw device pointers."""
+        keys=ptr, list_off=ptr, locs=ptr, tgt2tax=ptr, n_keys=, n_locs=, n_targets=[, tgt_windows=ptr]), raw device pointers.
+        tgt_windows (host: numpy u32 [n_targets]): windows per target for the global-window location form."""
         d = DbDesc()
         d.k, d.sketch_size, d.winlen, d.winstride, d.tgt_winstride = k, sketch_size, winlen, winstride, tgt_winstride
         d.n_shards, d.shard_id, d.device = n_shards, shard_id, device
@@ -169,11 +184,17 @@ class Database:
             assert len(oo) == len(kk) + 1
             d.n_keys, d.n_locs, d.n_targets = len(kk), len(ll), len(tt)
             d.keys, d.list_off, d.locs, d.tgt2tax = _np_ptr(kk), _np_ptr(oo), _np_ptr(ll), _np_ptr(tt)
+            if tgt_windows is not None:
+                tw = np.ascontiguousarray(tgt_windows, np.uint32)
+                assert len(tw) == len(tt)
+                self._keep = self._keep + (tw,)
+                d.tgt_windows = _np_ptr(tw)
             d.flags = flags
         else:
             p = device_ptrs
             d.n_keys, d.n_locs, d.n_targets = p["n_keys"], p["n_locs"], p["n_targets"]
             d.keys, d.list_off, d.locs, d.tgt2tax = p["keys"], p["list_off"], p["locs"], p["tgt2tax"]
+            d.tgt_windows = p.get("tgt_windows")
             d.flags = MCQ_DEVICE_PTRS | flags
         self.k, self.sketch_size, self.winlen, self.winstride = k, sketch_size, winlen, winstride
         self.device = device
@@ -220,6 +241,12 @@ class Database:
 
     def win_bits(self):
         return int(lib().mcq_db_win_bits(self.h))
+
+    def layout(self):
+        """what the handle was built as: location format / width, bucket size, load factor, sizes (mcq_db_layout)"""
+        lo = DbLayout()
+        _chk(lib().mcq_db_layout_get(self.h, C.byref(lo)))
+        return lo.as_dict()
 
     def assemble(self, n_lists, list_len_ptr, src_slot_ptr, n_slots, src_locs_ptr, bases_ptr, seq_off_ptr, n_seqs, paired,
                  win_off_ptr, loc_off_ptr, query_len_ptr, dst_locs_ptr, stream=None):

@@ -36,6 +36,34 @@ def make_genomes(n_species, strains_per_species, len_lo, len_hi, divergence, see
     return bases, off, torch.tensor(species, dtype=torch.int64, device=device)
 
 
+def add_genome(bases, seq_off, species, length, seed):
+    """Appends one random genome of `length` bases as a species of its own (a chromosome with more than 2^17 windows
+    -- 14.9 Mbp at the default stride -- makes a table RefSeq-like: target and window ids stop fitting 32 bits as fields)."""
+    dev = bases.device
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    extra = _ACGT.to(dev)[torch.randint(0, 4, (length,), generator=g, device=dev, dtype=torch.int64)]
+    off = torch.cat([seq_off, (seq_off[-1] + length).reshape(1)])
+    sp = torch.cat([species, (species.max() + 1).reshape(1)])
+    return torch.cat([bases, extra]), off, sp
+
+
+def split_targets(seq_off, species, pieces, keep_last_whole=False):
+    """Every genome becomes `pieces` targets of (nearly) equal length -- assemblies are many sequences per genome (RefSeq
+    bacteria: ~2^15-2^17 sequences) -- of the same species.  The bases do not move.  Returns (seq_off, species)."""
+    n = seq_off.numel() - 1
+    dev = seq_off.device
+    lens = seq_off[1:] - seq_off[:-1]
+    j = torch.arange(pieces, device=dev, dtype=torch.int64)
+    cut = seq_off[:-1, None] + (lens[:, None] * j[None, :]) // pieces          # [n, pieces] piece starts
+    sp = species[:, None].expand(n, pieces)
+    if keep_last_whole and n > 1:
+        cut_l = torch.cat([cut[:-1].reshape(-1), seq_off[-2].reshape(1)])
+        sp_l = torch.cat([sp[:-1].reshape(-1), species[-1].reshape(1)])
+    else:
+        cut_l, sp_l = cut.reshape(-1), sp.reshape(-1)
+    return torch.cat([cut_l, seq_off[-1].reshape(1)]).contiguous(), sp_l.contiguous()
+
+
 def sample_reads(bases, seq_off, n_reads, read_len, sub_rate, n_rate, seed, revcomp_half=True):
     """Fixed-length reads drawn uniformly over all targets.  Returns (reads uint8 [n_reads*read_len],
     read_off int64 [n_reads+1], origin target int64 [n_reads])."""

@@ -29,7 +29,8 @@ def main():
     table = eng.Table(gb.data_ptr(), goff.data_ptr(), goff.numel() - 1, emulate_ranks=P)
     keys, off, locs, _ = table.to_host()
     sp32 = species.to(torch.int32).contiguous()
-    db = eng.Database(None, None, None, None, n_shards=world, shard_id=rank, flags=eng.MCQ_DB_LOCS_64 if locs64 else 0,
+    db = eng.Database(None, None, None, None, n_shards=world, shard_id=rank,
+                      flags=(0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16)[locs64],   # bit fields 32 / 64, global window
                       device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr, tgt2tax=sp32.data_ptr(),
                                        n_keys=table.n_keys, n_locs=table.n_locs, n_targets=sp32.numel()))
     table.close()

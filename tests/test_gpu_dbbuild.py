@@ -106,7 +106,7 @@ def test_abi_table_host_pointers_and_truncation():
         tb.close()
 
 
-@pytest.mark.parametrize("flags", [0, 0x200])
+@pytest.mark.parametrize("flags", [0, 0x200, 0x2000 | 0x4000], ids=["loc32", "loc64", "gw-slots16"])
 @pytest.mark.parametrize("tag,P", [("mini", 4), ("tie", 2)])
 def test_abi_db_build_queries_like_the_reference(tag, P, flags):
     """mcq_db_build from the fixture genomes, then the fixture reads: the top hits the reference's
@@ -118,7 +118,8 @@ def test_abi_db_build_queries_like_the_reference(tag, P, flags):
     bases, off = _load_genomes(tag, dev)
     t2t = torch.from_numpy(np.asarray(fx.tgt2tax(), np.uint32).view(np.int32).copy()).to(dev)
     db = engine.Database.build(bases.data_ptr(), off.data_ptr(), t2t.data_ptr(), off.numel() - 1, emulate_ranks=P, flags=flags)
-    assert db.loc_bytes() == (8 if flags else 4)
+    assert db.loc_bytes() == (8 if flags == 0x200 else 4)
+    assert db.layout()["loc_format"] == (2 if flags & 0x2000 else 0 if flags == 0x200 else 1)
     rb, ro = orc.pack_reads(fx.interleaved())
     ws = engine.Workspace(db, len(fx.names), len(rb))
     cands, ncand = ws.query_host(rb, ro, True, max_cand=fx.maxcand, emulate_ranks=P, flags=engine.MCQ_QUIRK_SEQ_DROP)

@@ -98,33 +98,40 @@ def _reduce_against_oracle(make_lists):
     keys, off, locs = dbfile.union_shards(fx.shards)
     p = fx.params
     t2t = fx.tgt2tax()
-    db = eng.Database(keys, off, locs, t2t, k=p["qk"], sketch_size=p["qs"], winlen=p["qwinlen"], winstride=p["qwinstride"],
-                      tgt_winstride=p["winstride"])
     odb = orc.OracleDb(keys, off, locs, t2t, k=p["qk"], s=p["qs"], winlen=p["qwinlen"], winstride=p["qwinstride"],
                        tgt_winstride=p["winstride"])
     lists = make_lists(locs)
     loc_off = np.zeros(len(lists) + 1, np.int64); loc_off[1:] = np.cumsum([len(x) for x in lists])
     allv = np.concatenate(lists)
-    wb = db.win_bits()
-    if db.loc_bytes() == 4:
-        dl = torch.from_numpy((((allv >> np.uint64(32)) << np.uint64(wb)) | (allv & np.uint64(0xFFFFFFFF))).astype(np.uint32).view(np.int32)).to(dev)
-    else:
-        dl = torch.from_numpy(allv.view(np.int64)).to(dev)
+    # global-window form: windows per target = 1 + its largest window id in the table (what the handle derives)
+    ext = np.zeros(len(t2t), np.int64)
+    np.maximum.at(ext, (locs >> np.uint64(32)).astype(np.int64), (locs & np.uint64(0xFFFFFFFF)).astype(np.int64) + 1)
+    gw_off = np.concatenate([[0], np.cumsum(ext)]).astype(np.uint64)
     qlen = torch.full((len(lists),), 150, dtype=torch.int32, device=dev)
     doff = torch.from_numpy(loc_off).to(dev)
-    ws = eng.Workspace(db, len(lists), 1)
-    for P, M in ((1, 4), (2, 2), (32, 4)):          # (32, 4): lists in the workgroup kernel's LDS
-        for flags in (0, eng.MCQ_FORCE_RAW_SORT):
-            cands = torch.zeros((len(lists), M, 4), dtype=torch.int32, device=dev)
-            ncand = torch.zeros(len(lists), dtype=torch.int32, device=dev)
-            ws.reduce_device(len(lists), doff.data_ptr(), dl.data_ptr(), qlen.data_ptr(), cands.data_ptr(), ncand.data_ptr(),
-                             max_cand=M, emulate_ranks=P, flags=flags, stream=torch.cuda.current_stream(dev).cuda_stream)
-            ws.sync()
-            gc = cands.cpu().numpy().view(np.uint32); gn = ncand.cpu().numpy().view(np.uint32)
-            for q, lst in enumerate(lists):
-                oc, on = odb.reduce_query(lst, 150, max_cand=M, emulate_ranks=P)
-                assert gn[q] == on, (q, P, M, flags, len(lst), len(np.unique(lst)))
-                assert np.array_equal(gc[q, :on], oc[:on]), (q, P, M, flags, len(lst), len(np.unique(lst)), gc[q], oc)
+    for dbflags in (0, eng.MCQ_DB_LOCS_GW):           # the staged reduce kernels in both 32-bit location forms
+        db = eng.Database(keys, off, locs, t2t, k=p["qk"], sketch_size=p["qs"], winlen=p["qwinlen"], winstride=p["qwinstride"],
+                          tgt_winstride=p["winstride"], flags=dbflags)
+        wb = db.win_bits()
+        if db.layout()["loc_format"] == eng.MCQ_LOC_GLOBAL_WINDOW:
+            dl = torch.from_numpy((gw_off[(allv >> np.uint64(32)).astype(np.int64)] + (allv & np.uint64(0xFFFFFFFF))).astype(np.uint32).view(np.int32)).to(dev)
+        elif db.loc_bytes() == 4:
+            dl = torch.from_numpy((((allv >> np.uint64(32)) << np.uint64(wb)) | (allv & np.uint64(0xFFFFFFFF))).astype(np.uint32).view(np.int32)).to(dev)
+        else:
+            dl = torch.from_numpy(allv.view(np.int64)).to(dev)
+        ws = eng.Workspace(db, len(lists), 1)
+        for P, M in ((1, 4), (2, 2), (32, 4)):          # (32, 4): lists in the workgroup kernel's LDS
+            for flags in (0, eng.MCQ_FORCE_RAW_SORT):
+                cands = torch.zeros((len(lists), M, 4), dtype=torch.int32, device=dev)
+                ncand = torch.zeros(len(lists), dtype=torch.int32, device=dev)
+                ws.reduce_device(len(lists), doff.data_ptr(), dl.data_ptr(), qlen.data_ptr(), cands.data_ptr(), ncand.data_ptr(),
+                                 max_cand=M, emulate_ranks=P, flags=flags, stream=torch.cuda.current_stream(dev).cuda_stream)
+                ws.sync()
+                gc = cands.cpu().numpy().view(np.uint32); gn = ncand.cpu().numpy().view(np.uint32)
+                for q, lst in enumerate(lists):
+                    oc, on = odb.reduce_query(lst, 150, max_cand=M, emulate_ranks=P)
+                    assert gn[q] == on, (q, P, M, flags, len(lst), len(np.unique(lst)))
+                    assert np.array_equal(gc[q, :on], oc[:on]), (q, P, M, flags, len(lst), len(np.unique(lst)), gc[q], oc)
 
 
 def test_reduce_counts_any_multiset_exactly():

@@ -39,10 +39,16 @@ def _same(cands, ncand, oc, on):
 
 @pytest.mark.parametrize("tag,P", CASES)
 @pytest.mark.parametrize("block", [False, True, "raw"], ids=["wave", "block", "wave-rawsort"])
-@pytest.mark.parametrize("locs64", [False, True], ids=["loc32", "loc64"])
-def test_final_vs_reference_cli(eng, tag, P, block, locs64):
+@pytest.mark.parametrize("fmt", ["loc32", "loc64", "gw", "loc32-slots16", "gw-buckets64"])
+def test_final_vs_reference_cli(eng, tag, P, block, fmt):
+    # location formats (bit fields in 32 / 64 bits, global window index) x table layouts (64-B buckets, 16-B slots)
     fx = Fixture(tag, P)
-    db, odb = _dbs(eng, fx, flags=eng.MCQ_DB_LOCS_64 if locs64 else 0)
+    dbflags = {"loc32": 0, "loc64": eng.MCQ_DB_LOCS_64, "gw": eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16,
+               "loc32-slots16": eng.MCQ_DB_SLOTS_16, "gw-buckets64": eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_BUCKETS_64}[fmt]
+    db, odb = _dbs(eng, fx, flags=dbflags)
+    lay = db.layout()
+    assert lay["loc_format"] == (eng.MCQ_LOC_GLOBAL_WINDOW if fmt.startswith("gw") else eng.MCQ_LOC_FIELDS64 if fmt == "loc64" else eng.MCQ_LOC_FIELDS32)
+    assert lay["bucket_bytes"] == (16 if "slots16" in fmt or fmt == "gw" else 64)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     ws = eng.Workspace(db, len(fx.names), len(bases))
     flags = eng.MCQ_QUIRK_SEQ_DROP | {False: 0, True: eng.MCQ_FORCE_BLOCK_PATH, "raw": eng.MCQ_FORCE_RAW_SORT}[block]
@@ -63,7 +69,7 @@ def test_per_rank_candidates_with_positions(eng, tag, P):
     fx = Fixture(tag, P)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     for r in range(P):
-        db, odb = _dbs(eng, fx, [fx.shards[r]], flags=eng.MCQ_DB_LOCS_64 if r % 2 else 0)
+        db, odb = _dbs(eng, fx, [fx.shards[r]], flags=(0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16)[r % 3])
         ws = eng.Workspace(db, len(fx.names), len(bases))
         for flags in (0, eng.MCQ_FORCE_BLOCK_PATH, eng.MCQ_FORCE_RAW_SORT):
             cands, ncand = ws.query_host(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=1, flags=flags)
@@ -78,7 +84,7 @@ def test_sorted_match_lists(eng, tag, P):
     fx = Fixture(tag, P)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     for r in range(P):
-        db, odb = _dbs(eng, fx, [fx.shards[r]], flags=eng.MCQ_DB_LOCS_64 if r % 2 else 0)
+        db, odb = _dbs(eng, fx, [fx.shards[r]], flags=(0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW, eng.MCQ_DB_SLOTS_16)[r % 4])
         ws = eng.Workspace(db, len(fx.names), len(bases))
         moff, m = ws.debug_matches(bases, seq_off, True)
         for q in range(len(fx.names)):

@@ -143,7 +143,7 @@ def test_match_lists_on_every_path_vs_reference(eng, tag, P):
     fx = Fixture(tag, P)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     for r in range(P):
-        for dbflags in (0, eng.MCQ_DB_LOCS_64):
+        for dbflags in (0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16):
             db, odb = _dbs(eng, fx, [fx.shards[r]], flags=dbflags)
             ws = eng.Workspace(db, len(fx.names), len(bases))
             for pf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16, eng.MCQ_FORCE_BLOCK_PATH):
@@ -180,7 +180,7 @@ def test_match_lists_of_long_lists_vs_oracle(eng):
     want = [odb.matches(s.encode()) for s in seqs]
     T = np.array([len(w) for w in want])
     assert (T <= 64).any() and ((T > 64) & (T <= 512)).any() and ((T > 512) & (T <= 1024)).any() and (T > 1024).any(), np.percentile(T, [0, 50, 100])
-    for dbflags in (0, eng.MCQ_DB_LOCS_64):
+    for dbflags in (0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_BUCKETS_64):
         db = eng.Database(keys, off, locs, t2t, flags=dbflags)
         ws = eng.Workspace(db, n, n * L)
         for pf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16, eng.MCQ_FORCE_BLOCK_PATH):

@@ -21,7 +21,9 @@ def world():
     out = {}
     for P in (1, 2, 4):
         keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=P)
-        db = dbbuild.make_database(keys, off, locs, species, flags=eng.MCQ_DB_LOCS_64 if P == 4 else 0)
+        # P = 1: global-window locations in 16-B slots; P = 2: what the handle picks (bit fields, 64-B buckets); P = 4: 64-bit
+        db = dbbuild.make_database(keys, off, locs, species,
+                                   flags={1: eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16, 2: 0, 4: eng.MCQ_DB_LOCS_64}[P])
         odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), off.cpu().numpy().astype(np.uint64),
                            locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
         out[P] = (db, odb)
@@ -85,10 +87,14 @@ def test_db_roundtrip_lookup(world):
     dev = torch.device("cuda", 0)
     keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=2)
     species = torch.zeros(goff.numel() - 1, dtype=torch.int64, device=dev)
-    for n_shards in (1, 3):
+    # global-window form: windows per target = 1 + its largest window id (what the handle derives), offsets = their prefix sums
+    l_t, l_w = (locs >> 32), (locs & 0xFFFFFFFF)
+    ext = torch.zeros(goff.numel() - 1, dtype=torch.int64, device=dev).scatter_reduce(0, l_t, l_w + 1, "amax")
+    gw_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(ext, 0)])
+    for n_shards, dbflags in ((1, 0), (3, 0), (1, eng.MCQ_DB_LOCS_GW), (3, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16), (2, eng.MCQ_DB_SLOTS_16)):
         total = 0
         for sid in range(n_shards):
-            db = dbbuild.make_database(keys, off, locs, species, n_shards=n_shards, shard_id=sid)
+            db = dbbuild.make_database(keys, off, locs, species, n_shards=n_shards, shard_id=sid, flags=dbflags)
             k32 = torch.where(keys >= (1 << 31), keys - (1 << 32), keys).to(torch.int32).contiguous()
             # plus some absent keys and the reserved value
             probe = torch.cat([k32, torch.tensor([-1, 5, 7], dtype=torch.int32, device=dev)])
@@ -101,7 +107,12 @@ def test_db_roundtrip_lookup(world):
             native = torch.zeros(int(ooff[-1].item()) + 1, dtype=torch.int32 if db.loc_bytes() == 4 else torch.int64, device=dev)
             db.lookup_gather(probe.data_ptr(), n, ooff.data_ptr(), native.data_ptr(), stream=st)
             torch.cuda.synchronize()
-            if db.loc_bytes() == 4:          # (tgt << win_bits) | win  ->  (tgt << 32) | win
+            if db.layout()["loc_format"] == eng.MCQ_LOC_GLOBAL_WINDOW:        # gw_off[tgt] + win  ->  (tgt << 32) | win
+                assert dbflags & eng.MCQ_DB_LOCS_GW and db.loc_bytes() == 4
+                w = native.to(torch.int64) & 0xFFFFFFFF
+                t = torch.searchsorted(gw_off, w, right=True) - 1
+                out = (t << 32) | (w - gw_off[t])
+            elif db.loc_bytes() == 4:        # (tgt << win_bits) | win  ->  (tgt << 32) | win
                 wb = db.win_bits(); w = native.to(torch.int64) & 0xFFFFFFFF
                 out = ((w >> wb) << 32) | (w & ((1 << wb) - 1))
             else:
@@ -158,7 +169,7 @@ def test_many_strains_cross_every_list_size_boundary():
     reads, roff, _ = synth.sample_reads(gb, goff, n, L, 0.004, 0.001, seed=5)
     rb = reads.cpu().numpy().tobytes(); ro = roff.cpu().numpy().astype(np.uint64)
     oc, on, st = odb.query(rb, ro, False, max_cand=4, emulate_ranks=2, threads=8, want_stats=True)
-    for flags in (0, eng.MCQ_DB_LOCS_64):
+    for flags in (0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_BUCKETS_64):
         db = dbbuild.make_database(keys, off, locs, species, flags=flags)
         ws = eng.Workspace(db, n, n * L)
         for qf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16):
@@ -198,7 +209,7 @@ def test_crafted_lists_cross_the_distinct_key_limits():
     t2t = (np.arange(n_tgt) // 7).astype(np.uint32)
     rb, ro = orc.pack_reads([s.encode() for s in seqs])
     odb = orc.OracleDb(keys, off, locs, t2t)
-    for flags in (0, eng.MCQ_DB_LOCS_64):
+    for flags in (0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW):
         db = eng.Database(keys, off, locs, t2t, flags=flags)
         ws = eng.Workspace(db, n, n * L)
         for P, M in ((2, 2), (4, 4), (1, 3)):

@@ -42,7 +42,7 @@ def world1():
     keys, off, locs, _ = table.to_host()
     sp32 = species.to(torch.int32).contiguous()
     dbs = {}
-    for f in (0, eng.MCQ_DB_LOCS_64):
+    for f in (0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16):
         dbs[f] = eng.Database(None, None, None, None, flags=f,
                               device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr, tgt2tax=sp32.data_ptr(),
                                                n_keys=table.n_keys, n_locs=table.n_locs, n_targets=sp32.numel()))
@@ -51,10 +51,10 @@ def world1():
     return eng, synth, dev, gb, goff, dbs, odb
 
 
-@pytest.mark.parametrize("locs64", [0, 1])
+@pytest.mark.parametrize("locs64", [0, 1, 2], ids=["loc32", "loc64", "gw"])
 def test_one_rank_every_query_class(world1, locs64):
     eng, synth, dev, gb, goff, dbs, odb = world1
-    db = dbs[eng.MCQ_DB_LOCS_64 if locs64 else 0]
+    db = dbs[(0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16)[locs64]]
     st = torch.cuda.current_stream(dev).cuda_stream
     for paired, L, n in ((False, 150, 40000), (True, 150, 40000), (False, 500, 6000), (True, 250, 6000), (False, 6000, 300)):
         batches = []
@@ -134,13 +134,13 @@ def test_capacity_errors_are_reported(world1):
     sh.close()
 
 
-@pytest.mark.parametrize("paired,world,locs64", [(0, 2, 0), (1, 2, 1), (0, 4, 0)])
+@pytest.mark.parametrize("paired,world,locs64", [(0, 2, 0), (1, 2, 1), (0, 4, 0), (1, 2, 2)])
 def test_ranks_on_one_gpu_over_gloo(paired, world, locs64):
     with tempfile.TemporaryDirectory() as d:
         outp = os.path.join(d, "res")
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", str(29800 + paired + 10 * world),
+               "--master-addr", "127.0.0.1", "--master-port", str(29800 + paired + 10 * world + 100 * locs64),
                os.path.join(ROOT, "tests", "shard_native_worker.py"), outp, str(paired), str(locs64)]
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:]
