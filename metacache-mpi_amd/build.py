@@ -13,7 +13,8 @@ _OBJ = os.path.join(_HERE, "csrc", "_obj")
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmcq_hip.so")
+    """MCQ_HIP_LIB (tuning knob): another build of the library, e.g. a variant for a same-box A/B (scripts/ab_libs.sh)"""
+    return os.environ.get("MCQ_HIP_LIB") or os.path.join(_HERE, "libmcq_hip.so")
 
 
 def host_lib_path():
@@ -86,6 +87,8 @@ def build_host(force=False, verbose=False):
 
 def build_hip(force=False, verbose=False):
     """hipcc every unit of csrc/ for gfx950 into csrc/_obj/*.o, link libmcq_hip.so"""
+    if os.environ.get("MCQ_HIP_LIB"):          # a prebuilt variant was asked for: nothing to build
+        return lib_path()
     out = lib_path()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(_OBJ, exist_ok=True)

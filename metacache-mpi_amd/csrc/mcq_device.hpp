@@ -38,23 +38,25 @@ struct DbDev {
                              // (mcq_db_create): short lists -> 64-B buckets, long lists / large tables -> 16-B slots
     u32 slot_mask;           // nslots - 1 (power of two)
     u32 bsh;                 // log2(uint4 per bucket): 2 (64-B buckets) or 0 (16-B slots)
-    u32 inl;                 // longest list that lives in its bucket: 14 / 7 (64-B buckets, compact / wide), 0 (16-B slots)
-    u32 inl_first;           // index of a bucket's first inline location, in location units relative to the bucket
-    u64 ext0;                // first location behind the buckets, in location units relative to `locs`
     const void* locs;        // base of all lists = the bucket array itself (the long lists follow it in the same allocation):
                              // u64 (tgt<<32)|win, or a 32-bit word when `compact`: (tgt<<wb)|win, or (gw) the global window
                              // index gw_off[tgt] + win
     u32 wb;                  // window-id bits inside a location word (32 for u64 locations; unused with gw)
     u32 compact;             // 32-bit location words
-    u32 gw;                  // 32-bit location = global window index: for tables whose (target, window) space does not fit
-                             // 32 bits as two fields (RefSeq scale: >= 2^15 sequences, chromosomes of >= 2^17 windows)
-    u32 gw_shift;            // gw_blk has one entry per 2^gw_shift windows
-    const u32* gw_off;       // [n_targets + 1] first global window of every target
-    const u32* gw_blk;       // [(n_windows >> gw_shift) + 2] target that holds window b << gw_shift
     const u32* tgt2tax;
     u32 n_targets;
     u32 k, s, winlen, winstride, tgt_winstride;
     u32 magic_stride, magic_tgt_stride;   // floor(2^32 / stride): udiv_magic
+};
+// 32-bit location = global window index: for tables whose (target, window) space does not fit 32 bits as two fields (RefSeq
+// scale: >= 2^15 sequences, chromosomes of >= 2^17 windows).  A kernel argument of its own, the LAST one, read by the GW
+// instantiations only: inside DbDev it moved every later argument of the hot kernel, and the different SGPR allocation
+// that followed cost it 2 % (+270 spill reloads).
+struct GwDev {
+    const u32* off;          // [n_targets + 1] first global window of every target
+    const u32* blk;          // [(n_windows >> shift) + 2] target that holds window b << shift
+    u32 shift;               // blk has one entry per 2^shift windows
+    u32 on;
 };
 
 // ---- location formats -----------------------------------------------------------------------------------------------
@@ -69,12 +71,14 @@ struct DbDev {
 //           to stay in L2 (<= 1 MB + 4 B per target); a lookup is two dependent L2 loads per DISTINCT location of a read.
 template <class KeyT>
 struct LocShift {
+    static constexpr bool lookup = false;      // tgt / tbeg are arithmetic on the word
     u32 wb;
     __device__ __forceinline__ KeyT tbeg(KeyT k) const { return k & ~((((KeyT)1) << wb) - 1); }
     __device__ __forceinline__ u32 tgt(KeyT k) const { return (u32)(k >> wb); }
     __device__ __forceinline__ void locate(KeyT k, u32& t, KeyT& tb) const { t = tgt(k); tb = tbeg(k); }
 };
 struct LocGW {
+    static constexpr bool lookup = true;       // tgt / tbeg cost memory accesses: callers keep what they looked up
     const u32* __restrict__ off; const u32* __restrict__ blk; u32 shift;
     __device__ __forceinline__ void locate(u32 k, u32& t, u32& tb) const {
         const u32 b = k >> shift;
@@ -93,8 +97,8 @@ struct LocGW {
 template <class KeyT, bool GW> struct LocOf { typedef LocShift<KeyT> type; };
 template <> struct LocOf<u32, true> { typedef LocGW type; };
 template <class KeyT, bool GW>
-__device__ __forceinline__ typename LocOf<KeyT, GW>::type loc_format(const DbDev& db) {
-    if constexpr (GW) { LocGW f; f.off = db.gw_off; f.blk = db.gw_blk; f.shift = db.gw_shift; return f; }
+__device__ __forceinline__ typename LocOf<KeyT, GW>::type loc_format(const DbDev& db, const GwDev& g) {
+    if constexpr (GW) { LocGW f; f.off = g.off; f.blk = g.blk; f.shift = g.shift; return f; }
     else { LocShift<KeyT> f; f.wb = db.wb; return f; }
 }
 // smallest word of a window range of `numWindows` windows that ends at k (never below the target's first word)
@@ -618,22 +622,43 @@ __device__ __forceinline__ u32 wave_sketch_b(const BatchDev& b, u64 at, u32 n, u
 // requests per read on a 2 Gbp table), 16-B slots {key, len, offset} with every list behind the slot array once they are
 // not (>= 10 Gbp: most lists do not fit a bucket any more, and the 64-B array costs +27 GB and 1-3 % time).
 #define MCQ_BUCKET_BYTES 64u
-__device__ __forceinline__ uint4 bucket_head(const DbDev& db, u32 idx) { return db.slots[(u64)idx << db.bsh]; }
-__device__ __forceinline__ void bucket_list(const DbDev& db, u32 idx, const uint4& sl, u64& off, u32& len) {
+// (everything about a layout follows from two scalars, bsh and compact)
+__device__ __host__ __forceinline__ u32 bucket_inline_max(u32 bsh, u32 compact) { return ((bsh * 7u) >> 1) << compact; }   // 14 / 7 / 0
+// BSH = log2(uint4 per bucket) as a compile-time constant: the query kernels are short of SGPRs, and one more live
+// scalar in the probe loop (a run-time bucket size) costs the hot kernel 270 spill reloads and 2 % -- so every caller
+// branches once per probe on db.bsh (wave-uniform) into the code of its layout
+template <u32 BSH>
+__device__ __forceinline__ uint4 bucket_head_t(const DbDev& db, u32 idx) { return db.slots[(u64)idx << BSH]; }
+template <u32 BSH>
+__device__ __forceinline__ void bucket_list_t(const DbDev& db, u32 idx, const uint4& sl, u64& off, u32& len) {
     len = sl.y;
-    off = len <= db.inl ? ((u64)idx << (db.bsh + 1 + db.compact)) + db.inl_first          // 16 B = 2 wide / 4 compact locations
-                        : db.ext0 + (((u64)sl.w << 32) | sl.z);
+    const u32 sh = BSH + 1 + db.compact;                     // log2(locations per bucket): 16 B = 2 wide / 4 compact locations
+    off = len <= bucket_inline_max(BSH, db.compact) ? ((u64)idx << sh) + (1u << db.compact)      // behind the 8-B head
+                                                    : (((u64)db.slot_mask + 1) << sh) + (((u64)sl.w << 32) | sl.z);
 }
-__device__ __forceinline__ void probe(const DbDev& db, u32 f, u64& off, u32& len) {
-    len = 0; off = 0;
-    if (f == MCQ_EMPTY) return;
+template <u32 BSH>
+__device__ __forceinline__ void probe_t(const DbDev& db, u32 f, u64& off, u32& len) {
     u32 idx = tmh(f) & db.slot_mask;
     while (true) {
-        const uint4 sl = bucket_head(db, idx);
-        if (sl.x == f) { bucket_list(db, idx, sl, off, len); return; }
+        const uint4 sl = bucket_head_t<BSH>(db, idx);
+        if (sl.x == f) { bucket_list_t<BSH>(db, idx, sl, off, len); return; }
         if (sl.x == MCQ_EMPTY) return;
         idx = (idx + 1) & db.slot_mask;
     }
+}
+// BSH = 2 / 0: the layout is known at compile time (the wave kernels are instantiated per layout); -1: one wave-uniform
+// branch on db.bsh per probe (workgroup kernel, staged kernels, the match-list taps)
+template <int BSH = -1>
+__device__ __forceinline__ void probe(const DbDev& db, u32 f, u64& off, u32& len) {
+    len = 0; off = 0;
+    if (f == MCQ_EMPTY) return;
+    if constexpr (BSH >= 0) probe_t<(u32)BSH>(db, f, off, len);
+    else { if (db.bsh) probe_t<2>(db, f, off, len); else probe_t<0>(db, f, off, len); }
+}
+// (the owner-side lookup of the sharded path walks four probes at a time: its own loop, on these)
+__device__ __forceinline__ uint4 bucket_head(const DbDev& db, u32 idx) { return db.slots[(u64)idx << db.bsh]; }
+__device__ __forceinline__ void bucket_list(const DbDev& db, u32 idx, const uint4& sl, u64& off, u32& len) {
+    if (db.bsh) bucket_list_t<2>(db, idx, sl, off, len); else bucket_list_t<0>(db, idx, sl, off, len);
 }
 
 // ------------------------------------------------------------------ row 8: sort
@@ -986,14 +1011,17 @@ __device__ __forceinline__ void sweep_targets_weighted(const u32* SK, const u32*
 // multiplicity sums) and a narrow window range: distinct keys of one target have distinct windows, so the range
 // ending at an entry reaches back over at most numWindows - 1 predecessors -- checked with wave_shr:1 shifts
 // instead of a binary search through LDS.  numWindows <= 8.
+// tb_in (formats with LF::lookup only): the first word of the lane's target, looked up by the caller -- who keeps the
+// target for the top lists; a format whose tbeg is arithmetic computes it here (nothing extra stays live)
 template <class LF>
-__device__ __forceinline__ void sweep_targets_regs(u32 k, u32 incl, u32* H, u32 D, u32 numWindows, const LF& lf, u32 lane) {
+__device__ __forceinline__ void sweep_targets_regs(u32 k, u32 incl, u32 tb_in, u32* H, u32 D, u32 numWindows, const LF& lf, u32 lane) {
     H[lane] = 0;
     wave_sync();
     const bool valid = lane < D;
     asm("s_nop 1" : "+v"(k));                     // k may come straight out of an asm sort block (DPP read hazard)
     const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)k, 0x138, 0xF, 0xF, false);      // wave_shr:1
-    const u32 tb = lf.tbeg(valid ? k : bcast(k, 0));      // (padding lanes look up a real word)
+    u32 tb = tb_in;
+    if constexpr (!LF::lookup) tb = lf.tbeg(k);
     const bool head = valid && (lane == 0 || prev < tb);
     const u64 le = __ballot(head) & ((2ull << lane) - 1);
     const u32 myhead = le ? 63u - (u32)__builtin_clzll(le) : 0u;
@@ -1206,10 +1234,12 @@ __device__ __forceinline__ u32 fold_lists_write(const DbDev& db, const OptDev& o
 // round is one ds_max per candidate into the word of its rank instead of a DPP reduction per rank: all P
 // ranks advance in the same round (M rounds per 64 candidates instead of P x M), and a round costs a dozen
 // VALU instructions.  scr: 128 words of this wave's LDS segment (scr[0..64) maxima, scr[64..128) winner taxa).
-template <int JB = 9, class LF>
+// REGT (T <= 64 only): the target of entry j sits in lane j's t1 (the caller looked it up once, for the sweep) and
+// comes by shuffle instead of a second lookup -- for formats whose target is a memory access away (LocGW)
+template <int JB = 9, bool REGT = false, class LF>
 __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev& opt, const OutDev& out,
                                                    const u32* buf, u32* H, u32 T, u32 numWindows, const LF& lf,
-                                                   u64 q, u32 lane, u32* scr) {
+                                                   u64 q, u32 lane, u32* scr, u32 t1 = 0) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
     const u32 JMASK = (1u << JB) - 1;
@@ -1234,7 +1264,9 @@ __device__ __forceinline__ u32 topk_fold_write_lds(const DbDev& db, const OptDev
         const u32 k = base + lane;
         u32 cv = (k < nheads) ? H[k] : 0;
         const u32 jb = JMASK - (cv & JMASK);
-        const u32 tgt = lf.tgt(buf[cv ? jb : 0]);
+        u32 tgt;
+        if constexpr (REGT) tgt = __shfl(t1, (int)(cv ? jb : 0), 64);
+        else tgt = lf.tgt(buf[cv ? jb : 0]);
         u32 ctax = MCQ_EMPTY;
         if (cv != 0 && tgt < db.n_targets) ctax = db.tgt2tax[tgt];
         if (ctax == MCQ_EMPTY) cv = 0;

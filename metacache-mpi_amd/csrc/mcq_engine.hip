@@ -68,6 +68,7 @@ struct mcq_db {
     uint4* slots;             // one allocation: the buckets, then the lists too long for a bucket
     u32* tgt2tax;
     u32* gw_off; u32* gw_blk; // global-window form: first window of every target, block -> target (see LocGW)
+    GwDev g;                  // ... as the kernels take them
     u32 n_shards, shard_id;
     u32 bucket_bytes, slots_per_key;
     u64 n_ext, n_windows;
@@ -389,14 +390,15 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 #define MCQ_DEDUP_MAX_D 256u
 #endif
 #ifdef MCQ_TOPK_DPP        // tuning knob: DPP reductions per rank instead of LDS maxima for all ranks at once
-#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, lf, q, lane) topk_fold_write<u32, u32, 9>(db, opt, out, sk, h, D, nw, lf, q, lane)
+#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, lf, q, lane, t1) topk_fold_write<u32, u32, 9>(db, opt, out, sk, h, D, nw, lf, q, lane)
 #else
-#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, lf, q, lane) topk_dedup(db, opt, out, sk, h, D, nw, lf, q, lane)
+#define MCQ_TOPK_DEDUP(db, opt, out, sk, h, D, nw, lf, q, lane, t1) topk_dedup(db, opt, out, sk, h, D, nw, lf, q, lane, t1)
 #endif
 // top lists of the dedup path: more than 64 distinct keys (two to four rounds of 64 run heads) take all heads at once
+// t1 (D <= 64): the target of sorted key j in lane j, as dedup_finish looked it up
 template <class LF>
 __device__ __forceinline__ u32 topk_dedup(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* sk, u32* H, u32 D,
-                                          u32 numWindows, const LF& lf, u64 q, u32 lane) {
+                                          u32 numWindows, const LF& lf, u64 q, u32 lane, u32 t1) {
 #ifndef MCQ_TOPK_DEDUP_CHUNKED                                      // tuning knob (A/B)
     if (D > 64) {
         u32 nheads = 0;
@@ -411,7 +413,7 @@ __device__ __forceinline__ u32 topk_dedup(const DbDev& db, const OptDev& opt, co
         return topk_all_lds<9, 4>(db, opt, out, sk, H, nheads, numWindows, lf, q, lane, H + 256);
     }
 #endif
-    return topk_fold_write_lds(db, opt, out, sk, H, D, numWindows, lf, q, lane, H + 256);
+    return topk_fold_write_lds<9, LF::lookup>(db, opt, out, sk, H, D, numWindows, lf, q, lane, H + 256, t1);
 }
 __device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 23; }
 __device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 256; }
@@ -458,15 +460,19 @@ __device__ __forceinline__ u32 dedup_insert(const u32 (&r)[E], u32* buf, u32* hi
     return D;
 }
 // Second half, the same code for every E: sort the D distinct keys, fetch their multiplicities, prefix sums.
-// k1/incl1: the sorted keys and inclusive sums one per lane when D <= 64 (for sweep_targets_regs).
+// k1/incl1: the sorted keys and inclusive sums one per lane when D <= 64 (for sweep_targets_regs); t1/tb1: target and
+// first word of the target of k1 -- looked up here, right behind the sort, so that a format that has to go to memory
+// for them (LocGW) does so once per read and under the LDS work that follows.
 // Returns D, or ~0u when D > 256.
-__device__ __forceinline__ u32 dedup_finish(u32 D, u32* buf, u32* hits, u32 lane, u32& k1, u32& incl1) {
+template <class LF>
+__device__ __forceinline__ u32 dedup_finish(u32 D, u32* buf, u32* hits, u32 lane, const LF& lf, u32& k1, u32& incl1, u32& t1, u32& tb1) {
     u32* tabkey = buf; u32* tabcnt = hits; u32* list = hits + 256; u32* SK = dedup_sk(hits); u32* WP = dedup_wp(hits);
-    k1 = MCQ_EMPTY; incl1 = 0;
+    k1 = MCQ_EMPTY; incl1 = 0; t1 = 0; tb1 = 0;
     if (D > MCQ_DEDUP_MAX_D) return ~0u;
     if (D <= 64) {
         u32 k = lane < D ? list[lane] : MCQ_EMPTY;
         k = (D <= 32) ? wave_sort32_low(k, lane) : wave_sort64(k, lane);
+        if constexpr (LF::lookup) lf.locate(lane < D ? k : list[0], t1, tb1);      // (padding lanes look up a real word)
         const u32 c = lane < D ? dedup_count(tabkey, tabcnt, k) : 0u;
         const u32 incl = wave_incl_scan_dpp(c);
         wave_sync();                             // counts consumed: WP overwrites them
@@ -610,13 +616,14 @@ __device__ __forceinline__ void tap_distinct(const DebugDev& dbg, const u32* SK,
 
 // SH (feature-sharded path, home rank): the same kernel, but the probe results of a query's feature slots come from the
 // exchange (shard_fetch) instead of sketch + probe, and db.locs is the received location buffer.
-// GW: 32-bit locations in the global-window form (LocGW), else bit fields (LocShift)
-template <class KeyT, int LCAP, bool TAP = false, bool SH = false, bool GW = false>
+// GW: 32-bit locations in the global-window form (LocGW), else bit fields (LocShift).  BSH: table layout at compile time (2 = 64-B
+// buckets, 0 = 16-B slots; -1 = run-time: the TAP instantiations), see probe()
+template <class KeyT, int LCAP, bool TAP = false, bool SH = false, bool GW = false, int BSH = -1>
 __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
-                                                    CountersDev* ctr, u32* ovf_list, int force_block, DebugDev dbg, ShardDev sh) {
+                                                    CountersDev* ctr, u32* ovf_list, int force_block, DebugDev dbg, ShardDev sh, GwDev gwd) {
     static_assert(LCAP == 512, "wave path: 8 keys per lane at most, entry index packed into 9 bits");
     static_assert(!GW || sizeof(KeyT) == 4, "the global-window form is a 32-bit word");
-    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db);
+    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db, gwd);
     __shared__ KeyT s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
@@ -662,7 +669,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
             }
             if (lane < nfeat) myf = feat[lane];
             if (stop == 1) { if (myf == 12345u) out.ncand[q] = nfeat; continue; }
-            probe(db, myf, off, len);
+            probe<BSH>(db, myf, off, len);
             if (stop == 2) { if (len == 0x7FFFFFFFu) out.ncand[q] = (u32)off; continue; }
             }
             u32 incl = wave_incl_scan_dpp(len);
@@ -702,7 +709,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         if constexpr (sizeof(KeyT) == 4) {
             if (T <= MCQ_DEDUP_MAX_T && !(force_block & 2)) {
-                u32 D, k1 = MCQ_EMPTY, incl1 = 0;
+                u32 D, k1 = MCQ_EMPTY, incl1 = 0, t1 = 0, tb1 = 0;
                 bool skipped = false;
                 if (T <= 64)       D = gather_dedup_insert<1>(db, buf, hits, T, pos, len, off, lane, stop);
                 else if (T <= 128) D = gather_dedup_insert<2>(db, buf, hits, T, pos, len, off, lane, stop);
@@ -722,14 +729,14 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                     else if (T <= 384) D = gather_dedup_insert<6>(db, buf, hits, T, pos, len, off, lane, stop);
                     else               D = gather_dedup_insert<8>(db, buf, hits, T, pos, len, off, lane, stop);
                 }
-                if (D != ~1u) D = dedup_finish(D, buf, hits, lane, k1, incl1);
+                if (D != ~1u) D = dedup_finish(D, buf, hits, lane, lf, k1, incl1, t1, tb1);
                 if (stop == 3 || stop == 4) { if (buf[lane] == 0x1234u && D == 77u) out.ncand[q] = 1; wave_sync(); continue; }
                 if (D != ~0u) {
                     if constexpr (TAP) { if (dbg.mode == 2) tap_distinct(dbg, dedup_sk(hits), dedup_wp(hits), D, lf, q, lane); }
-                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
+                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, tb1, reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
                     else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
                     if (stop == 5) { if (buf[lane] == 0x12345u) out.ncand[q] = 1; wave_sync(); continue; }
-                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, q, lane);
+                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, q, lane, t1);
                     wave_sync();
                     continue;
                 }
@@ -770,11 +777,11 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
 #ifndef MCQ_WAVE16_OCC
 #define MCQ_WAVE16_OCC 4        // waves per SIMD it is compiled for: 5 fit the LDS, but then 10 VGPRs spill (+30 % time)
 #endif
-template <bool TAP = false, bool SH = false, bool GW = false>
+template <bool TAP = false, bool SH = false, bool GW = false, int BSH = -1>
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, BatchDev b, OptDev opt, OutDev out,
-                                                                      CountersDev* ctr, u32* ovf_list, DebugDev dbg, ShardDev sh) {
+                                                                      CountersDev* ctr, u32* ovf_list, DebugDev dbg, ShardDev sh, GwDev gwd) {
     constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
-    const typename LocOf<u32, GW>::type lf = loc_format<u32, GW>(db);
+    const typename LocOf<u32, GW>::type lf = loc_format<u32, GW>(db, gwd);
     __shared__ u32 s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
@@ -817,8 +824,8 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             two = nfeat > 64;                          // wave-uniform
             const u32 myf0 = lane < nfeat ? feat[lane] : MCQ_EMPTY;
             const u32 myf1 = (two && 64 + lane < nfeat) ? feat[64 + lane] : MCQ_EMPTY;
-            probe(db, myf0, off0, len0);
-            if (two) probe(db, myf1, off1, len1);
+            probe<BSH>(db, myf0, off0, len0);
+            if (two) probe<BSH>(db, myf1, off1, len1);
             }
         }
         const u32 incl0 = wave_incl_scan_dpp(len0);
@@ -850,16 +857,16 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         if (T <= MCQ_DEDUP_MAX_T) {                    // a wide read with a short list: the distinct-key tail of the first stage
-            u32 D, k1 = MCQ_EMPTY, incl1 = 0;
+            u32 D, k1 = MCQ_EMPTY, incl1 = 0, t1 = 0, tb1 = 0;
             if (T <= 128)      D = gather2_dedup_insert<2>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
             else if (T <= 256) D = gather2_dedup_insert<4>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
             else               D = gather2_dedup_insert<8>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
-            D = dedup_finish(D, buf, hits, lane, k1, incl1);
+            D = dedup_finish(D, buf, hits, lane, lf, k1, incl1, t1, tb1);
             if (D != ~0u) {
                 if constexpr (TAP) { if (dbg.mode == 2) tap_distinct(dbg, dedup_sk(hits), dedup_wp(hits), D, lf, q, lane); }
-                if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, buf, D, numWindows, lf, lane);
+                if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, tb1, buf, D, numWindows, lf, lane);
                 else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), buf, D, numWindows, lf, lane);
-                st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), buf, D, numWindows, lf, q, lane);
+                st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), buf, D, numWindows, lf, q, lane, t1);
                 wave_sync();
                 continue;
             }
@@ -944,9 +951,9 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
 // <4096, 512> with four per CU is slower: 15 % of those reads then sort in global scratch).
 template <class KeyT, int LCAPB, int NT, bool BIG = false, bool SH = false, bool GW = false>
 __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
-                                                      CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg, ShardDev sh) {
+                                                      CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg, ShardDev sh, GwDev gwd) {
     static_assert(LCAPB <= 8192, "packed sweep word: 13 index bits");
-    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db);
+    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db, gwd);
     constexpr u32 NW16 = NT / 64;
     __shared__ KeyT s_buf[LCAPB];
     __shared__ u32 s_hits[LCAPB];
@@ -1199,8 +1206,8 @@ __device__ __forceinline__ void load_sort_store(KeyT* buf, const KeyT* src, u32 
 
 template <class KeyT, int LCAP, bool GW = false>
 __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, u32* ovf_list,
-                                                     u64 nq, const u64* loc_off, const KeyT* locs, const u32* query_len) {
-    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db);
+                                                     u64 nq, const u64* loc_off, const KeyT* locs, const u32* query_len, GwDev gwd) {
+    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db, gwd);
     __shared__ KeyT s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
@@ -1227,18 +1234,18 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         if constexpr (sizeof(KeyT) == 4) {
             if (T <= MCQ_DEDUP_MAX_T && !(opt.hooks & 1)) {
                 const u32* src = locs + b0;
-                u32 D, k1, incl1;
+                u32 D, k1, incl1, t1, tb1;
                 if (T <= 64)       D = load_dedup_insert<1>(src, buf, hits, T, lane);
                 else if (T <= 128) D = load_dedup_insert<2>(src, buf, hits, T, lane);
                 else if (T <= 192) D = load_dedup_insert<3>(src, buf, hits, T, lane);
                 else if (T <= 256) D = load_dedup_insert<4>(src, buf, hits, T, lane);
                 else if (T <= 384) D = load_dedup_insert<6>(src, buf, hits, T, lane);
                 else               D = load_dedup_insert<8>(src, buf, hits, T, lane);
-                D = dedup_finish(D, reinterpret_cast<u32*>(buf), hits, lane, k1, incl1);
+                D = dedup_finish(D, reinterpret_cast<u32*>(buf), hits, lane, lf, k1, incl1, t1, tb1);
                 if (D != ~0u) {
-                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
+                    if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, tb1, reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
                     else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
-                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, q, lane);
+                    st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, q, lane, t1);
                     wave_sync();
                     continue;
                 }
@@ -1262,9 +1269,9 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
 // second wave stage of the staged path (see k_query_wave16): 513..1024 locations, 16 keys per lane
 template <bool GW = false>
 __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
-                                                                       u64 nq, const u64* loc_off, const u32* locs, const u32* query_len) {
+                                                                       u64 nq, const u64* loc_off, const u32* locs, const u32* query_len, GwDev gwd) {
     constexpr int LCAP = MCQ_LCAP_WAVE16, JB = 10;
-    const typename LocOf<u32, GW>::type lf = loc_format<u32, GW>(db);
+    const typename LocOf<u32, GW>::type lf = loc_format<u32, GW>(db, gwd);
     __shared__ u32 s_buf[4][LCAP];
     __shared__ u32 s_hits[4][LCAP];
     const u32 lane = threadIdx.x & 63;
@@ -1293,8 +1300,8 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db,
 
 template <class KeyT, int LCAPB, bool BIG = false, bool GW = false>
 __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
-                                                       ScratchDev sc, const u64* loc_off, const KeyT* locs, const u32* query_len) {
-    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db);
+                                                       ScratchDev sc, const u64* loc_off, const KeyT* locs, const u32* query_len, GwDev gwd) {
+    const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db, gwd);
     __shared__ KeyT s_buf[LCAPB];
     __shared__ u32 s_hits[LCAPB];
     __shared__ u32 s_biglist[BIG ? 2 * MCQ_BIGLIST_MAX : 1];
@@ -1710,7 +1717,7 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     if (desc->flags & MCQ_DB_SLOTS_16) bucket_bytes = 16;
     if (desc->flags & MCQ_DB_BUCKETS_64) bucket_bytes = 64;
     if (const char* e = getenv("MCQ_BUCKET_BYTES")) { const int v = atoi(e); if (v == 16 || v == 64) bucket_bytes = (u32)v; }   // tuning knob
-    const u32 inl = bucket_bytes == 64 ? (compact ? 14u : 7u) : 0u;
+    const u32 inl = bucket_inline_max(bucket_bytes == 64 ? 2u : 0u, compact);
     DBCHK(tmp.alloc((void**)&d_ext, std::max<u64>(1, nk) * 8));
     DBCHK(tmp.alloc((void**)&d_new, (nk + 1) * 8));
     if (nk) hipLaunchKernelGGL(k_ext_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, (const u64*)d_len, nk, inl, d_ext);
@@ -1765,10 +1772,9 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
 #undef DBRC
 
     db->d.slots = db->slots; db->d.slot_mask = (u32)(db->nslots - 1); db->d.locs = db->slots;
-    db->d.bsh = bucket_bytes == 64 ? 2u : 0u; db->d.inl = inl; db->d.inl_first = compact ? 2u : 1u;
-    db->d.ext0 = nslots * bucket_bytes / locsz;
+    db->d.bsh = bucket_bytes == 64 ? 2u : 0u;
     db->d.wb = wb; db->d.compact = compact;
-    db->d.gw = gw; db->d.gw_shift = gw_shift; db->d.gw_off = d_gwoff; db->d.gw_blk = d_gwblk;
+    db->g.on = gw; db->g.shift = gw_shift; db->g.off = d_gwoff; db->g.blk = d_gwblk;
     db->d.tgt2tax = db->tgt2tax; db->d.n_targets = desc->n_targets;
     db->d.k = desc->k; db->d.s = desc->sketch_size; db->d.winlen = desc->winlen; db->d.winstride = desc->winstride;
     db->d.tgt_winstride = desc->tgt_winstride ? desc->tgt_winstride : desc->winstride;
@@ -1811,12 +1817,12 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     if (const char* e = getenv("MCQ_BLOCK_WGS")) ws->n_block_wgs = std::max(1, atoi(e));      // tuning knob
     ws->ev_used = new std::vector<TimedLaunch>();
     ws->ev_free = new std::vector<TimedLaunch>();
-    ws->cap_wave = db->d.gw ? resident_blocks(k_query_wave<u32, 512, false, false, true>, 256, db->device)
-                 : db->d.compact ? resident_blocks(k_query_wave<u32, 512, false, false, false>, 256, db->device)
-                                 : resident_blocks(k_query_wave<u64, 512, false, false, false>, 256, db->device);
-    ws->cap_wave16 = db->d.gw ? resident_blocks(k_query_wave16<false, false, true>, 256, db->device)
-                              : resident_blocks(k_query_wave16<false, false, false>, 256, db->device);
-    ws->cap_reduce16 = db->d.gw ? resident_blocks(k_reduce_wave16<true>, 256, db->device) : resident_blocks(k_reduce_wave16<false>, 256, db->device);
+    ws->cap_wave = db->g.on ? resident_blocks(k_query_wave<u32, 512, false, false, true, 2>, 256, db->device)
+                 : db->d.compact ? resident_blocks(k_query_wave<u32, 512, false, false, false, 2>, 256, db->device)
+                                 : resident_blocks(k_query_wave<u64, 512, false, false, false, 2>, 256, db->device);
+    ws->cap_wave16 = db->g.on ? resident_blocks(k_query_wave16<false, false, true, 2>, 256, db->device)
+                              : resident_blocks(k_query_wave16<false, false, false, 2>, 256, db->device);
+    ws->cap_reduce16 = db->g.on ? resident_blocks(k_reduce_wave16<true>, 256, db->device) : resident_blocks(k_reduce_wave16<false>, 256, db->device);
     const u64 nb = (u64)ws->n_block_wgs;
 #define WSCHK(expr) HIPCHK_OR(expr, (void)mcq_ws_destroy(ws))
     WSCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
@@ -1972,28 +1978,29 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     LaunchTimer tm(ws, st);
     int rc = tm.begin(); if (rc) return rc;
     const bool tap = dbg.mode != 0;     // mcq_debug_matches: the instantiations that also write the sorted match lists
-    const bool gw = db->d.gw != 0;      // 32-bit locations in the global-window form: the GW instantiations
-#define MCQ_LAUNCH_WAVE(KT, TAPV, SHV, GWV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV, SHV, GWV>), dim3(grid), dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg, sh)
-#define MCQ_LAUNCH_WAVE32(TAPV, SHV) do { if (gw) MCQ_LAUNCH_WAVE(u32, TAPV, SHV, true); else MCQ_LAUNCH_WAVE(u32, TAPV, SHV, false); } while (0)
-    if (shp)                { if (db->d.compact) MCQ_LAUNCH_WAVE32(false, true); else MCQ_LAUNCH_WAVE(u64, false, true, false); }
-    else if (db->d.compact) { if (tap) MCQ_LAUNCH_WAVE32(true, false); else MCQ_LAUNCH_WAVE32(false, false); }
-    else                    { if (tap) MCQ_LAUNCH_WAVE(u64, true, false, false); else MCQ_LAUNCH_WAVE(u64, false, false, false); }
-#undef MCQ_LAUNCH_WAVE32
+    const bool gw = db->g.on != 0;      // 32-bit locations in the global-window form: the GW instantiations
+    const bool b64 = db->d.bsh != 0;    // table layout: the wave kernels are instantiated per layout (taps and the sharded home side: run-time / unused)
+#define MCQ_LAUNCH_WAVE(KT, TAPV, SHV, GWV, BSHV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV, SHV, GWV, BSHV>), dim3(grid), dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg, sh, db->g)
+#define MCQ_LAUNCH_WAVE_L(KT, GWV) do { if (b64) MCQ_LAUNCH_WAVE(KT, false, false, GWV, 2); else MCQ_LAUNCH_WAVE(KT, false, false, GWV, 0); } while (0)
+    if (shp)                { if (!db->d.compact) MCQ_LAUNCH_WAVE(u64, false, true, false, -1); else if (gw) MCQ_LAUNCH_WAVE(u32, false, true, true, -1); else MCQ_LAUNCH_WAVE(u32, false, true, false, -1); }
+    else if (tap)           { if (!db->d.compact) MCQ_LAUNCH_WAVE(u64, true, false, false, -1); else if (gw) MCQ_LAUNCH_WAVE(u32, true, false, true, -1); else MCQ_LAUNCH_WAVE(u32, true, false, false, -1); }
+    else if (db->d.compact) { if (gw) MCQ_LAUNCH_WAVE_L(u32, true); else MCQ_LAUNCH_WAVE_L(u32, false); }
+    else                    MCQ_LAUNCH_WAVE_L(u64, false);
+#undef MCQ_LAUNCH_WAVE_L
 #undef MCQ_LAUNCH_WAVE
     rc = tm.mark(); if (rc) return rc;
     if (db->d.compact) {   // second wave stage (back queue); no queue for 64-bit keys
         const dim3 g16(grid_for(ws->cap_wave16, want));
-#define MCQ_LAUNCH_WAVE16(TAPV, SHV) do { \
-        if (gw) hipLaunchKernelGGL((k_query_wave16<TAPV, SHV, true>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh); \
-        else    hipLaunchKernelGGL((k_query_wave16<TAPV, SHV, false>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh); } while (0)
-        if (shp)      MCQ_LAUNCH_WAVE16(false, true);
-        else if (tap) MCQ_LAUNCH_WAVE16(true, false);
-        else          MCQ_LAUNCH_WAVE16(false, false);
+#define MCQ_LAUNCH_WAVE16(TAPV, SHV, GWV, BSHV) hipLaunchKernelGGL((k_query_wave16<TAPV, SHV, GWV, BSHV>), g16, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, dbg, sh, db->g)
+        if (shp)      { if (gw) MCQ_LAUNCH_WAVE16(false, true, true, -1); else MCQ_LAUNCH_WAVE16(false, true, false, -1); }
+        else if (tap) { if (gw) MCQ_LAUNCH_WAVE16(true, false, true, -1); else MCQ_LAUNCH_WAVE16(true, false, false, -1); }
+        else if (gw)  { if (b64) MCQ_LAUNCH_WAVE16(false, false, true, 2); else MCQ_LAUNCH_WAVE16(false, false, true, 0); }
+        else          { if (b64) MCQ_LAUNCH_WAVE16(false, false, false, 2); else MCQ_LAUNCH_WAVE16(false, false, false, 0); }
 #undef MCQ_LAUNCH_WAVE16
     }
     rc = tm.mark(); if (rc) return rc;
 #define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV, SHV, GWV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV, SHV, GWV>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, D, b, od, o, ws->ctr, \
-                                                             (const u32*)ws->ovf_list, ws->sc, dbg, sh)
+                                                             (const u32*)ws->ovf_list, ws->sc, dbg, sh, db->g)
 #define MCQ_LAUNCH_BLOCK2(KT, LC, NTH, SHV, GWV) do { if (od.big) MCQ_LAUNCH_BLOCK(KT, LC, NTH, true, SHV, GWV); else MCQ_LAUNCH_BLOCK(KT, LC, NTH, false, SHV, GWV); } while (0)
 #define MCQ_LAUNCH_BLOCK32(SHV) do { if (gw) MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, SHV, true); else MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, SHV, false); } while (0)
     if (db->d.compact) { if (shp) MCQ_LAUNCH_BLOCK32(true); else MCQ_LAUNCH_BLOCK32(false); }
@@ -2237,7 +2244,7 @@ extern "C" int mcq_db_layout_get(const mcq_db* db, mcq_db_layout* out) {
     if (!db || !out) return fail(MCQ_E_ARG, "null argument");
     memset(out, 0, sizeof(*out));
     out->loc_bytes = db->d.compact ? 4u : 8u;
-    out->loc_format = db->d.gw ? MCQ_LOC_GLOBAL_WINDOW : db->d.compact ? MCQ_LOC_FIELDS32 : MCQ_LOC_FIELDS64;
+    out->loc_format = db->g.on ? MCQ_LOC_GLOBAL_WINDOW : db->d.compact ? MCQ_LOC_FIELDS32 : MCQ_LOC_FIELDS64;
     out->win_bits = db->d.wb; out->bucket_bytes = db->bucket_bytes; out->slots_per_key = db->slots_per_key;
     out->n_slots = db->nslots; out->n_keys = db->n_keys_local; out->n_locs = db->n_locs_local; out->n_ext_locs = db->n_ext;
     out->n_windows = db->n_windows; out->bytes = db->bytes;
@@ -2320,26 +2327,26 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     rc = tm.begin(); if (rc) return rc;
 #define MCQ_REDUCE32(GWV) do { \
         hipLaunchKernelGGL((k_reduce_wave<u32, kLcapWave, GWV>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list, \
-                           n_queries, loc_off, (const u32*)locs, query_len); \
+                           n_queries, loc_off, (const u32*)locs, query_len, db->g); \
         rc = tm.mark(); if (rc) return rc; \
         hipLaunchKernelGGL(k_reduce_wave16<GWV>, dim3(grid_for(ws->cap_reduce16, (n_queries + 3) / 4)), dim3(256), 0, st, db->d, od, o, ws->ctr, \
-                           (const u32*)ws->ovf_list, n_queries, loc_off, (const u32*)locs, query_len); \
+                           (const u32*)ws->ovf_list, n_queries, loc_off, (const u32*)locs, query_len, db->g); \
         rc = tm.mark(); if (rc) return rc; \
         if (od.big) hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, true, GWV>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr, \
-                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len); \
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len, db->g); \
         else        hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, false, GWV>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr, \
-                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len); } while (0)
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len, db->g); } while (0)
     if (db->d.compact) {
-        if (db->d.gw) MCQ_REDUCE32(true); else MCQ_REDUCE32(false);
+        if (db->g.on) MCQ_REDUCE32(true); else MCQ_REDUCE32(false);
     } else {
         hipLaunchKernelGGL((k_reduce_wave<u64, kLcapWave>), dim3(grid), dim3(256), 0, st, db->d, od, o, ws->ctr, ws->ovf_list,
-                           n_queries, loc_off, (const u64*)locs, query_len);
+                           n_queries, loc_off, (const u64*)locs, query_len, db->g);
         rc = tm.mark(); if (rc) return rc;
         rc = tm.mark(); if (rc) return rc;
         if (od.big) hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, true>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
-                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len, db->g);
         else        hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, false>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
-                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len);
+                                       (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len, db->g);
     }
 #undef MCQ_REDUCE32
     rc = tm.end(); if (rc) return rc;
