@@ -181,6 +181,18 @@ typedef struct {
 /* replaces sketch_database::read -> hash_multimap::deserialize (the table build) */
 int mcq_db_create(const mcq_db_desc* desc, mcq_db** out);
 int mcq_db_destroy(mcq_db* db);
+/* The same for a table that is larger than the memory for its one-piece description (RefSeq scale: 1.7e10 locations are
+ * 136 GB as 64-bit words): handed over in parts, e.g. one per feature-hash range (mcq_build_parts makes them) or one per
+ * shard file of the reference (src/sketch_database.h:858-999, after mapping (tgt, win) to tgt_windows' prefix sums + win).
+ * Device memory only (MCQ_DEVICE_PTRS).  desc->keys / list_off / locs / n_keys / n_locs are ignored, desc->tgt_windows is
+ * required: part locations are global-window words, and the handle keeps that form.  A key may appear in one part only. */
+typedef struct {
+    uint64_t n_keys, n_locs;
+    const uint32_t* keys;       /* [n_keys]                                                             */
+    const uint32_t* list_len;   /* [n_keys] lengths of the lists, which follow one another in `locs`    */
+    const uint32_t* locs;       /* [n_locs] global window indices, every list ascending                 */
+} mcq_db_part;
+int mcq_db_create_parts(const mcq_db_desc* desc, const mcq_db_part* parts, uint32_t n_parts, mcq_db** out);
 /* bytes of HBM held by the handle */
 uint64_t mcq_db_bytes(const mcq_db* db);
 
@@ -390,6 +402,18 @@ int mcq_table_info(const mcq_table* t, uint64_t* n_keys, uint64_t* n_locs, const
 int mcq_table_free(mcq_table* t);
 /* mcq_build_table + mcq_db_create in one call; the queryable handle is the only thing left in HBM */
 int mcq_db_build(const mcq_build_desc* desc, mcq_db** out);
+/* The build in parts, for tables whose one-piece temporaries do not fit the GPU (RefSeq scale: ~60 B per feature slot of
+ * the sequences; mcq_db_build takes this way by itself then).  The features are cut into ranges of h2(feature) -- sub-ranges
+ * of shard `shard_id` of `n_shards` when the table is sharded: only that shard's features are built -- and every range is
+ * built on its own from the sequences (device memory only): what stays is the table in the form the query side stores, keys
+ * + list lengths + 32-bit global-window words.  Same lists as mcq_build_table (per (feature, rank) limit, rank merge,
+ * -remove-overpopulated-features).  The caller may release the sequences before mcq_db_from_parts makes the handle.       */
+typedef struct mcq_parts mcq_parts;
+int mcq_build_parts(const mcq_build_desc* desc, mcq_parts** out);
+int mcq_parts_info(const mcq_parts* parts, uint64_t* n_keys, uint64_t* n_locs, uint64_t* n_windows, uint32_t* n_parts, uint64_t* bytes);
+/* tgt2tax: [n_targets] host, or device with MCQ_DEVICE_PTRS in flags; flags also takes MCQ_DB_SLOTS_16 / MCQ_DB_BUCKETS_64 */
+int mcq_db_from_parts(const mcq_parts* parts, const uint32_t* tgt2tax, uint32_t n_shards, uint32_t shard_id, uint32_t flags, mcq_db** out);
+int mcq_parts_free(mcq_parts* parts);
 const char* mcq_build_last_error(void);
 
 /* ---- debug / parity taps ------------------------------------------------------------

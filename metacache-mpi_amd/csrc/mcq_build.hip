@@ -192,6 +192,96 @@ extern "C" int mcq_table_info(const mcq_table* t, uint64_t* n_keys, uint64_t* n_
     return MCQ_OK;
 }
 
+// ---- the pipeline behind both forms of the build -----------------------------------------------------------------
+// (feature * P + rank, global window) pairs in (target, window) order -> stable sort by key, first max_locs of every
+// (feature, rank) group, lists of a feature merged over the ranks into (target, window) order, optionally
+// -remove-overpopulated-features; leaves fw[0..n_kept) = (feature << 32) | global window sorted, head[i] = 1 where a
+// feature's list starts, kid[i] = exclusive count of heads, n_keys.  Takes over key / val (both from tmpbuf).
+struct Lists { u64* fw = nullptr; u32* head = nullptr; u64* kid = nullptr; u64 n_kept = 0, n_keys = 0; };
+template <class Phase>
+static int sort_truncate(Scratch& tmpbuf, u64* key, u32* val, u64 n, u32 P, u32 max_locs, bool remove_overpop, Lists& L, Phase phase) {
+    u64* key2 = nullptr; u32* val2 = nullptr;
+    BCHK(tmpbuf.get(&key2, (n ? n : 1) * 8)); BCHK(tmpbuf.get(&val2, (n ? n : 1) * 4));
+    if (n) {
+        // keys are feature * P + rank < 2^32 * P: only these bits take part in the sort
+        u32 key_bits = 32; while (key_bits < 64 && (((u64)P - 1) >> (key_bits - 32))) ++key_bits;
+        size_t tmp = 0;
+        BCHK(rocprim::radix_sort_pairs(nullptr, tmp, key, key2, val, val2, n, 0, key_bits));
+        void* t = nullptr; BCHK(tmpbuf.get(&t, tmp ? tmp : 1));
+        BCHK(rocprim::radix_sort_pairs(t, tmp, key, key2, val, val2, n, 0, key_bits));
+        BCHK(hipDeviceSynchronize());
+        tmpbuf.put(t);
+    }
+    tmpbuf.put(key); tmpbuf.put(val);
+    phase("sort by (feature, rank)");
+
+    // rank inside each group, keep the first max_locs
+    u32 *head = nullptr, *keep = nullptr; u64 *gid = nullptr, *gstart = nullptr, *pos = nullptr;
+    BCHK(tmpbuf.get(&head, (n ? n : 1) * 4)); BCHK(tmpbuf.get(&keep, (n ? n : 1) * 4));
+    BCHK(tmpbuf.get(&gid, (n ? n : 1) * 8)); BCHK(tmpbuf.get(&pos, (n ? n : 1) * 8));
+    u64 n_groups = 0, n_kept = 0;
+    if (n) hipLaunchKernelGGL(k_heads, grid_for(n), dim3(TB), 0, 0, key2, n, head);
+    MCHK(excl_scan(head, gid, n, &n_groups));
+    BCHK(tmpbuf.get(&gstart, (n_groups ? n_groups : 1) * 8));
+    if (n) {
+        hipLaunchKernelGGL(k_group_start, grid_for(n), dim3(TB), 0, 0, head, gid, n, gstart);
+        hipLaunchKernelGGL(k_keep, grid_for(n), dim3(TB), 0, 0, key2, head, gid, gstart, n, max_locs, keep);
+    }
+    MCHK(excl_scan(keep, pos, n, &n_kept));
+    u64* fw = nullptr;
+    BCHK(tmpbuf.get(&fw, (n_kept ? n_kept : 1) * 8));
+    if (n) hipLaunchKernelGGL(k_compact, grid_for(n), dim3(TB), 0, 0, key2, val2, keep, pos, n, P, fw);
+    BCHK(hipDeviceSynchronize());
+    tmpbuf.put(key2); tmpbuf.put(val2); tmpbuf.put(keep); tmpbuf.put(gid); tmpbuf.put(gstart); tmpbuf.put(pos);
+    phase("truncate to max_locs");
+
+    // merge the virtual ranks' lists of a feature into (target, window) order
+    if (P > 1 && n_kept) {
+        u64* fw2 = nullptr; BCHK(tmpbuf.get(&fw2, n_kept * 8));
+        size_t tmp = 0;
+        BCHK(rocprim::radix_sort_keys(nullptr, tmp, fw, fw2, n_kept, 0, 64));
+        void* t = nullptr; BCHK(tmpbuf.get(&t, tmp ? tmp : 1));
+        BCHK(rocprim::radix_sort_keys(t, tmp, fw, fw2, n_kept, 0, 64));
+        BCHK(hipDeviceSynchronize());
+        tmpbuf.put(t); tmpbuf.put(fw);
+        fw = fw2;
+    }
+    phase("merge ranks");
+    u64* kid = nullptr; u64 n_keys = 0;
+    tmpbuf.put(head);
+    BCHK(tmpbuf.get(&head, (n_kept ? n_kept : 1) * 4)); BCHK(tmpbuf.get(&kid, (n_kept ? n_kept : 1) * 8));
+    if (n_kept) hipLaunchKernelGGL(k_feat_heads, grid_for(n_kept), dim3(TB), 0, 0, fw, n_kept, head);
+    MCHK(excl_scan(head, kid, n_kept, &n_keys));
+    if (remove_overpop && n_kept && max_locs > 1) {
+        u64 *first = nullptr, *pos2 = nullptr, *fw2 = nullptr; u32* keep2 = nullptr; u64 n2 = 0;
+        BCHK(tmpbuf.get(&first, (n_keys ? n_keys : 1) * 8)); BCHK(tmpbuf.get(&pos2, n_kept * 8)); BCHK(tmpbuf.get(&keep2, n_kept * 4));
+        hipLaunchKernelGGL(k_first_of_key, grid_for(n_kept), dim3(TB), 0, 0, head, kid, n_kept, first);
+        hipLaunchKernelGGL(k_keep_small, grid_for(n_kept), dim3(TB), 0, 0, fw, head, kid, first, n_kept, n_keys, (u64)max_locs - 1, keep2);
+        MCHK(excl_scan(keep2, pos2, n_kept, &n2));
+        BCHK(tmpbuf.get(&fw2, (n2 ? n2 : 1) * 8));
+        hipLaunchKernelGGL(k_compact_u64, grid_for(n_kept), dim3(TB), 0, 0, fw, keep2, pos2, n_kept, fw2);
+        BCHK(hipDeviceSynchronize());
+        tmpbuf.put(first); tmpbuf.put(pos2); tmpbuf.put(keep2); tmpbuf.put(fw);
+        fw = fw2; n_kept = n2;
+        if (n_kept) hipLaunchKernelGGL(k_feat_heads, grid_for(n_kept), dim3(TB), 0, 0, fw, n_kept, head);
+        MCHK(excl_scan(head, kid, n_kept, &n_keys));
+    }
+    L.fw = fw; L.head = head; L.kid = kid; L.n_kept = n_kept; L.n_keys = n_keys;
+    return MCQ_OK;
+}
+
+struct PhaseTrace {
+    bool on; std::chrono::steady_clock::time_point last;
+    PhaseTrace() : on(getenv("MCQ_BUILD_TRACE") != nullptr), last(std::chrono::steady_clock::now()) {}
+    void operator()(const char* name) {        // MCQ_BUILD_TRACE=1: phase times on stderr (adds a device synchronisation per phase)
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[mcq_build] %-28s %8.3f s\n", name, std::chrono::duration<double>(now - last).count());
+        last = now;
+    }
+};
+
 extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     if (!d || !out || !d->seq_off || (d->n_targets && !d->bases)) return bfail(MCQ_E_ARG, "null argument");
     if (d->n_targets < 1) return bfail(MCQ_E_ARG, "no targets");
@@ -202,16 +292,7 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     BCHK(tmpbuf.init(d->device));
     const bool dev = (d->flags & MCQ_DEVICE_PTRS) != 0;
     const u32 nt = d->n_targets;
-    // MCQ_BUILD_TRACE=1: phase times on stderr (diagnostic; adds a device synchronisation per phase)
-    const bool trace = getenv("MCQ_BUILD_TRACE") != nullptr;
-    auto t_last = std::chrono::steady_clock::now();
-    auto phase = [&](const char* name) {
-        if (!trace) return;
-        (void)hipDeviceSynchronize();
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[mcq_build] %-28s %8.3f s\n", name, std::chrono::duration<double>(now - t_last).count());
-        t_last = now;
-    };
+    PhaseTrace phase;
 
     // inputs on the device
     const char* bases = d->bases; const u64* seq_off = d->seq_off;
@@ -250,92 +331,23 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     tmpbuf.put(nfeat);
     phase("windows + sketches");
 
-    // (feature * P + rank, global window), stable sort: groups in (target, window) order
-    u64 *key = nullptr, *key2 = nullptr; u32 *val = nullptr, *val2 = nullptr;
-    BCHK(tmpbuf.get(&key, (n ? n : 1) * 8)); BCHK(tmpbuf.get(&key2, (n ? n : 1) * 8));
-    BCHK(tmpbuf.get(&val, (n ? n : 1) * 4)); BCHK(tmpbuf.get(&val2, (n ? n : 1) * 4));
-    phase("  (allocations)");
+    // (feature * P + rank, global window) in window order
+    u64* key = nullptr; u32* val = nullptr;
+    BCHK(tmpbuf.get(&key, (n ? n : 1) * 8)); BCHK(tmpbuf.get(&val, (n ? n : 1) * 4));
     if (n) hipLaunchKernelGGL(k_make_pairs, grid_for(n), dim3(TB), 0, 0, feat, n, s, T->win_off, nt, P, key, val);
-    phase("  (k_make_pairs)");
     tmpbuf.put(feat);
     phase("pairs");
-    if (n) {
-        // keys are feature * P + rank < 2^32 * P: only these bits take part in the sort
-        u32 key_bits = 32; while (key_bits < 64 && (((u64)P - 1) >> (key_bits - 32))) ++key_bits;
-        size_t tmp = 0;
-        BCHK(rocprim::radix_sort_pairs(nullptr, tmp, key, key2, val, val2, n, 0, key_bits));
-        void* t = nullptr; BCHK(tmpbuf.get(&t, tmp ? tmp : 1));
-        BCHK(rocprim::radix_sort_pairs(t, tmp, key, key2, val, val2, n, 0, key_bits));
-        BCHK(hipDeviceSynchronize());
-        tmpbuf.put(t);
-    }
-    tmpbuf.put(key); tmpbuf.put(val);
-    phase("sort by (feature, rank)");
-
-    // rank inside each group, keep the first max_locs
-    u32 *head = nullptr, *keep = nullptr; u64 *gid = nullptr, *gstart = nullptr, *pos = nullptr;
-    BCHK(tmpbuf.get(&head, (n ? n : 1) * 4)); BCHK(tmpbuf.get(&keep, (n ? n : 1) * 4));
-    BCHK(tmpbuf.get(&gid, (n ? n : 1) * 8)); BCHK(tmpbuf.get(&pos, (n ? n : 1) * 8));
-    u64 n_groups = 0, n_kept = 0;
-    if (n) hipLaunchKernelGGL(k_heads, grid_for(n), dim3(TB), 0, 0, key2, n, head);
-    phase("  (k_heads)");
-    MCHK(excl_scan(head, gid, n, &n_groups));
-    phase("  (scan heads)");
-    BCHK(tmpbuf.get(&gstart, (n_groups ? n_groups : 1) * 8));
-    if (n) {
-        hipLaunchKernelGGL(k_group_start, grid_for(n), dim3(TB), 0, 0, head, gid, n, gstart);
-        hipLaunchKernelGGL(k_keep, grid_for(n), dim3(TB), 0, 0, key2, head, gid, gstart, n, max_locs, keep);
-    }
-    phase("  (k_group_start, k_keep)");
-    MCHK(excl_scan(keep, pos, n, &n_kept));
-    phase("  (scan keep)");
-    u64* fw = nullptr;
-    BCHK(tmpbuf.get(&fw, (n_kept ? n_kept : 1) * 8));
-    if (n) hipLaunchKernelGGL(k_compact, grid_for(n), dim3(TB), 0, 0, key2, val2, keep, pos, n, P, fw);
-    BCHK(hipDeviceSynchronize());
-    tmpbuf.put(key2); tmpbuf.put(val2); tmpbuf.put(keep); tmpbuf.put(gid); tmpbuf.put(gstart); tmpbuf.put(pos);
-    phase("truncate to max_locs");
-
-    // merge the virtual ranks' lists of a feature into (target, window) order
-    if (P > 1 && n_kept) {
-        u64* fw2 = nullptr; BCHK(tmpbuf.get(&fw2, n_kept * 8));
-        size_t tmp = 0;
-        BCHK(rocprim::radix_sort_keys(nullptr, tmp, fw, fw2, n_kept, 0, 64));
-        void* t = nullptr; BCHK(tmpbuf.get(&t, tmp ? tmp : 1));
-        BCHK(rocprim::radix_sort_keys(t, tmp, fw, fw2, n_kept, 0, 64));
-        BCHK(hipDeviceSynchronize());
-        tmpbuf.put(t); tmpbuf.put(fw);
-        fw = fw2;
-    }
-    phase("merge ranks");
+    Lists L;
+    MCHK(sort_truncate(tmpbuf, key, val, n, P, max_locs, (d->flags & MCQ_BUILD_REMOVE_OVERPOPULATED) != 0, L, phase));
     // keys, offsets, (target, window) locations
-    u64* kid = nullptr; u64 n_keys = 0;
-    tmpbuf.put(head);
-    BCHK(tmpbuf.get(&head, (n_kept ? n_kept : 1) * 4)); BCHK(tmpbuf.get(&kid, (n_kept ? n_kept : 1) * 8));
-    if (n_kept) hipLaunchKernelGGL(k_feat_heads, grid_for(n_kept), dim3(TB), 0, 0, fw, n_kept, head);
-    MCHK(excl_scan(head, kid, n_kept, &n_keys));
-    if ((d->flags & MCQ_BUILD_REMOVE_OVERPOPULATED) && n_kept && max_locs > 1) {
-        u64 *first = nullptr, *pos2 = nullptr, *fw2 = nullptr; u32* keep2 = nullptr; u64 n2 = 0;
-        BCHK(tmpbuf.get(&first, (n_keys ? n_keys : 1) * 8)); BCHK(tmpbuf.get(&pos2, n_kept * 8)); BCHK(tmpbuf.get(&keep2, n_kept * 4));
-        hipLaunchKernelGGL(k_first_of_key, grid_for(n_kept), dim3(TB), 0, 0, head, kid, n_kept, first);
-        hipLaunchKernelGGL(k_keep_small, grid_for(n_kept), dim3(TB), 0, 0, fw, head, kid, first, n_kept, n_keys, (u64)max_locs - 1, keep2);
-        MCHK(excl_scan(keep2, pos2, n_kept, &n2));
-        BCHK(tmpbuf.get(&fw2, (n2 ? n2 : 1) * 8));
-        hipLaunchKernelGGL(k_compact_u64, grid_for(n_kept), dim3(TB), 0, 0, fw, keep2, pos2, n_kept, fw2);
-        BCHK(hipDeviceSynchronize());
-        tmpbuf.put(first); tmpbuf.put(pos2); tmpbuf.put(keep2); tmpbuf.put(fw);
-        fw = fw2; n_kept = n2;
-        if (n_kept) hipLaunchKernelGGL(k_feat_heads, grid_for(n_kept), dim3(TB), 0, 0, fw, n_kept, head);
-        MCHK(excl_scan(head, kid, n_kept, &n_keys));
-    }
-    T->n_keys = n_keys; T->n_locs = n_kept;
-    BCHK(hipMalloc(&T->keys, (n_keys ? n_keys : 1) * 4)); BCHK(hipMalloc(&T->list_off, (n_keys + 1) * 8));
-    BCHK(hipMalloc(&T->locs, (n_kept ? n_kept : 1) * 8));
-    if (n_kept) hipLaunchKernelGGL(k_emit, grid_for(n_kept), dim3(TB), 0, 0, fw, head, kid, n_kept, n_keys, T->win_off, nt, T->keys, T->list_off, T->locs);
+    T->n_keys = L.n_keys; T->n_locs = L.n_kept;
+    BCHK(hipMalloc(&T->keys, (L.n_keys ? L.n_keys : 1) * 4)); BCHK(hipMalloc(&T->list_off, (L.n_keys + 1) * 8));
+    BCHK(hipMalloc(&T->locs, (L.n_kept ? L.n_kept : 1) * 8));
+    if (L.n_kept) hipLaunchKernelGGL(k_emit, grid_for(L.n_kept), dim3(TB), 0, 0, L.fw, L.head, L.kid, L.n_kept, L.n_keys, T->win_off, nt, T->keys, T->list_off, T->locs);
     else BCHK(hipMemset(T->list_off, 0, 8));
     BCHK(hipDeviceSynchronize());
     BCHK(hipGetLastError());
-    tmpbuf.put(fw); tmpbuf.put(head); tmpbuf.put(kid);
+    tmpbuf.put(L.fw); tmpbuf.put(L.head); tmpbuf.put(L.kid);
     phase("emit keys / offsets / locations");
     if (t_bases) tmpbuf.put(t_bases);
     if (t_off) tmpbuf.put(t_off);
@@ -344,8 +356,247 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
     return MCQ_OK;
 }
 
+// ---- the build in parts: tables whose one-piece temporaries do not fit (RefSeq scale) -------------------------------
+// The features are cut into R ranges of h2(feature) (sub-ranges of the shard's range when the table is sharded: the same
+// hash as mcq_owner, so a part never crosses a shard).  Pass p sketches every target again (the sketch is the cheap part:
+// ~40 Gbp/s), in chunks of whole targets, keeps the features of range p -- flags, scan, scatter: (target, window) order is
+// kept, which the stable sort relies on -- and runs the pipeline above on them; what is left of a pass is its part of the
+// table in the form the query side stores: keys, list lengths, 32-bit global-window words.
+struct mcq_parts {
+    int device; u32 n_targets;
+    u32 k, s, winlen, winstride;
+    u64 n_windows;
+    u32* tgt_windows;         // device [n_targets]
+    std::vector<mcq_db_part> parts;
+    u64 n_keys, n_locs, bytes;
+};
+namespace {
+__device__ __forceinline__ u32 tmh_dev(u32 x) {        // thomas_mueller_hash (src/hash_int.h:39-45), as mcq_owner
+    x = ((x >> 16) ^ x) * 0x45d9f3bu; x = ((x >> 16) ^ x) * 0x45d9f3bu; return (x >> 16) ^ x;
+}
+__global__ void k_part_flags(const u32* feat, u64 n, u32 n_ranges, u32 range, u32* flag) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u32 f = feat[i];
+        flag[i] = (f != 0xFFFFFFFFu && (u32)(((u64)tmh_dev(f) * n_ranges) >> 32) == range) ? 1u : 0u;
+    }
+}
+// chunk slot i = window w0 + i / s; kept slots go to key / val at cursor + pos[i]
+__global__ void k_part_scatter(const u32* feat, const u32* flag, const u64* pos, u64 n, u32 s, u64 w0, const u64* win_off, u32 n_targets, u32 P,
+                               u64 cursor, u64 cap, u64* key, u32* val) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (!flag[i]) continue;
+        const u64 o = cursor + pos[i];
+        if (o >= cap) continue;                       // (reported by the host from the counts)
+        const u64 w = w0 + i / s;
+        const u32 t = P > 1 ? target_of(win_off, n_targets, w) : 0u;
+        key[o] = (u64)feat[i] * P + (P > 1 ? t % P : 0u);
+        val[o] = (u32)w;
+    }
+}
+__global__ void k_shift_off(const u64* in, u64 n, u64 base, u64* out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] - base;
+}
+__global__ void k_windows_of(const u64* win_off, u32 n_targets, u32* out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_targets) out[i] = (u32)(win_off[i + 1] - win_off[i]);
+}
+// part arrays from the sorted lists: the key of every list and the words themselves (lengths: k_part_first + k_part_len)
+__global__ void k_emit_part(const u64* fw, const u32* head, const u64* kid, u64 n, u32* keys, u32* locs) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        locs[i] = (u32)fw[i];
+        if (head[i]) keys[kid[i]] = (u32)(fw[i] >> 32);
+    }
+}
+__global__ void k_part_first(const u32* head, const u64* kid, u64 n, u64* first) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) if (head[i]) first[kid[i]] = i;
+}
+__global__ void k_part_len(const u64* first, u64 n_keys, u64 n, u32* list_len) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_keys) list_len[i] = (u32)(((i + 1 < n_keys) ? first[i + 1] : n) - first[i]);
+}
+}  // namespace
+
+extern "C" int mcq_parts_free(mcq_parts* p) {
+    if (!p) return MCQ_OK;
+    (void)hipSetDevice(p->device);
+    for (auto& q : p->parts) { (void)hipFree((void*)q.keys); (void)hipFree((void*)q.list_len); (void)hipFree((void*)q.locs); }
+    (void)hipFree(p->tgt_windows);
+    delete p;
+    return MCQ_OK;
+}
+extern "C" int mcq_parts_info(const mcq_parts* p, uint64_t* n_keys, uint64_t* n_locs, uint64_t* n_windows, uint32_t* n_parts, uint64_t* bytes) {
+    if (!p) return bfail(MCQ_E_ARG, "null argument");
+    if (n_keys) *n_keys = p->n_keys;
+    if (n_locs) *n_locs = p->n_locs;
+    if (n_windows) *n_windows = p->n_windows;
+    if (n_parts) *n_parts = (u32)p->parts.size();
+    if (bytes) *bytes = p->bytes;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_build_parts(const mcq_build_desc* d, mcq_parts** out) {
+    if (!d || !out || !d->seq_off || (d->n_targets && !d->bases)) return bfail(MCQ_E_ARG, "null argument");
+    if (d->n_targets < 1) return bfail(MCQ_E_ARG, "no targets");
+    if (!(d->flags & MCQ_DEVICE_PTRS)) return bfail(MCQ_E_ARG, "mcq_build_parts takes device pointers (the sequences of such a table do not fit a staging copy)");
+    const u32 P = d->emulate_ranks ? d->emulate_ranks : 1;
+    const u32 max_locs = d->max_locs ? d->max_locs : 254;
+    const u32 n_shards = d->n_shards ? d->n_shards : 1;
+    if (d->shard_id >= n_shards) return bfail(MCQ_E_ARG, "shard_id >= n_shards");
+    BCHK(hipSetDevice(d->device));
+    Scratch tmpbuf;
+    BCHK(tmpbuf.init(d->device));
+    const u32 nt = d->n_targets, s = d->sketch_size;
+    PhaseTrace phase;
+    mcq_db_desc sd; std::memset(&sd, 0, sizeof(sd));
+    sd.k = d->k; sd.sketch_size = d->sketch_size; sd.winlen = d->winlen; sd.winstride = d->winstride;
+    const u64 zero = 0; sd.list_off = &zero; sd.n_shards = 1; sd.device = d->device;
+    mcq_db* sk = nullptr;
+    if (mcq_db_create(&sd, &sk) != MCQ_OK) return bfail(MCQ_E_ARG, std::string("sketch parameters: ") + mcq_last_error());
+    struct SkGuard { mcq_db* h; ~SkGuard() { mcq_db_destroy(h); } } skg{sk};
+
+    mcq_parts* R = new mcq_parts();
+    R->device = d->device; R->n_targets = nt; R->k = d->k; R->s = s; R->winlen = d->winlen; R->winstride = d->winstride;
+    R->n_windows = 0; R->tgt_windows = nullptr; R->n_keys = R->n_locs = R->bytes = 0;
+    struct PartsGuard { mcq_parts*& p; ~PartsGuard() { if (p) mcq_parts_free(p); } } guard{R};
+
+    // windows of every target (device + host copy: the chunks are cut at target boundaries)
+    u64* win_off = nullptr;
+    BCHK(tmpbuf.get(&win_off, (u64)(nt + 1) * 8));
+    mcq_batch b; b.n_seqs = nt; b.bases = d->bases; b.seq_off = d->seq_off; b.paired = 0; b.flags = MCQ_DEVICE_PTRS; b.n_bases = 0;
+    MCHK(mcq_count_windows(sk, &b, win_off, nullptr));
+    std::vector<u64> h_win(nt + 1);
+    BCHK(hipMemcpy(h_win.data(), win_off, (u64)(nt + 1) * 8, hipMemcpyDeviceToHost));
+    const u64 n_win = h_win[nt];
+    if (n_win >= 0xFFFFFFFFull) return bfail(MCQ_E_UNSUPPORTED, "2^32 - 1 windows or more");
+    R->n_windows = n_win;
+    BCHK(hipMalloc(&R->tgt_windows, (u64)nt * 4));
+    hipLaunchKernelGGL(k_windows_of, dim3((nt + TB - 1) / TB), dim3(TB), 0, 0, (const u64*)win_off, nt, R->tgt_windows);
+    phase("windows");
+
+    // chunks of whole targets for the sketch (MCQ_BUILD_CHUNK_WINDOWS: tuning knob / test hook)
+    u64 chunk_win = 1ull << 24;
+    if (const char* e = getenv("MCQ_BUILD_CHUNK_WINDOWS")) chunk_win = std::max<u64>(1, strtoull(e, nullptr, 10));
+    std::vector<u32> cut{0};
+    u64 largest = 0;
+    for (u32 t = 0; t < nt;) {
+        u32 e = t + 1;
+        while (e < nt && h_win[e + 1] - h_win[t] <= chunk_win) ++e;
+        largest = std::max(largest, h_win[e] - h_win[t]);
+        cut.push_back(e); t = e;
+    }
+    // number of parts: what one pass keeps in flight (44 B per pair at its peak, plus the chunk's buffers) against a third of the
+    // free memory (MCQ_BUILD_PARTS: tuning knob / test hook)
+    size_t mem_free = 0, mem_total = 0;
+    BCHK(hipMemGetInfo(&mem_free, &mem_total));
+    const u64 n_slots_mine = (n_win * s + n_shards - 1) / n_shards;
+    const u64 chunk_bytes = largest * s * 16 + largest * 4;
+    u64 budget = mem_free / 3 > chunk_bytes + (1ull << 30) ? mem_free / 3 - chunk_bytes : (1ull << 30);
+    u32 n_parts = (u32)std::max<u64>(1, (n_slots_mine * 44 + budget - 1) / budget);
+    if (const char* e = getenv("MCQ_BUILD_PARTS")) n_parts = (u32)std::max<u64>(1, strtoull(e, nullptr, 10));
+    if ((u64)n_parts * n_shards > (1u << 20)) return bfail(MCQ_E_UNSUPPORTED, "too many parts");
+    const u32 n_ranges = n_parts * n_shards;
+    // a range's share of the slots: the hash spreads them evenly (3 % and 2^20 slack; an overflow is reported, not cut)
+    const u64 cap = (u64)((double)n_slots_mine / n_parts * 1.03) + (1ull << 20);
+
+    u32 *feat = nullptr, *nfeat = nullptr, *flag = nullptr; u64 *pos = nullptr, *woff = nullptr;
+    BCHK(tmpbuf.get(&feat, std::max<u64>(1, largest * s) * 4)); BCHK(tmpbuf.get(&nfeat, std::max<u64>(1, largest) * 4));
+    BCHK(tmpbuf.get(&flag, std::max<u64>(1, largest * s) * 4)); BCHK(tmpbuf.get(&pos, std::max<u64>(1, largest * s) * 8));
+    BCHK(tmpbuf.get(&woff, ((u64)nt + 1) * 8));
+    for (u32 p = 0; p < n_parts; ++p) {
+        const u32 range = d->shard_id * n_parts + p;
+        u64* key = nullptr; u32* val = nullptr;
+        BCHK(tmpbuf.get(&key, cap * 8)); BCHK(tmpbuf.get(&val, cap * 4));
+        u64 cursor = 0;
+        for (size_t c = 0; c + 1 < cut.size(); ++c) {
+            const u32 t0 = cut[c], t1 = cut[c + 1];
+            const u64 w0 = h_win[t0], nw = h_win[t1] - w0, ns = nw * s;
+            if (!nw) continue;
+            hipLaunchKernelGGL(k_shift_off, dim3((t1 - t0 + 1 + TB - 1) / TB), dim3(TB), 0, 0, (const u64*)(win_off + t0), (u64)(t1 - t0) + 1, w0, woff);
+            mcq_batch cb; cb.n_seqs = t1 - t0; cb.bases = d->bases; cb.seq_off = d->seq_off + t0; cb.paired = 0; cb.flags = MCQ_DEVICE_PTRS; cb.n_bases = 0;
+            MCHK(mcq_sketch(sk, &cb, woff, feat, nfeat, nullptr));
+            hipLaunchKernelGGL(k_part_flags, grid_for(ns), dim3(TB), 0, 0, (const u32*)feat, ns, n_ranges, range, flag);
+            u64 kept = 0;
+            MCHK(excl_scan(flag, pos, ns, &kept));
+            hipLaunchKernelGGL(k_part_scatter, grid_for(ns), dim3(TB), 0, 0, (const u32*)feat, (const u32*)flag, (const u64*)pos, ns, s, w0,
+                               (const u64*)win_off, nt, P, cursor, cap, key, val);
+            cursor += kept;
+            if (cursor > cap) return bfail(MCQ_E_CAPACITY, "a feature range holds more than its share of the features + 3 %: set MCQ_BUILD_PARTS");
+        }
+        BCHK(hipDeviceSynchronize());
+        phase("  sketch + keep the part's features");
+        Lists L;
+        MCHK(sort_truncate(tmpbuf, key, val, cursor, P, max_locs, (d->flags & MCQ_BUILD_REMOVE_OVERPOPULATED) != 0, L, phase));
+        mcq_db_part q; q.n_keys = L.n_keys; q.n_locs = L.n_kept; q.keys = nullptr; q.list_len = nullptr; q.locs = nullptr;
+        u32 *pk = nullptr, *pl = nullptr, *pw = nullptr; u64* first = nullptr;
+        BCHK(hipMalloc(&pk, (L.n_keys ? L.n_keys : 1) * 4)); q.keys = pk;
+        R->parts.push_back(q);                                   // (owned by R from here: freed by the guard on an error)
+        BCHK(hipMalloc(&pl, (L.n_keys ? L.n_keys : 1) * 4)); R->parts.back().list_len = pl;
+        BCHK(hipMalloc(&pw, (L.n_kept ? L.n_kept : 1) * 4)); R->parts.back().locs = pw;
+        BCHK(tmpbuf.get(&first, (L.n_keys ? L.n_keys : 1) * 8));
+        if (L.n_kept) {
+            hipLaunchKernelGGL(k_part_first, grid_for(L.n_kept), dim3(TB), 0, 0, (const u32*)L.head, (const u64*)L.kid, L.n_kept, first);
+            hipLaunchKernelGGL(k_part_len, grid_for(L.n_keys), dim3(TB), 0, 0, (const u64*)first, L.n_keys, L.n_kept, pl);
+            hipLaunchKernelGGL(k_emit_part, grid_for(L.n_kept), dim3(TB), 0, 0, (const u64*)L.fw, (const u32*)L.head, (const u64*)L.kid, L.n_kept, pk, pw);
+        }
+        BCHK(hipDeviceSynchronize());
+        BCHK(hipGetLastError());
+        tmpbuf.put(first); tmpbuf.put(L.fw); tmpbuf.put(L.head); tmpbuf.put(L.kid);
+        R->n_keys += L.n_keys; R->n_locs += L.n_kept; R->bytes += L.n_keys * 8 + L.n_kept * 4;
+        phase("  part emitted");
+    }
+    tmpbuf.put(feat); tmpbuf.put(nfeat); tmpbuf.put(flag); tmpbuf.put(pos); tmpbuf.put(woff); tmpbuf.put(win_off);
+    *out = R;
+    R = nullptr;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_db_from_parts(const mcq_parts* p, const uint32_t* tgt2tax, uint32_t n_shards, uint32_t shard_id, uint32_t flags, mcq_db** out) {
+    if (!p || !tgt2tax || !out) return bfail(MCQ_E_ARG, "null argument");
+    BCHK(hipSetDevice(p->device));
+    u32* t2t = nullptr;
+    if (!(flags & MCQ_DEVICE_PTRS)) {
+        BCHK(hipMalloc(&t2t, (u64)p->n_targets * 4));
+        BCHK(hipMemcpy(t2t, tgt2tax, (u64)p->n_targets * 4, hipMemcpyHostToDevice));
+    }
+    mcq_db_desc c; std::memset(&c, 0, sizeof(c));
+    c.k = p->k; c.sketch_size = p->s; c.winlen = p->winlen; c.winstride = p->winstride; c.tgt_winstride = p->winstride;
+    c.n_targets = p->n_targets; c.tgt2tax = t2t ? t2t : tgt2tax; c.tgt_windows = p->tgt_windows;
+    c.n_shards = n_shards ? n_shards : 1; c.shard_id = shard_id; c.device = p->device;
+    c.flags = MCQ_DEVICE_PTRS | (flags & (MCQ_DB_SLOTS_16 | MCQ_DB_BUCKETS_64));
+    const int rc = mcq_db_create_parts(&c, p->parts.data(), (u32)p->parts.size(), out);
+    if (rc != MCQ_OK) g_berr = mcq_last_error();
+    (void)hipFree(t2t);
+    return rc;
+}
+
 extern "C" int mcq_db_build(const mcq_build_desc* d, mcq_db** out) {
     if (!d || !out) return bfail(MCQ_E_ARG, "null argument");
+    // in parts when the one-piece temporaries (~60 B per feature slot of the sequences) would not leave room for the table --
+    // or when asked to (MCQ_BUILD_PARTS: test hook); needs the sequences in device memory
+    if ((d->flags & MCQ_DEVICE_PTRS) && !(d->flags & MCQ_DB_LOCS_64) && d->seq_off && d->n_targets) {
+        bool in_parts = getenv("MCQ_BUILD_PARTS") != nullptr;
+        if (!in_parts) {
+            u64 ends[1] = {0};
+            BCHK(hipSetDevice(d->device));
+            BCHK(hipMemcpy(ends, d->seq_off + d->n_targets, 8, hipMemcpyDeviceToHost));
+            size_t mem_free = 0, mem_total = 0;
+            BCHK(hipMemGetInfo(&mem_free, &mem_total));
+            const u64 slots = ends[0] / (d->winstride ? d->winstride : 1) * d->sketch_size;
+            in_parts = slots * 60 > mem_free / 2;
+        }
+        if (in_parts) {
+            mcq_parts* parts = nullptr;
+            MCHK(mcq_build_parts(d, &parts));
+            const int rc = mcq_db_from_parts(parts, d->tgt2tax, d->n_shards, d->shard_id, d->flags & (MCQ_DEVICE_PTRS | MCQ_DB_SLOTS_16 | MCQ_DB_BUCKETS_64), out);
+            mcq_parts_free(parts);
+            return rc;
+        }
+    }
     mcq_table* T = nullptr;
     MCHK(mcq_build_table(d, &T));
     u32* t2t = nullptr;

@@ -123,24 +123,35 @@ __global__ void k_fill_slots(uint4* slots, u64 n_uint4) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_uint4; i += stride) slots[i] = make_uint4(MCQ_EMPTY, 0, 0, 0);
 }
 
-// location (tgt << 32) | win of the public form -> the handle's native word: bit fields (tgt << wb) | win, or, with gw_off, the
-// global window index gw_off[tgt] + win
+// A table is handed over in one piece (mcq_db_create: offsets + public 64-bit locations) or in parts (mcq_db_create_parts:
+// list lengths + locations that are global-window words already).  PartView is what the build kernels see of either.
+struct PartView {
+    u64 n_keys, n_locs;
+    const u32* keys;
+    const u64* off;           // [n_keys + 1] exclusive offsets of the lists inside `locs`
+    const void* locs;         // u64 (tgt << 32) | win, or (gw_words) u32 global window indices
+    u32 gw_words;
+};
+// source location i of a part -> the handle's native word: bit fields (tgt << wb) | win, or, with gw_off, the global window index
+// gw_off[tgt] + win; a source that holds global-window words already is copied (the handle then keeps that form)
 template <class KeyT>
-__device__ __forceinline__ KeyT loc_native(u64 l, u32 wb, const u32* __restrict__ gw_off) {
+__device__ __forceinline__ KeyT loc_native(const PartView& pv, u64 i, u32 wb, const u32* __restrict__ gw_off) {
+    if (pv.gw_words) return (KeyT)static_cast<const u32*>(pv.locs)[i];
+    const u64 l = static_cast<const u64*>(pv.locs)[i];
     if (sizeof(KeyT) == 4 && gw_off) return (KeyT)(gw_off[(u32)(l >> 32)] + (u32)l);
     return (KeyT)(((l >> 32) << wb) | (l & 0xFFFFFFFFull));
 }
 // one thread per key: claim a bucket with CAS on the key word, then fill it: length, and either the list itself
-// (64-B buckets: up to 14 compact / 7 wide locations) or the offset of the list among the long ones (ext_off).
+// (64-B buckets: up to 14 compact / 7 wide locations) or the offset of the list among the long ones (ext_off + ext_base).
 // bq = uint4 per bucket (4 or 1); inl = longest inline list (0 with 16-B slots)
 template <class KeyT>
-__global__ void k_insert_keys(uint4* slots, u32 mask, u32 bq, u32 inl, const u32* keys, const u64* list_off, const u64* own_len, const u64* ext_off,
-                              const u64* locs, u64 n_keys, u32 wb, const u32* gw_off) {
+__global__ void k_insert_keys(uint4* slots, u32 mask, u32 bq, u32 inl, PartView pv, const u64* own_len, const u64* ext_off, u64 ext_base,
+                              u32 wb, const u32* gw_off) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_keys) return;
+    if (i >= pv.n_keys) return;
     const u32 len = (u32)own_len[i];
     if (len == 0) return;                                 // foreign or empty
-    const u32 key = keys[i];
+    const u32 key = pv.keys[i];
     u32 idx = tmh(key) & mask;
     while (true) {
         u32* w = reinterpret_cast<u32*>(&slots[(u64)idx * bq]);
@@ -149,31 +160,29 @@ __global__ void k_insert_keys(uint4* slots, u32 mask, u32 bq, u32 inl, const u32
             w[1] = len;
             if (len <= inl) {
                 KeyT* dst = reinterpret_cast<KeyT*>(w + 2);
-                const u64 src = list_off[i];
-                for (u32 t = 0; t < len; ++t) dst[t] = loc_native<KeyT>(locs[src + t], wb, gw_off);
-            } else { const u64 b = ext_off[i]; w[2] = (u32)b; w[3] = (u32)(b >> 32); }
+                const u64 src = pv.off[i];
+                for (u32 t = 0; t < len; ++t) dst[t] = loc_native<KeyT>(pv, src + t, wb, gw_off);
+            } else { const u64 b = ext_base + ext_off[i]; w[2] = (u32)b; w[3] = (u32)(b >> 32); }
             return;
         }
         idx = (idx + 1) & mask;
     }
 }
 
-// list length per key if owned by this shard, else 0; ext_len: the same for lists that do not fit a bucket
-__global__ void k_owned_len(const u32* keys, const u64* list_off, u64 n_keys, u32 n_shards, u32 shard_id, u32 inline_max, u64* out_len, u64* ext_len) {
+// list length per key if owned by this shard, else 0
+__global__ void k_owned_len(PartView pv, u32 n_shards, u32 shard_id, u64* out_len) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_keys) return;
-    u32 own = (u32)(((u64)tmh(keys[i]) * n_shards) >> 32);
-    const u64 len = (own == shard_id) ? (list_off[i + 1] - list_off[i]) : 0;
-    out_len[i] = len;
-    if (ext_len) ext_len[i] = len > inline_max ? len : 0;
+    if (i >= pv.n_keys) return;
+    u32 own = (u32)(((u64)tmh(pv.keys[i]) * n_shards) >> 32);
+    out_len[i] = (own == shard_id) ? (pv.off[i + 1] - pv.off[i]) : 0;
 }
-// owned non-empty keys and owned locations of the whole key array (two u64 counters)
-__global__ void k_owned_totals(const u64* own_len, u64 n_keys, unsigned long long* totals) {
-    unsigned long long k = 0, l = 0;
+// owned non-empty keys, owned locations, and of those the ones in lists longer than inl64 (what a 64-B bucket cannot hold): totals[3]
+__global__ void k_owned_totals(const u64* own_len, u64 n_keys, u32 inl64, unsigned long long* totals) {
+    unsigned long long k = 0, l = 0, x = 0;
     const u64 stride = (u64)gridDim.x * blockDim.x;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride) { const u64 v = own_len[i]; k += v > 0; l += v; }
-    for (int d = 32; d > 0; d >>= 1) { k += __shfl_xor(k, d, 64); l += __shfl_xor(l, d, 64); }
-    if ((threadIdx.x & 63) == 0 && l) { atomicAdd(&totals[0], k); atomicAdd(&totals[1], l); }
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_keys; i += stride) { const u64 v = own_len[i]; k += v > 0; l += v; x += v > inl64 ? v : 0; }
+    for (int d = 32; d > 0; d >>= 1) { k += __shfl_xor(k, d, 64); l += __shfl_xor(l, d, 64); x += __shfl_xor(x, d, 64); }
+    if ((threadIdx.x & 63) == 0 && l) { atomicAdd(&totals[0], k); atomicAdd(&totals[1], l); if (x) atomicAdd(&totals[2], x); }
 }
 __global__ void k_ext_len(const u64* own_len, u64 n_keys, u32 inline_max, u64* ext_len) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -182,13 +191,13 @@ __global__ void k_ext_len(const u64* own_len, u64 n_keys, u32 inline_max, u64* e
 
 // copy the owned long lists behind the buckets
 template <class KeyT>
-__global__ void k_copy_lists(const u64* list_off, const u64* ext_off, const u64* locs, KeyT* out, u64 n_keys, u32 wb, const u32* gw_off) {
+__global__ void k_copy_lists(PartView pv, const u64* ext_off, KeyT* out, u32 wb, const u32* gw_off) {
     // one wave per key, grid-stride (the grid is bounded: total threads must stay < 2^32)
     const u32 lane = threadIdx.x & 63;
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 key = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; key < n_keys; key += nwaves) {
-        u64 b = ext_off[key], n = ext_off[key + 1] - b, src = list_off[key];
-        for (u64 t = lane; t < n; t += 64) out[b + t] = loc_native<KeyT>(locs[src + t], wb, gw_off);
+    for (u64 key = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; key < pv.n_keys; key += nwaves) {
+        u64 b = ext_off[key], n = ext_off[key + 1] - b, src = pv.off[key];
+        for (u64 t = lane; t < n; t += 64) out[b + t] = loc_native<KeyT>(pv, src + t, wb, gw_off);
     }
 }
 
@@ -1618,95 +1627,71 @@ extern "C" uint32_t mcq_owner(uint32_t feature, uint32_t n_shards) {
 }
 
 // ------------------------------------------------------------------ db
-extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
-    if (!desc || !out) return fail(MCQ_E_ARG, "null argument");
+// temporaries are released on every way out; the handle itself by mcq_db_destroy on failure
+struct DevTemps {
+    std::vector<void*> p;
+    ~DevTemps() { for (void* x : p) (void)hipFree(x); }
+    hipError_t alloc(void** out, u64 bytes) { hipError_t e = hipMalloc(out, bytes ? bytes : 1); if (e == hipSuccess) p.push_back(*out); return e; }
+    void release(void* x) { for (auto& q : p) if (q == x) { (void)hipFree(x); q = nullptr; } }
+};
+static int check_params(const mcq_db_desc* desc) {
     if (desc->k < 1 || desc->k > 16) return fail(MCQ_E_UNSUPPORTED, "k must be 1..16");
     if (desc->sketch_size < 1 || desc->sketch_size > 32) return fail(MCQ_E_UNSUPPORTED, "sketch_size must be 1..32");
     if (desc->winlen < desc->k || desc->winlen > 128) return fail(MCQ_E_UNSUPPORTED, "winlen must be k..128");
     if (desc->winstride < 1) return fail(MCQ_E_ARG, "winstride must be >= 1");
-    u32 n_shards = desc->n_shards ? desc->n_shards : 1;
-    if (desc->shard_id >= n_shards) return fail(MCQ_E_ARG, "shard_id >= n_shards");
-    HIPCHK(hipSetDevice(desc->device));
-
-    const bool dev = (desc->flags & MCQ_DEVICE_PTRS) != 0;
-    const u64 nk = desc->n_keys, nl = desc->n_locs;
-    const u32* d_keys = desc->keys; const u64* d_off = desc->list_off; const u64* d_locs = desc->locs;
-    // temporaries are released on every way out; the handle itself by mcq_db_destroy on failure
-    struct Temps { std::vector<void*> p; ~Temps() { for (void* x : p) (void)hipFree(x); }
-                   hipError_t alloc(void** out, u64 bytes) { hipError_t e = hipMalloc(out, bytes); if (e == hipSuccess) p.push_back(*out); return e; } } tmp;
-    u32* t_keys = nullptr; u64* t_off = nullptr; u64* t_locs = nullptr;
-    if (!dev) {
-        HIPCHK(tmp.alloc((void**)&t_keys, std::max<u64>(1, nk) * 4));
-        HIPCHK(tmp.alloc((void**)&t_off, (nk + 1) * 8));
-        HIPCHK(tmp.alloc((void**)&t_locs, std::max<u64>(1, nl) * 8));
-        if (nk) HIPCHK(hipMemcpy(t_keys, desc->keys, nk * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(t_off, desc->list_off, (nk + 1) * 8, hipMemcpyHostToDevice));
-        if (nl) HIPCHK(hipMemcpy(t_locs, desc->locs, nl * 8, hipMemcpyHostToDevice));
-        d_keys = t_keys; d_off = t_off; d_locs = t_locs;
-    }
-
-    // ---- location format: 32-bit bit fields (tgt << wb) | win when target and window ids fit; else the 32-bit global
-    // window index (any table of fewer than 2^32 - 1 windows); else 64-bit words
+    if (desc->shard_id >= (desc->n_shards ? desc->n_shards : 1)) return fail(MCQ_E_ARG, "shard_id >= n_shards");
+    return MCQ_OK;
+}
+// windows per target -> gw_off (u32 [n_targets + 1]) and the block table; ext: device, u32 [n_targets]
+static int make_gw_tables(const u32* d_ext, u32 nt, DevTemps& tmp, u32** gw_off, u32** gw_blk, u32* gw_shift, u64* n_windows) {
     const u32 TB = 256;
-    u32 wb = 32, compact = 0, gw = 0;
-    u32 *d_gwoff = nullptr, *d_gwblk = nullptr; u32 gw_shift = 0; u64 n_windows = 0;
-    if ((desc->flags & MCQ_DB_LOCS_64) && (desc->flags & MCQ_DB_LOCS_GW)) return fail(MCQ_E_ARG, "MCQ_DB_LOCS_64 and MCQ_DB_LOCS_GW exclude each other");
-    if (!(desc->flags & MCQ_DB_LOCS_64)) {
-        u32* d_mw = nullptr; u32 maxwin = 0;
-        HIPCHK(tmp.alloc((void**)&d_mw, 4));
-        HIPCHK(hipMemset(d_mw, 0, 4));
-        if (nl) hipLaunchKernelGGL(k_max_win, dim3(1024), dim3(256), 0, 0, d_locs, nl, d_mw);
-        HIPCHK(hipMemcpy(&maxwin, d_mw, 4, hipMemcpyDeviceToHost));
-        u32 winbits = 1; while (winbits < 32 && (maxwin >> winbits)) ++winbits;
-        u32 maxtgt = desc->n_targets ? desc->n_targets - 1 : 0;
-        u32 tgtbits = 1; while (tgtbits < 32 && (maxtgt >> tgtbits)) ++tgtbits;
-        if (desc->loc_win_bits > winbits) winbits = desc->loc_win_bits;
-        if (!(desc->flags & MCQ_DB_LOCS_GW) && winbits + tgtbits <= 32 && winbits <= 31 &&
-            ((((u64)maxtgt << winbits) | maxwin) < 0xFFFFFFFFull)) { compact = 1; wb = winbits; }
-        else if (desc->n_targets) {
-            // global-window form: windows per target (given, or 1 + the largest window id among the locations), offsets
-            const u32 nt = desc->n_targets;
-            u32* d_ext = nullptr; u64* d_off64 = nullptr;
-            HIPCHK(tmp.alloc((void**)&d_ext, (u64)nt * 4));
-            HIPCHK(tmp.alloc((void**)&d_off64, ((u64)nt + 1) * 8));
-            if (desc->tgt_windows) HIPCHK(hipMemcpy(d_ext, desc->tgt_windows, (u64)nt * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
-            else {
-                HIPCHK(hipMemset(d_ext, 0, (u64)nt * 4));
-                if (nl) hipLaunchKernelGGL(k_tgt_extent, dim3(2048), dim3(256), 0, 0, d_locs, nl, nt, d_ext);
-            }
-            { int rcs = device_exclusive_scan<u32>(d_ext, d_off64, nt, 0); if (rcs) return rcs; }
-            HIPCHK(hipMemcpy(&n_windows, d_off64 + nt, 8, hipMemcpyDeviceToHost));
-            if (n_windows < 0xFFFFFFFFull) {
-                compact = 1; gw = 1; wb = 0;
-                // block table: at most 2^18 entries (1 MB: stays in L2), at least 64 windows per block
-                gw_shift = 6; while ((n_windows >> gw_shift) > (1ull << 18)) ++gw_shift;
-                const u64 n_blk = (n_windows >> gw_shift) + 2;
-                HIPCHK(hipMalloc(&d_gwoff, ((u64)nt + 1) * 4));
-                hipLaunchKernelGGL(k_u64_to_u32, dim3((u32)((nt + 1 + TB - 1) / TB)), dim3(TB), 0, 0, (const u64*)d_off64, d_gwoff, (u64)nt + 1);
-                if (hipMalloc(&d_gwblk, n_blk * 4) != hipSuccess) { (void)hipFree(d_gwoff); return fail(MCQ_E_HIP, "hipMalloc of the window block table failed"); }
-                hipLaunchKernelGGL(k_gw_blocks, dim3((u32)((n_blk + TB - 1) / TB)), dim3(TB), 0, 0, (const u32*)d_gwoff, nt, gw_shift, n_blk, d_gwblk);
-            } else if (desc->flags & MCQ_DB_LOCS_GW) return fail(MCQ_E_UNSUPPORTED, "MCQ_DB_LOCS_GW: the table has 2^32 - 1 windows or more");
-        }
-    }
+    u64* d_off64 = nullptr;
+    HIPCHK(tmp.alloc((void**)&d_off64, ((u64)nt + 1) * 8));
+    { int rcs = device_exclusive_scan<u32>(d_ext, d_off64, nt, 0); if (rcs) return rcs; }
+    HIPCHK(hipMemcpy(n_windows, d_off64 + nt, 8, hipMemcpyDeviceToHost));
+    *gw_off = nullptr; *gw_blk = nullptr;
+    if (*n_windows >= 0xFFFFFFFFull) return MCQ_OK;       // does not fit 32 bits: the caller decides
+    // block table: at most 2^18 entries (1 MB: stays in L2), at least 64 windows per block
+    u32 sh = 6; while ((*n_windows >> sh) > (1ull << 18)) ++sh;
+    const u64 n_blk = (*n_windows >> sh) + 2;
+    HIPCHK(hipMalloc(gw_off, ((u64)nt + 1) * 4));
+    hipLaunchKernelGGL(k_u64_to_u32, dim3((u32)((nt + 1 + TB - 1) / TB)), dim3(TB), 0, 0, (const u64*)d_off64, *gw_off, (u64)nt + 1);
+    if (hipMalloc(gw_blk, n_blk * 4) != hipSuccess) { (void)hipFree(*gw_off); *gw_off = nullptr; return fail(MCQ_E_HIP, "hipMalloc of the window block table failed"); }
+    hipLaunchKernelGGL(k_gw_blocks, dim3((u32)((n_blk + TB - 1) / TB)), dim3(TB), 0, 0, (const u32*)*gw_off, nt, sh, n_blk, *gw_blk);
+    *gw_shift = sh;
+    return MCQ_OK;
+}
+
+// the table itself, from one or several parts (device memory); format decided by the caller
+static int create_table(const mcq_db_desc* desc, const std::vector<PartView>& parts, u32 compact, u32 wb, u32 gw,
+                        u32* d_gwoff, u32* d_gwblk, u32 gw_shift, u64 n_windows, mcq_db** out) {
+    const u32 TB = 256;
+    const bool dev = (desc->flags & MCQ_DEVICE_PTRS) != 0;
+    const u32 n_shards = desc->n_shards ? desc->n_shards : 1;
     const u64 locsz = compact ? 4 : 8;
     mcq_db* db = new mcq_db();
     memset(db, 0, sizeof(*db));
     db->device = desc->device; db->n_shards = n_shards; db->shard_id = desc->shard_id;
     db->gw_off = d_gwoff; db->gw_blk = d_gwblk;           // (released by mcq_db_destroy from here on)
+    DevTemps tmp;
 #define DBCHK(expr) HIPCHK_OR(expr, (void)mcq_db_destroy(db))
 #define DBRC(expr) do { int rc_ = (expr); if (rc_) { (void)mcq_db_destroy(db); return rc_; } } while (0)
 
-    // owned list lengths, owned non-empty keys and locations
+    // ---- pass 1 over the parts: owned non-empty keys, owned locations, locations of lists too long for a 64-B bucket
+    u64 nk_max = 0;
+    for (const auto& pv : parts) nk_max = std::max(nk_max, pv.n_keys);
     u64 *d_len = nullptr, *d_ext = nullptr, *d_new = nullptr; unsigned long long* d_tot = nullptr;
-    DBCHK(tmp.alloc((void**)&d_len, std::max<u64>(1, nk) * 8));
-    DBCHK(tmp.alloc((void**)&d_tot, 16));
-    DBCHK(hipMemset(d_tot, 0, 16));
-    if (nk) {
-        hipLaunchKernelGGL(k_owned_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, d_keys, d_off, nk, n_shards, desc->shard_id, 0u, d_len, (u64*)nullptr);
-        hipLaunchKernelGGL(k_owned_totals, dim3(1024), dim3(TB), 0, 0, (const u64*)d_len, nk, d_tot);
+    DBCHK(tmp.alloc((void**)&d_len, std::max<u64>(1, nk_max) * 8));
+    DBCHK(tmp.alloc((void**)&d_tot, 24));
+    DBCHK(hipMemset(d_tot, 0, 24));
+    const u32 inl64 = bucket_inline_max(2u, compact);
+    for (const auto& pv : parts) {
+        if (!pv.n_keys) continue;
+        hipLaunchKernelGGL(k_owned_len, dim3((u32)((pv.n_keys + TB - 1) / TB)), dim3(TB), 0, 0, pv, n_shards, desc->shard_id, d_len);
+        hipLaunchKernelGGL(k_owned_totals, dim3(1024), dim3(TB), 0, 0, (const u64*)d_len, pv.n_keys, inl64, d_tot);
     }
-    unsigned long long tot[2] = {0, 0};
-    DBCHK(hipMemcpy(tot, d_tot, 16, hipMemcpyDeviceToHost));
+    unsigned long long tot[3] = {0, 0, 0};
+    DBCHK(hipMemcpy(tot, d_tot, 24, hipMemcpyDeviceToHost));
     const u64 nk_local = tot[0], nl_local = tot[1];
 
     // ---- layout, per table.  64-B buckets hold a list of up to 14 (7) locations next to its key -- in the sector the
@@ -1717,13 +1702,9 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     if (desc->flags & MCQ_DB_SLOTS_16) bucket_bytes = 16;
     if (desc->flags & MCQ_DB_BUCKETS_64) bucket_bytes = 64;
     if (const char* e = getenv("MCQ_BUCKET_BYTES")) { const int v = atoi(e); if (v == 16 || v == 64) bucket_bytes = (u32)v; }   // tuning knob
-    const u32 inl = bucket_inline_max(bucket_bytes == 64 ? 2u : 0u, compact);
-    DBCHK(tmp.alloc((void**)&d_ext, std::max<u64>(1, nk) * 8));
-    DBCHK(tmp.alloc((void**)&d_new, (nk + 1) * 8));
-    if (nk) hipLaunchKernelGGL(k_ext_len, dim3((u32)((nk + TB - 1) / TB)), dim3(TB), 0, 0, (const u64*)d_len, nk, inl, d_ext);
-    DBRC(device_exclusive_scan<u64>(d_ext, d_new, nk, 0));
-    u64 nl_ext = 0;
-    DBCHK(hipMemcpy(&nl_ext, d_new + nk, 8, hipMemcpyDeviceToHost));
+    const u32 bsh = bucket_bytes == 64 ? 2u : 0u;
+    const u32 inl = bucket_inline_max(bsh, compact);
+    const u64 nl_ext = bucket_bytes == 64 ? tot[2] : nl_local;
 
     // load factor <= 0.25 (43 % of a read's features are not in the table, and every step of a linear probe is a new
     // sector) while the slot array stays below 48 GB and a third of the free memory, else <= 0.5 -- also when the
@@ -1756,23 +1737,36 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     const u32 bq = bucket_bytes / 16;
     const u64 n_uint4 = nslots * bq;
     hipLaunchKernelGGL(k_fill_slots, dim3((u32)std::min<u64>((n_uint4 + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, db->slots, n_uint4);
-    if (nk) {
-        const dim3 ig((u32)((nk + TB - 1) / TB));
-        if (compact) hipLaunchKernelGGL(k_insert_keys<u32>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), bq, inl, d_keys, d_off, (const u64*)d_len, (const u64*)d_new, d_locs, nk, wb, (const u32*)d_gwoff);
-        else         hipLaunchKernelGGL(k_insert_keys<u64>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), bq, inl, d_keys, d_off, (const u64*)d_len, (const u64*)d_new, d_locs, nk, 32u, (const u32*)nullptr);
+
+    // ---- pass 2: insert part by part; the long lists of part p start where those of part p - 1 end
+    DBCHK(tmp.alloc((void**)&d_ext, std::max<u64>(1, nk_max) * 8));
+    DBCHK(tmp.alloc((void**)&d_new, (nk_max + 1) * 8));
+    char* ext = reinterpret_cast<char*>(db->slots) + nslots * bucket_bytes;
+    u64 ext_base = 0;
+    for (const auto& pv : parts) {
+        if (!pv.n_keys) continue;
+        const dim3 ig((u32)((pv.n_keys + TB - 1) / TB));
+        hipLaunchKernelGGL(k_owned_len, ig, dim3(TB), 0, 0, pv, n_shards, desc->shard_id, d_len);
+        hipLaunchKernelGGL(k_ext_len, ig, dim3(TB), 0, 0, (const u64*)d_len, pv.n_keys, inl, d_ext);
+        DBRC(device_exclusive_scan<u64>(d_ext, d_new, pv.n_keys, 0));
+        u64 part_ext = 0;
+        DBCHK(hipMemcpy(&part_ext, d_new + pv.n_keys, 8, hipMemcpyDeviceToHost));
+        if (ext_base + part_ext > std::max<u64>(1, nl_ext)) { (void)mcq_db_destroy(db); return fail(MCQ_E_ARG, "the parts changed between the two passes"); }
+        if (compact) hipLaunchKernelGGL(k_insert_keys<u32>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), bq, inl, pv, (const u64*)d_len, (const u64*)d_new, ext_base, wb, (const u32*)d_gwoff);
+        else         hipLaunchKernelGGL(k_insert_keys<u64>, ig, dim3(TB), 0, 0, db->slots, (u32)(nslots - 1), bq, inl, pv, (const u64*)d_len, (const u64*)d_new, ext_base, 32u, (const u32*)nullptr);
         DBCHK(hipGetLastError());
-        char* ext = reinterpret_cast<char*>(db->slots) + nslots * bucket_bytes;
-        const dim3 cg((u32)std::min<u64>((nk * 64 + TB - 1) / TB, 1u << 20));
-        if (compact) hipLaunchKernelGGL(k_copy_lists<u32>, cg, dim3(TB), 0, 0, d_off, (const u64*)d_new, d_locs, (u32*)ext, nk, wb, (const u32*)d_gwoff);
-        else         hipLaunchKernelGGL(k_copy_lists<u64>, cg, dim3(TB), 0, 0, d_off, (const u64*)d_new, d_locs, (u64*)ext, nk, 32u, (const u32*)nullptr);
+        const dim3 cg((u32)std::min<u64>((pv.n_keys * 64 + TB - 1) / TB, 1u << 20));
+        if (compact) hipLaunchKernelGGL(k_copy_lists<u32>, cg, dim3(TB), 0, 0, pv, (const u64*)d_new, reinterpret_cast<u32*>(ext) + ext_base, wb, (const u32*)d_gwoff);
+        else         hipLaunchKernelGGL(k_copy_lists<u64>, cg, dim3(TB), 0, 0, pv, (const u64*)d_new, reinterpret_cast<u64*>(ext) + ext_base, 32u, (const u32*)nullptr);
         DBCHK(hipGetLastError());
+        ext_base += part_ext;
     }
     DBCHK(hipDeviceSynchronize());
 #undef DBCHK
 #undef DBRC
 
     db->d.slots = db->slots; db->d.slot_mask = (u32)(db->nslots - 1); db->d.locs = db->slots;
-    db->d.bsh = bucket_bytes == 64 ? 2u : 0u;
+    db->d.bsh = bsh;
     db->d.wb = wb; db->d.compact = compact;
     db->g.on = gw; db->g.shift = gw_shift; db->g.off = d_gwoff; db->g.blk = d_gwblk;
     db->d.tgt2tax = db->tgt2tax; db->d.n_targets = desc->n_targets;
@@ -1783,6 +1777,91 @@ extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
     db->bytes = table_bytes + (u64)desc->n_targets * 4 + (gw ? ((u64)desc->n_targets + 1) * 4 + ((n_windows >> gw_shift) + 2) * 4 : 0);
     *out = db;
     return MCQ_OK;
+}
+
+extern "C" int mcq_db_create(const mcq_db_desc* desc, mcq_db** out) {
+    if (!desc || !out) return fail(MCQ_E_ARG, "null argument");
+    { int rc = check_params(desc); if (rc) return rc; }
+    HIPCHK(hipSetDevice(desc->device));
+
+    const bool dev = (desc->flags & MCQ_DEVICE_PTRS) != 0;
+    const u64 nk = desc->n_keys, nl = desc->n_locs;
+    const u32* d_keys = desc->keys; const u64* d_off = desc->list_off; const u64* d_locs = desc->locs;
+    DevTemps tmp;
+    u32* t_keys = nullptr; u64* t_off = nullptr; u64* t_locs = nullptr;
+    if (!dev) {
+        HIPCHK(tmp.alloc((void**)&t_keys, std::max<u64>(1, nk) * 4));
+        HIPCHK(tmp.alloc((void**)&t_off, (nk + 1) * 8));
+        HIPCHK(tmp.alloc((void**)&t_locs, std::max<u64>(1, nl) * 8));
+        if (nk) HIPCHK(hipMemcpy(t_keys, desc->keys, nk * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(t_off, desc->list_off, (nk + 1) * 8, hipMemcpyHostToDevice));
+        if (nl) HIPCHK(hipMemcpy(t_locs, desc->locs, nl * 8, hipMemcpyHostToDevice));
+        d_keys = t_keys; d_off = t_off; d_locs = t_locs;
+    }
+
+    // ---- location format: 32-bit bit fields (tgt << wb) | win when target and window ids fit; else the 32-bit global
+    // window index (any table of fewer than 2^32 - 1 windows); else 64-bit words
+    u32 wb = 32, compact = 0, gw = 0;
+    u32 *d_gwoff = nullptr, *d_gwblk = nullptr; u32 gw_shift = 0; u64 n_windows = 0;
+    if ((desc->flags & MCQ_DB_LOCS_64) && (desc->flags & MCQ_DB_LOCS_GW)) return fail(MCQ_E_ARG, "MCQ_DB_LOCS_64 and MCQ_DB_LOCS_GW exclude each other");
+    if (!(desc->flags & MCQ_DB_LOCS_64)) {
+        u32* d_mw = nullptr; u32 maxwin = 0;
+        HIPCHK(tmp.alloc((void**)&d_mw, 4));
+        HIPCHK(hipMemset(d_mw, 0, 4));
+        if (nl) hipLaunchKernelGGL(k_max_win, dim3(1024), dim3(256), 0, 0, d_locs, nl, d_mw);
+        HIPCHK(hipMemcpy(&maxwin, d_mw, 4, hipMemcpyDeviceToHost));
+        u32 winbits = 1; while (winbits < 32 && (maxwin >> winbits)) ++winbits;
+        u32 maxtgt = desc->n_targets ? desc->n_targets - 1 : 0;
+        u32 tgtbits = 1; while (tgtbits < 32 && (maxtgt >> tgtbits)) ++tgtbits;
+        if (desc->loc_win_bits > winbits) winbits = desc->loc_win_bits;
+        if (!(desc->flags & MCQ_DB_LOCS_GW) && winbits + tgtbits <= 32 && winbits <= 31 &&
+            ((((u64)maxtgt << winbits) | maxwin) < 0xFFFFFFFFull)) { compact = 1; wb = winbits; }
+        else if (desc->n_targets) {
+            // global-window form: windows per target (given, or 1 + the largest window id among the locations), offsets
+            const u32 nt = desc->n_targets;
+            u32* d_ext = nullptr;
+            HIPCHK(tmp.alloc((void**)&d_ext, (u64)nt * 4));
+            if (desc->tgt_windows) HIPCHK(hipMemcpy(d_ext, desc->tgt_windows, (u64)nt * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+            else {
+                HIPCHK(hipMemset(d_ext, 0, (u64)nt * 4));
+                if (nl) hipLaunchKernelGGL(k_tgt_extent, dim3(2048), dim3(256), 0, 0, d_locs, nl, nt, d_ext);
+            }
+            int rc = make_gw_tables(d_ext, nt, tmp, &d_gwoff, &d_gwblk, &gw_shift, &n_windows); if (rc) return rc;
+            if (d_gwoff) { compact = 1; gw = 1; wb = 0; }
+            else if (desc->flags & MCQ_DB_LOCS_GW) return fail(MCQ_E_UNSUPPORTED, "MCQ_DB_LOCS_GW: the table has 2^32 - 1 windows or more");
+        }
+    }
+    PartView pv; pv.n_keys = nk; pv.n_locs = nl; pv.keys = d_keys; pv.off = d_off; pv.locs = d_locs; pv.gw_words = 0;
+    return create_table(desc, std::vector<PartView>{pv}, compact, wb, gw, d_gwoff, d_gwblk, gw_shift, n_windows, out);
+}
+
+// The same for a table that is larger than the memory for its one-piece description (RefSeq scale: the 64-bit locations
+// alone would be 8 B x 1.7e10): handed over in parts -- e.g. one per feature-hash range, as mcq_build_parts makes them --
+// whose locations are 32-bit global-window words already.  Device memory only.
+extern "C" int mcq_db_create_parts(const mcq_db_desc* desc, const mcq_db_part* parts, uint32_t n_parts, mcq_db** out) {
+    if (!desc || !out || (n_parts && !parts)) return fail(MCQ_E_ARG, "null argument");
+    { int rc = check_params(desc); if (rc) return rc; }
+    if (!(desc->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "mcq_db_create_parts takes device pointers");
+    if (desc->flags & MCQ_DB_LOCS_64) return fail(MCQ_E_UNSUPPORTED, "parts hold global-window words: the handle keeps that form");
+    if (!desc->tgt_windows || !desc->n_targets) return fail(MCQ_E_ARG, "mcq_db_create_parts needs tgt_windows (the words of the parts are defined by it)");
+    HIPCHK(hipSetDevice(desc->device));
+    DevTemps tmp;
+    u32 *d_gwoff = nullptr, *d_gwblk = nullptr; u32 gw_shift = 0; u64 n_windows = 0;
+    int rc = make_gw_tables(desc->tgt_windows, desc->n_targets, tmp, &d_gwoff, &d_gwblk, &gw_shift, &n_windows); if (rc) return rc;
+    if (!d_gwoff) return fail(MCQ_E_UNSUPPORTED, "the table has 2^32 - 1 windows or more");
+    std::vector<PartView> pvs;
+    std::vector<u64*> offs;
+    for (u32 i = 0; i < n_parts; ++i) {
+        const mcq_db_part& p = parts[i];
+        if (p.n_keys && (!p.keys || !p.list_len || (p.n_locs && !p.locs))) { (void)hipFree(d_gwoff); (void)hipFree(d_gwblk); return fail(MCQ_E_ARG, "null pointer in a part"); }
+        u64* off = nullptr;
+        if (tmp.alloc((void**)&off, (p.n_keys + 1) * 8) != hipSuccess) { (void)hipFree(d_gwoff); (void)hipFree(d_gwblk); return fail(MCQ_E_HIP, "hipMalloc of a part's list offsets failed"); }
+        rc = device_exclusive_scan<u32>(p.list_len, off, p.n_keys, 0);
+        if (rc) { (void)hipFree(d_gwoff); (void)hipFree(d_gwblk); return rc; }
+        PartView pv; pv.n_keys = p.n_keys; pv.n_locs = p.n_locs; pv.keys = p.keys; pv.off = off; pv.locs = p.locs; pv.gw_words = 1;
+        pvs.push_back(pv);
+    }
+    return create_table(desc, pvs, 1, 0, 1, d_gwoff, d_gwblk, gw_shift, n_windows, out);
 }
 
 extern "C" int mcq_db_destroy(mcq_db* db) {

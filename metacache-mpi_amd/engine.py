@@ -135,6 +135,10 @@ def lib():
         L.mcq_table_info.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.mcq_table_free.argtypes = [C.c_void_p]
         L.mcq_build_last_error.restype = C.c_char_p
+        L.mcq_build_parts.argtypes = [C.POINTER(BuildDesc), C.POINTER(C.c_void_p)]
+        L.mcq_parts_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        L.mcq_db_from_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.mcq_parts_free.argtypes = [C.c_void_p]
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         L.mcq_packed_bytes.restype = C.c_uint64; L.mcq_packed_bytes.argtypes = [C.c_uint64]
@@ -501,6 +505,47 @@ class Table:
     def close(self):
         if getattr(self, "h", None):
             lib().mcq_table_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Parts:
+    """mcq_build_parts: the table built in feature-hash ranges and kept as keys / list lengths / 32-bit global-window words
+    (device memory) -- for tables whose one-piece build does not fit (RefSeq scale).  database() makes the queryable
+    handle (any shard of it); the sequences may be released before that."""
+
+    def __init__(self, bases_ptr, seq_off_ptr, n_targets, emulate_ranks=1, k=16, sketch_size=16, winlen=128, winstride=113,
+                 max_locs=0, n_shards=1, shard_id=0, device=0, flags=0):
+        d = _build_desc(bases_ptr, seq_off_ptr, None, n_targets, emulate_ranks, k, sketch_size, winlen, winstride,
+                        max_locs, n_shards, shard_id, device, flags, True)
+        h = C.c_void_p()
+        rc = lib().mcq_build_parts(C.byref(d), C.byref(h))
+        if rc != 0:
+            raise McqError(rc, (lib().mcq_build_last_error() or b"").decode())
+        self.h, self.n_targets, self.device = h, n_targets, device
+        self.k, self.sketch_size, self.winlen, self.winstride = k, sketch_size, winlen, winstride
+        nk, nl, nw, nb = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        npar = C.c_uint32()
+        _chk(lib().mcq_parts_info(h, C.byref(nk), C.byref(nl), C.byref(nw), C.byref(npar), C.byref(nb)))
+        self.n_keys, self.n_locs, self.n_windows, self.n_parts, self.bytes = int(nk.value), int(nl.value), int(nw.value), int(npar.value), int(nb.value)
+
+    def database(self, tgt2tax_ptr, n_shards=1, shard_id=0, flags=0, device_ptrs=True):
+        db = Database.__new__(Database)
+        db.k, db.sketch_size, db.winlen, db.winstride, db.device = self.k, self.sketch_size, self.winlen, self.winstride, self.device
+        h = C.c_void_p()
+        rc = lib().mcq_db_from_parts(self.h, tgt2tax_ptr, n_shards, shard_id, flags | (MCQ_DEVICE_PTRS if device_ptrs else 0), C.byref(h))
+        if rc != 0:
+            raise McqError(rc, (lib().mcq_build_last_error() or b"").decode())
+        db.h = h
+        return db
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcq_parts_free(self.h); self.h = None
 
     def __del__(self):
         try:

@@ -203,3 +203,103 @@ def test_reference_reads_and_queries_shards_written_from_the_gpu_build(tag, P, t
             got[t[0]].setdefault(t[1], {})[t[2]] = [[int(x) for x in it.split(":")] for it in t[4:] if it]
     for kind in ("M", "T", "C"):
         assert got[kind] == fx.ranks[kind], kind
+
+
+# ---- the build in parts (mcq_build_parts / mcq_db_create_parts: tables whose one-piece build does not fit) ----------------
+def _all_lists_of(engine, db, keys, win_off):
+    """every key's list out of a handle (mcq_lookup_count / _gather), as (tgt << 32) | win: list lengths [n_keys] and
+    the lists back to back"""
+    dev = torch.device("cuda", 0)
+    k32 = torch.from_numpy(np.ascontiguousarray(keys).view(np.int32).copy()).to(dev)
+    n = k32.numel()
+    lens = torch.zeros(n, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    db.lookup_count(k32.data_ptr(), n, lens.data_ptr(), None, st)
+    ooff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens.to(torch.int64), 0, out=ooff[1:])
+    lay = db.layout()
+    native = torch.zeros(int(ooff[-1].item()) + 1, dtype=torch.int32 if lay["loc_bytes"] == 4 else torch.int64, device=dev)
+    db.lookup_gather(k32.data_ptr(), n, ooff.data_ptr(), native.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    w = native[:-1].to(torch.int64) & (0xFFFFFFFF if lay["loc_bytes"] == 4 else -1)
+    if lay["loc_format"] == engine.MCQ_LOC_GLOBAL_WINDOW:
+        go = torch.from_numpy(win_off.astype(np.int64)).to(dev)
+        t = torch.searchsorted(go, w, right=True) - 1
+        out = (t << 32) | (w - go[t])
+    elif lay["loc_bytes"] == 4:
+        wb = lay["win_bits"]
+        out = ((w >> wb) << 32) | (w & ((1 << wb) - 1))
+    else:
+        out = w
+    return lens.cpu().numpy().astype(np.int64), out.cpu().numpy().astype(np.uint64)
+
+
+@pytest.mark.parametrize("P,flags", [(1, 0), (2, 0), (3, 0x1000)])
+def test_build_in_parts_equals_the_one_piece_build(P, flags, monkeypatch):
+    """the same sequences through mcq_build_table (the build that is pinned to the reference's shard files above) and through
+    mcq_build_parts with 3 feature ranges and sketch chunks of a few targets: every key, every list, and any shard of it"""
+    engine = importlib.import_module("metacache-mpi_amd.engine")
+    synth = importlib.import_module("metacache-mpi_amd.synth")
+    dev = torch.device("cuda", 0)
+    gb, goff, species = synth.make_genomes(5, 9, 80_000, 160_000, 0.02, seed=12, device=dev)
+    if flags:        # a repeat family, so that -remove-overpopulated-features and the 254 limit have something to do
+        unit = gb[:113].clone()
+        rep = unit.repeat(300)
+        gb = torch.cat([gb, rep, rep]); goff = torch.cat([goff, goff[-1:] + rep.numel(), goff[-1:] + 2 * rep.numel()])
+        species = torch.cat([species, species[-1:] + 1, species[-1:] + 1])
+    nt = goff.numel() - 1
+    tb = engine.Table(gb.data_ptr(), goff.data_ptr(), nt, emulate_ranks=P, flags=flags)
+    keys, loff, locs, win_off = tb.to_host()
+    tb.close()
+    monkeypatch.setenv("MCQ_BUILD_PARTS", "3")
+    monkeypatch.setenv("MCQ_BUILD_CHUNK_WINDOWS", "9000")
+    parts = engine.Parts(gb.data_ptr(), goff.data_ptr(), nt, emulate_ranks=P, flags=flags)
+    assert parts.n_parts == 3 and parts.n_keys == len(keys) and parts.n_locs == len(locs) and parts.n_windows == int(win_off[-1])
+    sp32 = species.to(torch.int32).contiguous()
+    want_len = np.diff(loff.astype(np.int64))
+    for layout in (0, engine.MCQ_DB_SLOTS_16, engine.MCQ_DB_BUCKETS_64):
+        db = parts.database(sp32.data_ptr(), flags=layout)
+        lay = db.layout()
+        assert lay["loc_format"] == engine.MCQ_LOC_GLOBAL_WINDOW and lay["n_keys"] == len(keys) and lay["n_locs"] == len(locs)
+        lens, lists = _all_lists_of(engine, db, keys, win_off)
+        assert np.array_equal(lens, want_len) and np.array_equal(lists, locs), layout
+        db.close()
+    # shards of it, from the same parts and from a build that only made the shard
+    seen = 0
+    for sid in range(2):
+        own = np.array([engine.owner(int(k), 2) == sid for k in keys])
+        for src in (parts, engine.Parts(gb.data_ptr(), goff.data_ptr(), nt, emulate_ranks=P, flags=flags, n_shards=2, shard_id=sid)):
+            db = src.database(sp32.data_ptr(), n_shards=2, shard_id=sid)
+            lens, lists = _all_lists_of(engine, db, keys, win_off)
+            assert np.array_equal(lens, np.where(own, want_len, 0))
+            assert np.array_equal(lists, locs[np.repeat(own, want_len)])
+            assert db.layout()["n_keys"] == int(own.sum())
+            db.close()
+            if src is not parts:
+                assert src.n_keys == int(own.sum())
+                src.close()
+        seen += int(own.sum())
+    assert seen == len(keys)
+    parts.close()
+
+
+@pytest.mark.parametrize("tag,P", [("mini", 4), ("tie", 2), ("overpop", 2)])
+def test_db_build_in_parts_queries_like_the_reference(tag, P, monkeypatch):
+    """mcq_db_build taking the in-parts way (forced): the fixture reads get the top hits the reference's own run printed"""
+    engine = importlib.import_module("metacache-mpi_amd.engine")
+    from oracle import mc_oracle as orc
+    dev = torch.device("cuda", 0)
+    fx = Fixture(tag, P)
+    bases, off = _load_genomes(tag, dev)
+    t2t = torch.from_numpy(np.asarray(fx.tgt2tax(), np.uint32).view(np.int32).copy()).to(dev)
+    monkeypatch.setenv("MCQ_BUILD_PARTS", "2")
+    monkeypatch.setenv("MCQ_BUILD_CHUNK_WINDOWS", "700")
+    db = engine.Database.build(bases.data_ptr(), off.data_ptr(), t2t.data_ptr(), off.numel() - 1, emulate_ranks=P,
+                               flags=engine.MCQ_BUILD_REMOVE_OVERPOPULATED if tag == "overpop" else 0)
+    assert db.layout()["loc_format"] == engine.MCQ_LOC_GLOBAL_WINDOW
+    rb, ro = orc.pack_reads(fx.interleaved())
+    ws = engine.Workspace(db, len(fx.names), len(rb))
+    cands, ncand = ws.query_host(rb, ro, True, max_cand=fx.maxcand, emulate_ranks=P, flags=engine.MCQ_QUIRK_SEQ_DROP)
+    for q, name in enumerate(fx.names):
+        mine = [[fx.tax.id_of_key(c[0]), int(c[1])] for c in cands[q, :ncand[q]]]
+        assert mine == fx.final[name]["tophits"], (name, mine, fx.final[name])
