@@ -77,6 +77,11 @@ def parse():
                          "global window index, else 64 bit); gw / fields64 force a form (fields32 = auto, fails the run if it does not fit)")
     ap.add_argument("--bucket-bytes", type=int, default=0, choices=[0, 16, 64], help="table layout: 0 = per table (mean list length), 16 / 64 force it")
     ap.add_argument("--contigs", type=int, default=1, help="split every genome into this many targets (RefSeq assemblies: many sequences per genome)")
+    ap.add_argument("--refseq-scale", action="store_true",
+                    help="BASELINE configs[2] shape on ONE GPU: --species 2600 x 10 strains (104 Gbp), --contigs 2 (52 001 targets), one 16 Mbp "
+                         "chromosome, -remove-overpopulated-features, table built in parts; any of these can still be given explicitly")
+    ap.add_argument("--remove-overpopulated", action="store_true", help="build option -remove-overpopulated-features (src/mode_build.cpp:847-1074)")
+    ap.add_argument("--build-parts", action="store_true", help="build the table in feature-hash parts (mcq_build_parts) whatever its size")
     ap.add_argument("--long-genome-mbp", type=float, default=0.0,
                     help="add one genome of this many Mbp (>= 14.9 Mbp = 2^17 windows: with >= 2^15 targets the (target, window) "
                          "fields no longer fit 32 bits, as on RefSeq)")
@@ -126,6 +131,12 @@ def algorithmic_bytes(n_bases, st):
 
 def main():
     a = parse()
+    if a.refseq_scale:          # defaults of the RefSeq-scale shape (explicit arguments win)
+        argv = " ".join(sys.argv[1:])
+        if "--species" not in argv: a.species = 2600
+        if "--contigs" not in argv: a.contigs = 2
+        if "--long-genome-mbp" not in argv: a.long_genome_mbp = 16.0
+        a.remove_overpopulated = True
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(spawn_ranks(a))
     import torch
@@ -184,46 +195,24 @@ def main():
 
     # ---- database: same seeded genomes on every rank; each rank keeps its hash-range shard
     t_setup = time.time()
-    gen_bases, gen_off, species = synth.make_genomes(n_species, a.strains, a.genome_min, a.genome_max,
-                                                     a.divergence, seed=3, device=dev)
-    if a.long_genome_mbp > 0:
-        gen_bases, gen_off, species = synth.add_genome(gen_bases, gen_off, species, int(a.long_genome_mbp * 1e6), seed=4)
+    if a.refseq_scale:
+        # BASELINE configs[2] shape on one GPU: >= 100 Gbp, >= 2^15 sequences, one chromosome of > 2^17 windows
+        gen_bases, gen_off, species = synth.make_genomes_big(n_species, a.strains, a.genome_min, a.genome_max, a.divergence, seed=3,
+                                                             device=dev, extra_genome=int(a.long_genome_mbp * 1e6))
+    else:
+        gen_bases, gen_off, species = synth.make_genomes(n_species, a.strains, a.genome_min, a.genome_max,
+                                                         a.divergence, seed=3, device=dev)
+        if a.long_genome_mbp > 0:
+            gen_bases, gen_off, species = synth.add_genome(gen_bases, gen_off, species, int(a.long_genome_mbp * 1e6), seed=4)
     if a.contigs > 1:
         gen_off, species = synth.split_targets(gen_off, species, a.contigs, keep_last_whole=a.long_genome_mbp > 0)
-    # table built on the GPU through the C ABI (mcq_build_table, csrc/mcq_build.hip)
-    torch.cuda.empty_cache()            # the builder allocates with hipMalloc, outside torch's cache
-    t_build = time.time()
-    table = eng.Table(gen_bases.data_ptr(), gen_off.data_ptr(), gen_off.numel() - 1, emulate_ranks=a.emulate_ranks,
-                      device=dev.index or 0)
-    torch.cuda.synchronize(dev)
-    t_build = time.time() - t_build
-    sp32 = species.to(torch.int32).contiguous()
-
-    dbflags = {"auto": 0, "fields32": 0, "fields64": eng.MCQ_DB_LOCS_64, "gw": eng.MCQ_DB_LOCS_GW}[a.loc_format] | \
-              {0: 0, 16: eng.MCQ_DB_SLOTS_16, 64: eng.MCQ_DB_BUCKETS_64}[a.bucket_bytes]
-
-    def make_db(n_shards=1, shard_id=0):
-        return eng.Database(None, None, None, None, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0, flags=dbflags,
-                            device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr,
-                                             tgt2tax=sp32.data_ptr(), n_keys=table.n_keys, n_locs=table.n_locs,
-                                             n_targets=sp32.numel()))
-    # full table (fused single-GPU path / replicas) and/or this rank's hash-range shard
-    db = make_db() if with_fused else None
-    db_shard = make_db(world, rank) if with_sharded else None
-    db_layout = (db or db_shard).layout()
-    db_layout.pop("gw_offsets", None)
-    db_layout["loc_format"] = {eng.MCQ_LOC_FIELDS64: "fields64", eng.MCQ_LOC_FIELDS32: "fields32", eng.MCQ_LOC_GLOBAL_WINDOW: "global_window"}[db_layout["loc_format"]]
-    if a.loc_format == "fields32" and db_layout["loc_format"] != "fields32":
-        sys.exit("--loc-format fields32: the (target, window) fields of this table do not fit 32 bits (the handle chose %s)" % db_layout["loc_format"])
-    n_keys, n_locs, n_targets = table.n_keys, table.n_locs, species.numel()
-    keys, list_off, locs = (None, None, None)
-    want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and (world == 1 or n_locs <= 600_000_000)
-    if want_cpu:
-        keys, list_off, locs, _ = table.to_host()       # only the CPU baseline (the checker) reads these
-    table.close()
+    n_targets = species.numel()
     db_bp = int(gen_off[-1].item())
+    tgt_windows = synth.window_counts(gen_off)
+    t_genomes = time.time() - t_setup
 
-    # ---- reads (distinct batches, resident in HBM before the clock starts)
+    # ---- reads (distinct batches, resident in HBM before the clock starts; sampled before the table is built, because the
+    # sequences of a table built in parts are released before the table itself is allocated)
     L, B = a.read_len, a.batch
     paired = a.workload == "paired"
     if a.workload == "long":
@@ -231,7 +220,7 @@ def main():
     nb = a.distinct_batches or a.steps
     free = torch.cuda.mem_get_info(dev)[0]
     per_batch = (B * a.long_mean * 12) if a.workload == "long" else (B * L * 3)
-    nb = max(1, min(nb, int(free * 0.5) // per_batch))
+    nb = max(1, min(nb, int(free * (0.1 if a.refseq_scale else 0.5)) // per_batch))
     batches, offsets = [], []
     for i in range(nb):
         sd = 1000 + 7919 * rank + i
@@ -242,7 +231,56 @@ def main():
         else:
             r, off, _ = synth.sample_long_reads(gen_bases, gen_off, B, a.long_mean, 0.08, seed=sd)
         batches.append(r); offsets.append(off)
-    del gen_bases
+
+    # ---- table built on the GPU through the C ABI (csrc/mcq_build.hip): in one piece (mcq_build_table), or in feature-hash
+    # parts (mcq_build_parts) when the one-piece temporaries would not fit -- the RefSeq-scale table
+    torch.cuda.empty_cache()            # the builder allocates with hipMalloc, outside torch's cache
+    sp32 = species.to(torch.int32).contiguous()
+    bflags = eng.MCQ_BUILD_REMOVE_OVERPOPULATED if a.remove_overpopulated else 0
+    dbflags = {"auto": 0, "fields32": 0, "fields64": eng.MCQ_DB_LOCS_64, "gw": eng.MCQ_DB_LOCS_GW}[a.loc_format] | \
+              {0: 0, 16: eng.MCQ_DB_SLOTS_16, 64: eng.MCQ_DB_BUCKETS_64}[a.bucket_bytes]
+    in_parts = a.refseq_scale or a.build_parts
+    keys, list_off, locs = (None, None, None)
+    t_build = time.time()
+    if in_parts:
+        parts = eng.Parts(gen_bases.data_ptr(), gen_off.data_ptr(), n_targets, emulate_ranks=a.emulate_ranks, flags=bflags, device=dev.index or 0)
+        torch.cuda.synchronize(dev)
+        t_build = time.time() - t_build
+        n_keys, n_locs, n_parts = parts.n_keys, parts.n_locs, parts.n_parts
+        del gen_bases                   # the sequences go before the table comes
+        torch.cuda.empty_cache()
+        lflags = dbflags & (eng.MCQ_DB_SLOTS_16 | eng.MCQ_DB_BUCKETS_64)
+        db = parts.database(sp32.data_ptr(), flags=lflags) if with_fused else None
+        db_shard = parts.database(sp32.data_ptr(), n_shards=world, shard_id=rank, flags=lflags) if with_sharded else None
+        parts.close()
+        # the CPU leg (the checker) works on the part of the table a batch can touch, read back through the staged entry points
+        want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and with_fused
+        host_table = None
+    else:
+        table = eng.Table(gen_bases.data_ptr(), gen_off.data_ptr(), n_targets, emulate_ranks=a.emulate_ranks, flags=bflags,
+                          device=dev.index or 0)
+        torch.cuda.synchronize(dev)
+        t_build = time.time() - t_build
+        n_parts = 1
+
+        def make_db(n_shards=1, shard_id=0):
+            return eng.Database(None, None, None, None, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0, flags=dbflags,
+                                device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr,
+                                                 tgt2tax=sp32.data_ptr(), n_keys=table.n_keys, n_locs=table.n_locs,
+                                                 n_targets=sp32.numel()))
+        # full table (fused single-GPU path / replicas) and/or this rank's hash-range shard
+        db = make_db() if with_fused else None
+        db_shard = make_db(world, rank) if with_sharded else None
+        n_keys, n_locs = table.n_keys, table.n_locs
+        want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and (world == 1 or n_locs <= 600_000_000)
+        host_table = table.to_host()[:3] if want_cpu else None      # only the CPU baseline (the checker) reads these
+        table.close()
+        del gen_bases
+    db_layout = (db or db_shard).layout()
+    db_layout.pop("gw_offsets", None)
+    db_layout["loc_format"] = {eng.MCQ_LOC_FIELDS64: "fields64", eng.MCQ_LOC_FIELDS32: "fields32", eng.MCQ_LOC_GLOBAL_WINDOW: "global_window"}[db_layout["loc_format"]]
+    if a.loc_format == "fields32" and db_layout["loc_format"] != "fields32":
+        sys.exit("--loc-format fields32: the (target, window) fields of this table do not fit 32 bits (the handle chose %s)" % db_layout["loc_format"])
     max_bases = max(int(o[-1].item()) for o in offsets)
     nq = B // 2 if paired else B
     sharded = None
@@ -366,7 +404,7 @@ def main():
             "config": {
                 "workload": "%s: %d synthetic genomes (%d species x %d strains, %.1f%% divergence, %.2f Gbp) in HBM, %s per step per GPU, "
                             "k=16 s=16 w=128/113" %
-                            ({"c2": "BASELINE configs[1]" if world == 1 else "BASELINE configs[2] shape",
+                            ({"c2": ("BASELINE configs[2] shape (RefSeq scale) on one GPU" if a.refseq_scale else "BASELINE configs[1]") if world == 1 else "BASELINE configs[2] shape",
                               "paired": "BASELINE configs[3] shape", "long": "BASELINE configs[4] shape"}[a.workload],
                              n_targets, n_species, a.strains, 100 * a.divergence, db_bp / 1e9,
                              {"c2": "%d x %d bp single-end reads" % (B, L), "paired": "%d reads = %d pairs of 2x%d bp" % (B, B // 2, L),
@@ -379,7 +417,8 @@ def main():
                 "parallelism": {"single": "1 GPU", "replicas": "replicas only (DB replicated, reads split)",
                                 "sharded": "feature table hash-range-sharded over %d GPU(s), features to their owners and hits back (%s)" %
                                            (world, "device copy" if world == 1 else ("RCCL send/recv groups" if a.backend == "nccl" else "host-staged gloo rehearsal"))}[mode],
-                "setup_s": round(t_setup, 1), "db_build_s": round(t_build, 3),
+                "setup_s": round(t_setup, 1), "db_build_s": round(t_build, 3), "db_build_parts": n_parts, "genomes_s": round(t_genomes, 1),
+                "remove_overpopulated_features": bool(a.remove_overpopulated),
             },
         }
         if sharded_elapsed is not None:
@@ -531,8 +570,22 @@ def main():
     if want_cpu:
         # the GPU buffers still hold the last timed batch's result (fused leg if it ran, else the sharded leg)
         gc, gn = (cands, ncand) if with_fused else (cands_s, ncand_s)
-        out["cpu_baseline"] = cpu_baseline(a, keys, list_off, locs, species, batches, offsets, (a.warmup + a.steps - 1) % nb,
-                                           gc, gn, B, paired, bounded=world > 1)
+        if host_table is not None:
+            from oracle import mc_oracle as orc
+            whole = orc.OracleDb(host_table[0], host_table[1], host_table[2], species.cpu().numpy().astype(np.uint32))
+            odb_of = lambda i: whole
+            note = ""
+        else:
+            # table too large for the host: the oracle runs on the part of it this batch can touch (oracle/subtable.py)
+            from oracle import mc_oracle as orc
+            from oracle import subtable
+
+            def odb_of(i):
+                k_, o_, l_ = subtable.batch_subtable(eng, db, batches[i % nb].data_ptr(), offsets[i % nb].data_ptr(), B, dev, tgt_windows)
+                return orc.OracleDb(k_, o_, l_, species.cpu().numpy().astype(np.uint32))
+            note = "; oracle on the sub-table of each batch's features, read back from the GPU table (oracle/subtable.py)"
+        out["cpu_baseline"] = cpu_baseline(a, odb_of, batches, offsets, (a.warmup + a.steps - 1) % nb,
+                                           gc, gn, B, paired, bounded=world > 1 or host_table is None, note=note)
         parity_ok = out["cpu_baseline"]["gpu_matches_cpu_on_first_batch"] is not False
         ref_file = os.path.join(ROOT, "profiles", "r02_reference_at_scale.json")
         if os.path.exists(ref_file) and world == 1 and n_species == 50 and not a.small:
@@ -561,20 +614,20 @@ def main():
     sys.exit(rc)
 
 
-def cpu_baseline(a, keys, list_off, locs, species, batches, offsets, first, cands, ncand, B, paired, bounded=False):
+def cpu_baseline(a, odb_of, batches, offsets, first, cands, ncand, B, paired, bounded=False, note=""):
     """The oracle (bit-exact CPU restatement of the reference path) timed on this box's
     host cores on a bounded sample of the same workload (whole batches, starting with the
     last timed one, until ~cpu_seconds), and checked against the GPU result of that batch."""
     from oracle import mc_oracle as orc
     aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(aff, a.cpu_threads))
-    odb = orc.OracleDb(keys, list_off, locs, species.cpu().numpy().astype(np.uint32))
     nq = B // 2 if paired else B
     total_t, total_n, ok, nb = 0.0, 0, None, len(batches)
     i = first
     while total_t < a.cpu_seconds and total_n < 16 * B:
         rb = batches[i % nb].cpu().numpy().tobytes()
         ro = offsets[i % nb].cpu().numpy().astype(np.uint64)
+        odb = odb_of(i)                 # (not timed: the table is given, as the reference's database load is)
         t0 = time.perf_counter()
         oc, on = odb.query(rb, ro, paired, max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, threads=cores)
         total_t += time.perf_counter() - t0
@@ -589,7 +642,7 @@ def cpu_baseline(a, keys, list_off, locs, species, batches, offsets, first, cand
         if bounded:
             break
     return {"value": total_n / total_t, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "%d reads (%d whole batches of the timed workload), %d threads, DB build excluded" % (total_n, total_n // B, cores),
+            "sample": "%d reads (%d whole batches of the timed workload), %d threads, DB build excluded%s" % (total_n, total_n // B, cores, note),
             "seconds": total_t, "gpu_matches_cpu_on_first_batch": ok}
 
 

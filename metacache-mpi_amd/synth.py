@@ -36,6 +36,49 @@ def make_genomes(n_species, strains_per_species, len_lo, len_hi, divergence, see
     return bases, off, torch.tensor(species, dtype=torch.int64, device=device)
 
 
+def make_genomes_big(n_species, strains_per_species, len_lo, len_hi, divergence, seed, device, extra_genome=0):
+    """The species/strain model of make_genomes for databases of 100+ Gbp (BASELINE configs[2]): the lengths
+    are drawn first and the bases written in place into ONE buffer (torch.cat of the pieces would need the memory twice).
+    extra_genome > 0 appends one random genome of that many bases as a species of its own (a chromosome of more than 2^17
+    windows).  A different random stream than make_genomes.  Returns (bases uint8, seq_off int64 [n+1], species int64 [n])."""
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    acgt = _ACGT.to(device)
+    L = torch.randint(len_lo, len_hi + 1, (n_species,), generator=g, device=device).cpu()
+    lens = L.repeat_interleave(strains_per_species)
+    if extra_genome > 0:
+        lens = torch.cat([lens, torch.tensor([extra_genome])])
+    off = torch.zeros(lens.numel() + 1, dtype=torch.int64)
+    off[1:] = torch.cumsum(lens, 0)
+    bases = torch.empty(int(off[-1]), dtype=torch.uint8, device=device)
+    t = 0
+    for sp in range(n_species):
+        n = int(L[sp])
+        anc = torch.randint(0, 4, (n,), generator=g, device=device, dtype=torch.uint8)
+        for _ in range(strains_per_species):
+            mut = torch.rand(n, generator=g, device=device) < divergence
+            shift = torch.randint(1, 4, (n,), generator=g, device=device, dtype=torch.uint8)
+            codes = torch.where(mut, (anc + shift) & 3, anc)
+            o = int(off[t])
+            torch.index_select(acgt, 0, codes.to(torch.int32), out=bases[o:o + n])
+            t += 1
+    species = torch.arange(n_species).repeat_interleave(strains_per_species)
+    if extra_genome > 0:
+        o = int(off[t])
+        step = 1 << 26
+        for a0 in range(0, extra_genome, step):
+            m = min(step, extra_genome - a0)
+            torch.index_select(acgt, 0, torch.randint(0, 4, (m,), generator=g, device=device, dtype=torch.int32), out=bases[o + a0:o + a0 + m])
+        species = torch.cat([species, torch.tensor([n_species])])
+    return bases, off.to(device), species.to(device)
+
+
+def window_counts(seq_off, winlen=128, stride=113):
+    """windows of every sequence (src/dna_encoding.h:259-276), int64 [n]"""
+    n = seq_off[1:] - seq_off[:-1]
+    nfull = torch.clamp(n - winlen, min=0) // stride + 1
+    return torch.where(n <= winlen, torch.ones_like(n), nfull + (nfull * stride < n).to(n.dtype))
+
+
 def add_genome(bases, seq_off, species, length, seed):
     """Appends one random genome of `length` bases as a species of its own (a chromosome with more than 2^17 windows
     -- 14.9 Mbp at the default stride -- makes a table RefSeq-like: target and window ids stop fitting 32 bits as fields)."""
