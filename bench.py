@@ -368,7 +368,7 @@ def main():
               "kernel_note": "HIP events between the path's kernels on their stream (mcq_ws_timing), averaged over %d batches; "
                              "achieved = algorithmic bytes per batch / SUM of the three kernels' times; `kernel` = the one with the largest share" % n_batches,
               "algorithmic_bytes_per_launch": algo, "bytes_per_read": algo / B, "launches_timed": n_batches,
-              "per_launch": {k: stats[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow") if k in stats}}
+              "per_launch": {k: stats[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow", "n_two_class", "n_two_class_retry") if k in stats}}
         if kind == "sharded":
             rf["kernel_note"] += "; k_shard_sketch / k_shard_lookup and the exchange are not in this sum -- see whole_step"
             rf["whole_step"] = {"achieved": algo / (elapsed / a.steps) / 1e9, "frac": algo / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,

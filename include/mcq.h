@@ -62,6 +62,8 @@ enum {
                                       de-duplicating it first (the path of > 256 distinct keys / 64-bit keys) */
     MCQ_NO_WAVE16 = 0x800u,        /* test hook: queries of 513..1024 locations take the workgroup path
                                       instead of the second wave stage                     */
+    MCQ_NO_TWO_CLASS = 0x4000u,    /* test hook: long match lists are sorted whole instead of taking the two-class tail
+                                      (light / heavy locations: DESIGN.md section 4); same results either way            */
     MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000u, /* mcq_build_desc.flags: the build option
                                    -remove-overpopulated-features (src/mode_build.cpp:847-1074): a feature whose
                                    per-rank location counts (after the per-rank limit) sum to more than
@@ -148,7 +150,7 @@ typedef struct {
                                    with -maxcand 4, script/ft/QueryGeneric_FT.sh:115) they live in the LDS of the
                                    workgroup kernel, which then takes every query: same results, ~5x slower    */
     uint64_t insert_size_max;   /* insertSizeMax                                         */
-    uint32_t flags;             /* MCQ_QUIRK_SEQ_DROP and the MCQ_FORCE_* / MCQ_NO_WAVE16 test hooks; any other
+    uint32_t flags;             /* MCQ_QUIRK_SEQ_DROP and the MCQ_FORCE_* / MCQ_NO_WAVE16 / MCQ_NO_TWO_CLASS test hooks; any other
                                    bit is rejected with MCQ_E_ARG                         */
 } mcq_query_opts;
 
@@ -176,6 +178,9 @@ typedef struct {
     uint64_t n_cands;           /* candidates written                                  */
     uint64_t n_overflow;        /* queries that left the first wave stage (second wave
                                    stage or block-per-query path)                      */
+    uint64_t n_two_class;       /* queries answered by the two-class tail (heavy locations sorted, light ones only
+                                   as far as they can enter a top list)                */
+    uint64_t n_two_class_retry; /* queries that tail could not prove exact and handed on to the exact path */
 } mcq_stats;
 
 /* replaces sketch_database::read -> hash_multimap::deserialize (the table build) */

@@ -132,7 +132,7 @@ struct OptDev {
     u32 big;                 // pow2ceil(P) x M > 64: the P lists do not fit one wave's lanes -- every query takes the
                              // workgroup kernel, which keeps them in LDS (MCQ_BIGLIST_MAX entries)
     u32 quirk_seq_drop;
-    u32 hooks;               // staged reduce kernel: 1 = no de-duplicating pass, 2 = no second wave stage, 4 = workgroup kernel only
+    u32 hooks;               // 8 = no two-class tail; staged reduce kernel: 1 = no de-duplicating pass, 2 = no second wave stage, 4 = workgroup kernel only
     u64 insert_size_max;
     u32 n_fold;              // fold schedule: (snd -> rcv) in the reference's order
     u32 n_levels;            // rounds of the tree; the edges of one round touch disjoint ranks
@@ -152,11 +152,13 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     u32 err_count;           // queries that exceeded the block path's capacity
     u32 ovf_mid_count;       // queued from the back of the same array: <= 64 features, 513..1024 locations (k_query_wave16)
     u32 n_ovf;               // queries queued (the two counts above are reserved slots: a few are left empty)
+    unsigned long long n_two_class;   // queries answered by the two-class tail
+    unsigned long long n_two_class_retry;   // ... that it gave up and handed to the exact path (lists not provably exact)
     // not zeroed per call (set once per workspace): the first wave stage leaves the probe results of the queries it
     // queues by their length here -- 64 words per back-queue slot: list offset << 16 | list length of the
     // lane's feature -- so the second stage neither sketches nor probes them again.  (In a cache line of its own: the
     // counters above are hammered by atomics, and a load from their line queues behind them.)
-    unsigned long long pad_[26];
+    unsigned long long pad_[24];
     unsigned long long* probe_buf;
 };
 static_assert(offsetof(CountersDev, probe_buf) == 256, "probe_buf sits 256 bytes into the block");
@@ -1343,6 +1345,119 @@ __device__ __forceinline__ u32 topk_all_lds(const DbDev& db, const OptDev& opt, 
         wave_sync();
     }
     return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, lf, q, lane, mx, wt);
+}
+
+// ---- rows 8-11 in two classes (large tables: most of a read's locations are chance hits on unrelated targets) ------
+// On a RefSeq-scale table a 150-base read gathers ~900 locations of which ~700 are single chance hits, each alone on its
+// target; sorting and sweeping all of them to find the dozen targets that matter is most of the work.  The window space is
+// cut into cells of 2^cs >= numWindows words (cell = word >> cs; bit fields or global-window words alike): a window range
+// spans at most two adjacent cells, so a word whose own cell holds nothing else and whose two neighbour cells are empty --
+// a LIGHT word -- lies in no range with a second location: every range that contains it has exactly one hit.  All other
+// words are HEAVY, and a heavy word's range neighbours are heavy too (they share or neighbour its cell), so the sweep over
+// the heavy words alone gives their exact hit counts.  Two bit maps in LDS (cell occupied / cell holds two or more),
+// indexed by the cell's low bits: a collision only makes a light word heavy -- more work, same result.
+//
+// The top lists need no run heads either: list r = the first M distinct taxa among ALL words of virtual rank r taken as
+// entries (hits of the range ending at the word, word) in the order (hits descending, word ascending) -- per taxon the
+// first such entry is the reference's (max hits, first candidate reaching them), and weaker entries of a target that has a
+// better one retire with its taxon.  Light entries all have one hit, so they come last, in word order: only a PREFIX of
+// them (the smallest few, words below theta) can enter a list.  The lists are built from the heavy run heads plus that
+// prefix; they are exact when every list is full and ends in an entry that precedes every omitted light word (two or more
+// hits, or a word below theta) -- else the caller falls back to the exact path over all words.
+#define MCQ_CELL_LOG 15u                          // 32768 cells per map: 1024 words of LDS each
+#define MCQ_CELL_WORDS (1u << (MCQ_CELL_LOG - 5))
+__device__ __forceinline__ u32 cell_shift(u32 numWindows) { return 32u - (u32)__builtin_clz(numWindows - 1); }     // 2^cs >= numWindows (>= 2)
+// G threads clear both maps
+__device__ __forceinline__ void cells_clear(u32* occ, u32* multi, u32 tid, u32 G) {
+    u32 zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));             // (not hoistable: see dedup_insert)
+    const uint4 z = make_uint4(zero, zero, zero, zero);
+    for (u32 i = tid; i < MCQ_CELL_WORDS / 4; i += G) { reinterpret_cast<uint4*>(occ)[i] = z; reinterpret_cast<uint4*>(multi)[i] = z; }
+}
+__device__ __forceinline__ void cells_insert(u32 key, u32 cs, u32* occ, u32* multi) {
+    const u32 bit = (key >> cs) & ((1u << MCQ_CELL_LOG) - 1), m = 1u << (bit & 31);
+    if (atomicOr(&occ[bit >> 5], m) & m) atomicOr(&multi[bit >> 5], m);
+}
+__device__ __forceinline__ bool cells_heavy(u32 key, u32 cs, const u32* occ, const u32* multi) {
+    const u32 bit = (key >> cs) & ((1u << MCQ_CELL_LOG) - 1);
+    const u32 lo = (bit - 1) & ((1u << MCQ_CELL_LOG) - 1), hi = (bit + 1) & ((1u << MCQ_CELL_LOG) - 1);
+    return ((multi[bit >> 5] >> (bit & 31)) | (occ[lo >> 5] >> (lo & 31)) | (occ[hi >> 5] >> (hi & 31))) & 1u;
+}
+
+// Top lists + fold + write from the heavy run heads (H[0..nheads) packed (hits << JB | JMASK - j), j indexing the sorted
+// distinct heavy words SK) and the light prefix (lkey: this lane's light word, MCQ_EMPTY = none; ascending or not does not
+// matter).  Entries are compared as 64-bit words (hits << 32 | ~word): heavy and light ones in one order.  NC chunks of 64
+// heads.  light_omitted: light words >= theta exist that are not among the entries.  Returns the number of candidates
+// written, or ~0u when the lists cannot be proven exact (nothing written then).  scr: 192 words of LDS (64 x u64, 64 x u32).
+template <int JB, int NC, class LF>
+__device__ __forceinline__ u32 topk_two_class(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* SK, u32 D, const u32* H, u32 nheads,
+                                              u32 lkey, bool light_omitted, u32 theta, u32 numWindows, const LF& lf, u64 q, u32 lane, u32* scr) {
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    const bool p2 = (P & (P - 1)) == 0;
+    const u32 JMASK = (1u << JB) - 1;
+    unsigned long long* mx = reinterpret_cast<unsigned long long*>(scr);
+    u32* wt = scr + 128;
+    unsigned long long w[NC + 1]; u32 tax[NC + 1], rk[NC + 1];
+#pragma unroll
+    for (int c = 0; c <= NC; ++c) {
+        w[c] = 0; tax[c] = MCQ_EMPTY; rk[c] = 0;
+        u32 key = MCQ_EMPTY, hits = 0;
+        if (c < NC) {
+            if ((u32)(c * 64) >= nheads) continue;               // wave-uniform
+            const u32 k = c * 64 + lane;
+            const u32 v = (k < nheads) ? H[k] : 0u;
+            if (v) { key = SK[JMASK - (v & JMASK)]; hits = v >> JB; }
+        } else if (lkey != MCQ_EMPTY) { key = lkey; hits = 1; }
+        const u32 tgt = lf.tgt(hits ? key : SK[0]);               // (idle lanes look up a real word)
+        if (hits && tgt < db.n_targets) tax[c] = db.tgt2tax[tgt];
+        rk[c] = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+        if (hits && tax[c] != MCQ_EMPTY) w[c] = ((unsigned long long)hits << 32) | (u32)~key;
+    }
+    const u32 rl = lane / seg, li = lane - rl * seg;
+    const bool lslot = (li < M) && (rl < P);
+    u32 Ltax = MCQ_EMPTY; unsigned long long Lw = 0;
+    for (u32 i = 0; i < M; ++i) {
+        mx[lane] = 0;
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c <= NC; ++c) if (w[c] != 0) atomicMax(&mx[rk[c]], w[c]);
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c <= NC; ++c) if (w[c] != 0 && w[c] == mx[rk[c]]) wt[rk[c]] = tax[c];          // words are distinct: one winner per rank
+        wave_sync();
+        const unsigned long long ml = mx[rl];
+        const u32 wtl = wt[rl];
+        if (lslot && li == i && ml != 0) { Ltax = wtl; Lw = ml; }
+#pragma unroll
+        for (int c = 0; c <= NC; ++c) if (w[c] != 0 && tax[c] == wt[rk[c]]) w[c] = 0;                  // (a live entry's rank has a fresh winner)
+        wave_sync();
+    }
+    // exact? every list full and ending before every omitted light word
+    if (light_omitted) {
+        const bool last = lslot && li == M - 1;
+        const bool ok = Lw != 0 && ((u32)(Lw >> 32) >= 2 || (u32)~(u32)Lw < theta);
+        if (__ballot(last && !ok)) return ~0u;
+    }
+    u32* mx32 = scr; u32* wt32 = scr + 64;
+    wave_sync();
+    if (P > 1) return fold_lists_write<u32, u32, JB>(db, opt, out, SK, Ltax, (u32)(Lw >> 32) << JB, numWindows, lf, q, lane, mx32, wt32);
+    // one list, with window ranges: a single hit is its own range; else the range that ends at the word, inside SK
+    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lw != 0));
+    if (lane < n) {
+        const u32 key = ~(u32)Lw, hits = (u32)(Lw >> 32);
+        u32 t, tb;
+        lf.locate(key, t, tb);
+        u32 beg = key - tb;
+        if (hits >= 2) {
+            const u32 lowkey = range_low<u32>(key, tb, numWindows);
+            u32 lo = 0, hi = D;
+            while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (SK[mid] < lowkey) lo = mid + 1; else hi = mid; }
+            beg = SK[lo] - tb;
+        }
+        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = make_uint4(Ltax, hits, beg, key - tb);
+    }
+    if (lane == 0) out.ncand[q] = n;
+    return n;
 }
 
 // ---- rows 10-11 for the workgroup kernels ----------------------------------------------------------

@@ -545,6 +545,128 @@ __device__ __forceinline__ u32 load_dedup_insert(const u32* __restrict__ src, u3
     return dedup_insert<E>(r, buf, hits, T, lane);
 }
 
+// the same for a list that sits in the wave's own LDS (src may lie inside `hits`: everything is in registers before the
+// table is cleared)
+template <int E>
+__device__ __forceinline__ u32 lds_dedup_insert(const u32* src, u32* buf, u32* hits, u32 T, u32 lane) {
+    u32 r[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { const u32 t = e * 64 + lane; r[e] = t < T ? src[t] : MCQ_EMPTY; }
+    wave_sync();
+    return dedup_insert<E>(r, buf, hits, T, lane);
+}
+
+// Heavy words of the two-class tail: nH of them staged in hits[0..nH), E = registers per lane they need.  They repeat
+// (a true target is hit by up to s features per window), so the distinct-key table is tried first -- any number of words,
+// up to 256 distinct ones -- and only a list with more distinct words is sorted raw (E >= 8 then).  Either way the sweep
+// leaves the sorted words SK[0..D) and the run heads' packed words, which go, with the light prefix, into the lists.
+template <int E, class LF>
+__device__ __forceinline__ u32 heavy_tail(const DbDev& db, const OptDev& opt, const OutDev& out, u32 nH, u32 lkey, bool omitted, u32 theta, u32 safe,
+                                          u32 numWindows, const LF& lf, u64 q, u32 lane, u32* buf, u32* hits) {
+    constexpr int JB = 10;                                   // entry index of the lists: up to 1024 sorted words
+    u32 D = 0;
+    u32 *SK = dedup_sk(hits), *H = buf;
+    bool nine = true;                                        // H packed with 9 index bits (distinct-key sweeps) or JB
+    if (nH) {
+        u32 rh[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const u32 t = e * 64 + lane; rh[e] = t < nH ? hits[t] : MCQ_EMPTY; }
+        wave_sync();
+        u32 k1 = MCQ_EMPTY, incl1 = 0, t1 = 0, tb1 = 0;
+        const u32 Dd = dedup_insert<E>(rh, buf, hits, nH, lane);
+        if (E <= 4 || Dd <= MCQ_DEDUP_MAX_D) {
+            D = dedup_finish(Dd, buf, hits, lane, lf, k1, incl1, t1, tb1);
+            if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, tb1, H, D, numWindows, lf, lane);
+            else sweep_targets_weighted(SK, dedup_wp(hits), H, D, numWindows, lf, lane);
+        } else if constexpr (E > 4) {
+            wave_sync();
+            wave_regsort<u32, E>(rh, lane);
+            SK = buf; H = hits; D = nH; nine = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) SK[e * 64 + lane] = rh[e];
+            wave_sync();
+            sweep_targets_wave<u32, JB>(SK, H, D, numWindows, lf, lane);
+        }
+    } else wave_sync();
+    // run heads to the front of H (in place: writes trail reads), re-packed with JB index bits.  A head with ONE hit is no
+    // better than a light word: it stays only below theta -- the others join the omitted light words (same proof: one hit,
+    // word >= theta)
+    u32 nheads = 0;
+    bool dropped = false;
+    for (u32 base = 0; base < D; base += 64) {
+        const u32 j = base + lane;
+        const u32 hv = (j < D) ? H[j] : 0;
+        const u32 h = nine ? hv >> 9 : hv >> JB, jb = nine ? 511u - (hv & 511u) : ((1u << JB) - 1) - (hv & ((1u << JB) - 1));
+        const bool one = hv != 0 && h == 1u && SK[jb] >= theta;
+        const u64 hb = __ballot(hv != 0 && !one);
+        if (hv != 0 && !one) H[nheads + lane_rank(hb)] = (h << JB) | (((1u << JB) - 1) - jb);
+        nheads += (u32)__builtin_popcountll(hb);
+        dropped = dropped || __ballot(one) != 0;
+    }
+    wave_sync();
+    if (D == 0 && lane == 0) SK[0] = safe;                   // (idle lanes look up SK[0])
+    wave_sync();
+    if (nheads > 256) return ~1u;                            // (heads with two or more hits, or below theta: a dozen or two)
+    // scratch of the lists: 192 words of H's segment that neither the heads (<= 256 words) nor, in the other segment, SK touch
+    const u32 n = topk_two_class<JB, 4>(db, opt, out, SK, D, H, nheads, lkey, omitted || dropped, theta, numWindows, lf, q, lane, H + 512 + 64);
+    return n == ~0u ? ~1u : n;
+}
+
+// ---- the two-class tail of a wave (mcq_device.hpp, "rows 8-11 in two classes") for a raw match list held in registers,
+// r[e] = word e * 64 + lane, T words.  buf / hits: the wave's two LDS segments (>= 1024 words each).
+// Returns the number of candidates written; ~0u = not attempted or not taken, r[] untouched, the caller sorts the raw
+// list as before; ~1u = given up after the registers were spent: the caller queues the query for the exact path.
+#define MCQ_TWO_CLASS_MAX_PM 16u        // beyond P x M = 16 the light prefix rarely fills the lists: not attempted
+#ifndef MCQ_TWO_CLASS_EXPECT
+#define MCQ_TWO_CLASS_EXPECT 40.0f      // light words expected below theta (tuning knob)
+#endif
+template <int E, class LF>
+__device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt, const OutDev& out, u32 (&r)[E], u32 T, u32 numWindows,
+                                              float word_space, const LF& lf, u64 q, u32 lane, u32* buf, u32* hits) {
+    if (opt.P * opt.max_cand > MCQ_TWO_CLASS_MAX_PM || (opt.hooks & 8u)) return ~0u;
+    const u32 cs = cell_shift(numWindows);
+    u32* occ = buf; u32* multi = hits;
+    cells_clear(occ, multi, lane, 64);
+    wave_sync();
+    // (tried: every register's atomics issued back to back without a branch, zeros ORed where nothing is to be set -- twice
+    // the LDS atomics and 5 spilled VGPRs: second wave stage 5.1 -> 7.5 ms on the RefSeq-scale table)
+#pragma unroll
+    for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T) cells_insert(r[e], cs, occ, multi);
+    wave_sync();
+    u32 hm = 0;                                              // bit e: r[e] is heavy
+#pragma unroll
+    for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T && cells_heavy(r[e], cs, occ, multi)) hm |= 1u << e;
+    wave_sync();                                             // the maps are dead: heavy words -> hits[0..nH), light prefix -> buf[0..nP)
+    const float th = word_space * MCQ_TWO_CLASS_EXPECT * __builtin_amdgcn_rcpf((float)T);
+    const u32 theta = th >= 4294967040.0f ? 0xFFFFFFFEu : (u32)th;
+    u32 nH = 0, nL = 0, nP = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if ((u32)(e * 64) >= T) break;                       // wave-uniform
+        const bool valid = (u32)(e * 64) + lane < T, heavy = (hm >> e) & 1u;
+        const u64 bh = __ballot(valid && heavy);
+        if (valid && heavy) hits[nH + lane_rank(bh)] = r[e];
+        nH += (u32)__builtin_popcountll(bh);
+        nL += (u32)__builtin_popcountll(__ballot(valid && !heavy));
+        const bool pre = valid && !heavy && r[e] < theta;
+        const u64 bp = __ballot(pre);
+        if (pre) { const u32 i = nP + lane_rank(bp); if (i < 64) buf[i] = r[e]; }
+        nP += (u32)__builtin_popcountll(bp);
+    }
+    wave_sync();
+    if (nP > 64) return ~0u;                                 // theta too generous for this read (words far from uniform)
+    const u32 safe = bcast(r[0], 0);                         // any real word (T >= 1)
+    const u32 lkey = lane < nP ? buf[lane] : MCQ_EMPTY;
+    const bool omitted = nL > nP;
+    // from here on r[] is spent: the heavy words come back from LDS into as many registers as they need
+    if (nH <= 64)  return heavy_tail<1>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
+    if (nH <= 128) return heavy_tail<2>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
+    if (nH <= 256) return heavy_tail<4>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
+    if (nH <= 512) return heavy_tail<8>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
+    if constexpr (E > 8) return heavy_tail<16>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
+    return ~1u;
+}
+
 // geometry of one read (or pair) on the wave path
 struct ReadGeom {
     u64 o0, o1;          // byte offsets of the mates
@@ -801,8 +923,12 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     u32* feat = hits + 64;
     const u32 nwaves = gridDim.x * 4;
     const u32 n_mid = ctr->ovf_mid_count;
-    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
+    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_retry = 0;
     u32 fq_next = 0, fq_left = 0;                      // this wave's reservation in the front queue (wide reads with > 1024 locations)
+    // size of the space the location words live in (for the light-word threshold of the two-class tail)
+    float word_space;
+    if constexpr (GW) word_space = (float)gwd.off[db.n_targets];
+    else word_space = (db.wb < 32 && ((u64)db.n_targets << db.wb) < 0xFFFFFFFFull) ? (float)((u64)db.n_targets << db.wb) : 4294967040.0f;
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
         const u32 q32 = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
         if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
@@ -884,6 +1010,22 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         {
             u32 r[16];
             gather_regs2<16>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, hits);
+            if constexpr (!TAP) {                       // (the taps want the whole sorted list)
+                const u32 n2 = two_class_tail<16>(db, opt, out, r, T, numWindows, word_space, lf, q, lane, buf, hits);
+                if (n2 == ~1u) {                        // given up after the registers were spent: the workgroup kernel takes it
+                    st_loc -= T; st_retry += 1;
+                    if (fq_left == 0) {
+                        u32 base = 0;
+                        if (lane == 0) base = atomicAdd(&ctr->ovf_count, MCQ_OVF_CHUNK);
+                        fq_next = bcast(base, 0); fq_left = MCQ_OVF_CHUNK;
+                    }
+                    if (lane == 0) ovf_list[fq_next] = q32;
+                    ++fq_next; --fq_left;
+                    wave_sync();
+                    continue;
+                }
+                if (n2 != ~0u) { st_cand += n2; st_two += 1; wave_sync(); continue; }
+            }
             wave_regsort<u32, 16>(r, lane);
 #pragma unroll
             for (int e = 0; e < 16; ++e) buf[e * 64 + lane] = r[e];
@@ -895,6 +1037,8 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         wave_sync();
     }
     if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
+    if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
+    if (lane == 0 && st_retry) atomicAdd(&ctr->n_two_class_retry, st_retry);
     if (lane == 0 && (st_feat | st_loc | st_hit)) {
         if (st_feat) atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);
@@ -1581,9 +1725,9 @@ static void fold_schedule(u32 P, std::vector<std::pair<u32, u32>>& sched, std::v
 
 // flags of mcq_query_opts a caller may set (anything else is rejected: a stray bit must not change results silently)
 #ifdef MCQ_PROFILE_HOOKS        // profiling builds only: bits 12..15 = stop the fused kernel after stage 1..5 (results invalid)
-#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16 | 0xF000u)
+#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16 | MCQ_NO_TWO_CLASS | 0xF000u)
 #else
-#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16)
+#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16 | MCQ_NO_TWO_CLASS)
 #endif
 static int force_bits(u32 flags) {
     int f = ((flags & MCQ_FORCE_BLOCK_PATH) ? 1 : 0) | ((flags & MCQ_FORCE_RAW_SORT) ? 2 : 0) | ((flags & MCQ_NO_WAVE16) ? 4 : 0);
@@ -1607,7 +1751,7 @@ static int make_opt(const mcq_query_opts* o, OptDev& d) {
     d.max_cand = o->max_cand; d.P = P; d.seg = d.big ? o->max_cand : 64 / p2;
     d.quirk_seq_drop = (o->flags & MCQ_QUIRK_SEQ_DROP) ? 1 : 0;
     d.hooks = ((o->flags & MCQ_FORCE_RAW_SORT) ? 1u : 0u) | ((o->flags & MCQ_NO_WAVE16) ? 2u : 0u) |
-              (((o->flags & MCQ_FORCE_BLOCK_PATH) || d.big) ? 4u : 0u);
+              (((o->flags & MCQ_FORCE_BLOCK_PATH) || d.big) ? 4u : 0u) | ((o->flags & MCQ_NO_TWO_CLASS) ? 8u : 0u);
     d.insert_size_max = o->insert_size_max;
     std::vector<std::pair<u32, u32>> sched;
     std::vector<u32> level_end;
@@ -2231,6 +2375,7 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
         stats->n_features = ws->ctr_host->n_features; stats->n_hit_features = ws->ctr_host->n_hit_features;
         stats->n_locations = ws->ctr_host->n_locations; stats->n_cands = ws->ctr_host->n_cands;
         stats->n_overflow = ws->ctr_host->n_ovf;
+        stats->n_two_class = ws->ctr_host->n_two_class; stats->n_two_class_retry = ws->ctr_host->n_two_class_retry;
     }
     if (ws->ctr_host->err_count)
         return fail(MCQ_E_CAPACITY, std::to_string(ws->ctr_host->err_count) + " queries exceeded the workspace's per-query capacity");

@@ -23,6 +23,7 @@ MCQ_LOC_FIELDS64, MCQ_LOC_FIELDS32, MCQ_LOC_GLOBAL_WINDOW = 0, 1, 2
 MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000   # Table / Database.build: -remove-overpopulated-features
 MCQ_FORCE_RAW_SORT = 0x400       # debug: wave path without the de-duplicating pass
 MCQ_NO_WAVE16 = 0x800            # debug: 513..1024 locations take the workgroup path, not the second wave stage
+MCQ_NO_TWO_CLASS = 0x4000        # debug: long match lists are sorted whole (no light / heavy split)
 
 MCQ_OK, MCQ_E_ARG, MCQ_E_HIP, MCQ_E_CAPACITY, MCQ_E_UNSUPPORTED = 0, -1, -2, -3, -4
 
@@ -73,7 +74,7 @@ class Result(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("n_features", C.c_uint64), ("n_hit_features", C.c_uint64),
-                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64)]
+                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64), ("n_two_class", C.c_uint64), ("n_two_class_retry", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}

@@ -172,7 +172,7 @@ def test_many_strains_cross_every_list_size_boundary():
     for flags in (0, eng.MCQ_DB_LOCS_64, eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_BUCKETS_64):
         db = dbbuild.make_database(keys, off, locs, species, flags=flags)
         ws = eng.Workspace(db, n, n * L)
-        for qf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16):
+        for qf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16, eng.MCQ_NO_TWO_CLASS):
             cands, ncand = ws.query_host(rb, ro, False, max_cand=4, emulate_ranks=2, flags=qf)
             _compare(cands, ncand, oc, on, "many strains flags=%x qf=%x" % (flags, qf))
         s = ws.sync()
@@ -214,9 +214,11 @@ def test_crafted_lists_cross_the_distinct_key_limits():
         ws = eng.Workspace(db, n, n * L)
         for P, M in ((2, 2), (4, 4), (1, 3)):
             oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, threads=8)
-            for qf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16):
+            for qf in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_NO_WAVE16, eng.MCQ_NO_TWO_CLASS):
                 cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P, flags=qf)
                 _compare(cands, ncand, oc, on, "crafted lists flags=%x P=%d M=%d qf=%x" % (flags, P, M, qf))
+                tc = ws.sync()["n_two_class"]
+                assert (tc == 0) if (qf & (eng.MCQ_NO_TWO_CLASS | eng.MCQ_NO_WAVE16) or flags == eng.MCQ_DB_LOCS_64) else True, (qf, tc)
         s = ws.sync()
         moff, m = ws.debug_matches(rb, ro, False)
         T = np.diff(moff.astype(np.int64))
@@ -326,3 +328,50 @@ def test_more_wide_queries_than_the_old_queue_held():
     want_c = np.tile(oc, (reps, 1, 1))
     mask = np.arange(4)[None, :] < want_n[:, None]
     assert np.array_equal(cands[mask], want_c[mask])
+
+
+def test_two_class_tail_on_chance_hits():
+    """What a RefSeq-scale table does to a read, in small: every feature of a read has a long list of locations that are
+    (almost all) alone on their target -- chance hits -- plus the read's true target.  600-1000 locations per read: the second
+    wave stage, whose two-class tail sorts only the heavy words and takes the light ones as far as they can enter a list.
+    Same results as the oracle with and without it, in all three location forms, single-end and paired, P x M up to 16 (and
+    32, where the tail is not attempted); most reads must have taken it."""
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    rng = np.random.default_rng(77)
+    n, L, n_tgt, n_win = 3000, 150, 20000, 3000
+    seqs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(n)]
+    feats = {}
+    for i, sq in enumerate(seqs):
+        for w0, w1 in orc.windows(L):
+            for f in orc.sketch(sq[w0:w1].encode()):
+                feats.setdefault(int(f), []).append(i)
+    keys = np.array(sorted(feats), np.uint32)
+    lists = []
+    for f in keys:
+        per = int(rng.integers(18, 34))
+        t = rng.integers(0, n_tgt, size=per).astype(np.uint64)
+        w = rng.integers(0, n_win, size=per).astype(np.uint64)
+        own = []
+        for i in feats[int(f)]:                   # the read's own target: a few windows around one locus, so that ranges add up
+            own.append((np.uint64(i % n_tgt) << np.uint64(32)) | np.uint64(100 + int(rng.integers(0, 3))))
+        lists.append(np.sort(np.concatenate([(t << np.uint64(32)) | w, np.array(own, np.uint64)])))
+    off = np.zeros(len(keys) + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in lists])
+    locs = np.concatenate(lists)
+    t2t = (np.arange(n_tgt) // 3).astype(np.uint32)
+    rb, ro = orc.pack_reads([s.encode() for s in seqs])
+    odb = orc.OracleDb(keys, off, locs, t2t)
+    for dbflags in (0, eng.MCQ_DB_LOCS_GW, eng.MCQ_DB_LOCS_64):
+        db = eng.Database(keys, off, locs, t2t, flags=dbflags)
+        for paired in (False, True):
+            nq = n // 2 if paired else n
+            ws = eng.Workspace(db, nq, n * L)
+            for P, M in ((2, 2), (1, 4), (4, 4), (8, 2), (8, 4)):
+                oc, on = odb.query(rb, ro, paired, max_cand=M, emulate_ranks=P, threads=8)
+                for qf in (0, eng.MCQ_NO_TWO_CLASS):
+                    cands, ncand = ws.query_host(rb, ro, paired, max_cand=M, emulate_ranks=P, flags=qf)
+                    _compare(cands, ncand, oc, on, "two-class dbflags=%x paired=%d P=%d M=%d qf=%x" % (dbflags, paired, P, M, qf))
+                    st = ws.sync()
+                    if dbflags != eng.MCQ_DB_LOCS_64 and not qf and P * M <= 16 and not paired:
+                        assert st["n_two_class"] > nq // 2, st
+                    if qf or dbflags == eng.MCQ_DB_LOCS_64 or P * M > 16:
+                        assert st["n_two_class"] == 0, st
