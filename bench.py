@@ -368,7 +368,7 @@ def main():
               "kernel_note": "HIP events between the path's kernels on their stream (mcq_ws_timing), averaged over %d batches; "
                              "achieved = algorithmic bytes per batch / SUM of the three kernels' times; `kernel` = the one with the largest share" % n_batches,
               "algorithmic_bytes_per_launch": algo, "bytes_per_read": algo / B, "launches_timed": n_batches,
-              "per_launch": {k: stats[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow", "n_two_class", "n_two_class_retry") if k in stats}}
+              "per_launch": {k: stats[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow", "n_two_class", "n_two_class_retry", "n_narrow_queued") if k in stats}}
         if kind == "sharded":
             rf["kernel_note"] += "; k_shard_sketch / k_shard_lookup and the exchange are not in this sum -- see whole_step"
             rf["whole_step"] = {"achieved": algo / (elapsed / a.steps) / 1e9, "frac": algo / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
@@ -423,6 +423,7 @@ def main():
         }
         if sharded_elapsed is not None:
             out["sharded_all_to_all"] = {"value": total_reads / sharded_elapsed, "unit": "reads/s", "ms_per_step": 1e3 * sharded_elapsed / a.steps,
+                                         "rccl_ranks": (sh_stats or {}).get("exchange_bytes_per_step", {}).get("rccl_ranks"),
                                          "per_step_per_gpu": sh_stats, "matches_fused_kernel_on_every_rank": sharded_ok,
                                          "note": "feature table hash-range-sharded over %d GPU(s), features and hits exchanged by all-to-all" % world}
         if fused_elapsed is not None and world > 1:
@@ -498,10 +499,32 @@ def main():
             # round trips); it is an extra untimed step in front of the warmup
             step_sharded(0)
             sharded.sync(stream)
-            sharded_elapsed = timed(step_sharded, lambda: sharded.timing(True))
+            xb0 = {}
+
+            def start_sharded_clock():
+                sharded.timing(True)
+                xb0.update(sharded.exchange_bytes())
+            sharded_elapsed = timed(step_sharded, start_sharded_clock)
             sh_stats = sharded.sync(stream)
             sh_kms, sh_kn = sharded.kernel_times()
+            stage_ms, stage_n = sharded.stage_times()
             sharded.timing(False)
+            xb1 = sharded.exchange_bytes()
+            nbt = max(1, xb1["batches"] - xb0["batches"])
+            per = {k: (xb1[k] - xb0[k]) / nbt for k in ("x1", "x2_ends", "x2_locations", "own_blocks")}
+            loc_bytes = (db_shard.layout()["loc_bytes"])
+            payload = 4 * sh_stats["n_features"] + 4 * sh_stats["n_features"] + loc_bytes * sh_stats["n_locations"]
+            sent = per["x1"] + per["x2_ends"] + per["x2_locations"] + per["own_blocks"]
+            sh_stats["exchange_bytes_per_step"] = dict(
+                per, rccl_ranks=xb1["rccl_ranks"], block_features=xb1["block_features"], block_locations=xb1["block_locations"],
+                to_other_ranks=per["x1"] + per["x2_ends"] + per["x2_locations"],
+                padding_share=(1.0 - payload / sent) if sent else None,
+                note="bytes this rank hands to the transport per batch: X1 feature blocks, X2 list ends + tile starts, X2 locations (%d-B words); "
+                     "own_blocks never leave the device; padding_share = 1 - (features x 4 B out + list ends x 4 B + locations back) / all of it" % loc_bytes)
+            sh_stats["stage_ms_per_step"] = dict({k: v / max(1, stage_n) for k, v in stage_ms.items()},
+                                                 S3=sum(sh_kms) / max(1, sh_kn),
+                                                 note="events around the stages on their streams (they overlap across batches: the sum exceeds ms_per_step); "
+                                                      "S1 sketch + route, X1 features out, S2 owner-side lookup, X2 lists back, S3 home-side reduce kernels")
             sh_stats["exchange_block_features_locations"] = list(sharded.caps())
             if with_fused:
                 # same batch through the fused kernel on the replicated table: bit-identical results expected on every rank

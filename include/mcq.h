@@ -181,6 +181,9 @@ typedef struct {
     uint64_t n_two_class;       /* queries answered by the two-class tail (heavy locations sorted, light ones only
                                    as far as they can enter a top list)                */
     uint64_t n_two_class_retry; /* queries that tail could not prove exact and handed on to the exact path */
+    uint64_t n_narrow_queued;   /* queries with narrow window ranges (short reads, pairs) counted in the workgroup kernels' queue:
+                                   from 4096 on they get the workgroup kernel with the two-class tail (an upper bound: an
+                                   entry may be counted twice)                                            */
 } mcq_stats;
 
 /* replaces sketch_database::read -> hash_multimap::deserialize (the table build) */
@@ -362,6 +365,15 @@ int mcq_shard_get_caps(const mcq_shard* ctx, uint64_t* features_per_peer, uint64
 /* timing of the home side's reduce kernels, as mcq_ws_timing / mcq_ws_kernel_times */
 int mcq_shard_timing(mcq_shard* ctx, int enable);
 int mcq_shard_kernel_times(mcq_shard* ctx, double* ms /* [3] */, uint64_t* n_batches);
+/* ... and of the other stages of a batch (events on the streams they run on; enabled by mcq_shard_timing): ms[0] S1 (window
+ * count + sketch + route), ms[1] X1 (feature blocks to their owners), ms[2] S2 (owner-side lookup), ms[3] X2 (list ends and
+ * locations back), summed over the n batches harvested so far.  The stages of consecutive batches overlap: the sum of a
+ * batch's stages is more than the step time.                                                                          */
+int mcq_shard_stage_times(mcq_shard* ctx, double* ms /* [4] */, uint64_t* n_batches);
+/* accounting of the exchanges since the context was created: out[0] batches; bytes handed to the transport for OTHER ranks in
+ * out[1] X1, out[2] X2 list ends + tile starts, out[3] X2 locations; out[4] bytes of this rank's own blocks; out[5] ranks of
+ * the RCCL communicator (0 = another transport); out[6], out[7] block sizes of the padded mode (features / locations per peer) */
+int mcq_shard_exchange_bytes(const mcq_shard* ctx, uint64_t* out /* [8] */);
 
 /* ---- row f4: FASTQ ingest on the GPU ------------------------------------------------
  * text: raw FASTQ bytes in DEVICE memory (4 lines per record, as fastq_reader::read_next reads

@@ -139,6 +139,7 @@ struct OptDev {
     unsigned char level_end[8];          // edges [level_end[l-1], level_end[l]) belong to round l
     unsigned char fold_snd[MCQ_MAX_FOLD];
     unsigned char fold_rcv[MCQ_MAX_FOLD];
+    u64 tc_limit;            // workgroup kernels: queries shorter than this belong to the two-class kernel (0 = there is none)
 };
 
 struct OutDev {
@@ -154,11 +155,13 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     u32 n_ovf;               // queries queued (the two counts above are reserved slots: a few are left empty)
     unsigned long long n_two_class;   // queries answered by the two-class tail
     unsigned long long n_two_class_retry;   // ... that it gave up and handed to the exact path (lists not provably exact)
+    unsigned long long n_narrow;      // front-queue entries with narrow window ranges (query shorter than OptDev::tc_limit): the two-class
+                                      // workgroup kernel's share, if it is worth a kernel
     // not zeroed per call (set once per workspace): the first wave stage leaves the probe results of the queries it
     // queues by their length here -- 64 words per back-queue slot: list offset << 16 | list length of the
     // lane's feature -- so the second stage neither sketches nor probes them again.  (In a cache line of its own: the
     // counters above are hammered by atomics, and a load from their line queues behind them.)
-    unsigned long long pad_[24];
+    unsigned long long pad_[23];
     unsigned long long* probe_buf;
 };
 static_assert(offsetof(CountersDev, probe_buf) == 256, "probe_buf sits 256 bytes into the block");
@@ -1364,23 +1367,25 @@ __device__ __forceinline__ u32 topk_all_lds(const DbDev& db, const OptDev& opt, 
 // them (the smallest few, words below theta) can enter a list.  The lists are built from the heavy run heads plus that
 // prefix; they are exact when every list is full and ends in an entry that precedes every omitted light word (two or more
 // hits, or a word below theta) -- else the caller falls back to the exact path over all words.
-#define MCQ_CELL_LOG 15u                          // 32768 cells per map: 1024 words of LDS each
-#define MCQ_CELL_WORDS (1u << (MCQ_CELL_LOG - 5))
+#define MCQ_CELL_LOG 15u                          // one wave: 32768 cells per map, 1024 words of LDS each (the workgroup kernel: 2^17)
 __device__ __forceinline__ u32 cell_shift(u32 numWindows) { return 32u - (u32)__builtin_clz(numWindows - 1); }     // 2^cs >= numWindows (>= 2)
-// G threads clear both maps
+// G threads clear both maps (2^(LOG - 5) words each)
+template <u32 LOG = MCQ_CELL_LOG>
 __device__ __forceinline__ void cells_clear(u32* occ, u32* multi, u32 tid, u32 G) {
     u32 zero;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zero));             // (not hoistable: see dedup_insert)
     const uint4 z = make_uint4(zero, zero, zero, zero);
-    for (u32 i = tid; i < MCQ_CELL_WORDS / 4; i += G) { reinterpret_cast<uint4*>(occ)[i] = z; reinterpret_cast<uint4*>(multi)[i] = z; }
+    for (u32 i = tid; i < (1u << (LOG - 7)); i += G) { reinterpret_cast<uint4*>(occ)[i] = z; reinterpret_cast<uint4*>(multi)[i] = z; }
 }
+template <u32 LOG = MCQ_CELL_LOG>
 __device__ __forceinline__ void cells_insert(u32 key, u32 cs, u32* occ, u32* multi) {
-    const u32 bit = (key >> cs) & ((1u << MCQ_CELL_LOG) - 1), m = 1u << (bit & 31);
+    const u32 bit = (key >> cs) & ((1u << LOG) - 1), m = 1u << (bit & 31);
     if (atomicOr(&occ[bit >> 5], m) & m) atomicOr(&multi[bit >> 5], m);
 }
+template <u32 LOG = MCQ_CELL_LOG>
 __device__ __forceinline__ bool cells_heavy(u32 key, u32 cs, const u32* occ, const u32* multi) {
-    const u32 bit = (key >> cs) & ((1u << MCQ_CELL_LOG) - 1);
-    const u32 lo = (bit - 1) & ((1u << MCQ_CELL_LOG) - 1), hi = (bit + 1) & ((1u << MCQ_CELL_LOG) - 1);
+    const u32 bit = (key >> cs) & ((1u << LOG) - 1);
+    const u32 lo = (bit - 1) & ((1u << LOG) - 1), hi = (bit + 1) & ((1u << LOG) - 1);
     return ((multi[bit >> 5] >> (bit & 31)) | (occ[lo >> 5] >> (lo & 31)) | (occ[hi >> 5] >> (hi & 31))) & 1u;
 }
 
@@ -1442,6 +1447,78 @@ __device__ __forceinline__ u32 topk_two_class(const DbDev& db, const OptDev& opt
     wave_sync();
     if (P > 1) return fold_lists_write<u32, u32, JB>(db, opt, out, SK, Ltax, (u32)(Lw >> 32) << JB, numWindows, lf, q, lane, mx32, wt32);
     // one list, with window ranges: a single hit is its own range; else the range that ends at the word, inside SK
+    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lw != 0));
+    if (lane < n) {
+        const u32 key = ~(u32)Lw, hits = (u32)(Lw >> 32);
+        u32 t, tb;
+        lf.locate(key, t, tb);
+        u32 beg = key - tb;
+        if (hits >= 2) {
+            const u32 lowkey = range_low<u32>(key, tb, numWindows);
+            u32 lo = 0, hi = D;
+            while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (SK[mid] < lowkey) lo = mid + 1; else hi = mid; }
+            beg = SK[lo] - tb;
+        }
+        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = make_uint4(Ltax, hits, beg, key - tb);
+    }
+    if (lane == 0) out.ncand[q] = n;
+    return n;
+}
+
+// The same with the entries in LDS instead of registers (the workgroup kernel is compiled for 64 VGPRs; one of its waves
+// builds the lists while the others wait): up to NE_MAX - 64 run heads + 64 light words.  ent: 4 * NE_MAX + 192 words of LDS
+// (entry words as u64, taxa, ranks, then the lists' scratch).
+template <int JB, u32 NE_MAX, class LF>
+__device__ __forceinline__ u32 topk_two_class_lds(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* SK, u32 D, const u32* H, u32 nheads,
+                                                  u32 lkey, u32 n_light, bool light_omitted, u32 theta, u32 numWindows, const LF& lf, u64 q, u32 lane, u32* ent) {
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    const bool p2 = (P & (P - 1)) == 0;
+    const u32 JMASK = (1u << JB) - 1;
+    unsigned long long* EW = reinterpret_cast<unsigned long long*>(ent);
+    u32* ET = ent + 2 * NE_MAX; u32* ER = ent + 3 * NE_MAX;
+    u32* scr = ent + 4 * NE_MAX;
+    unsigned long long* mx = reinterpret_cast<unsigned long long*>(scr);
+    u32* wt = scr + 128;
+    const u32 NE = nheads + n_light;
+    for (u32 base = 0; base < NE; base += 64) {
+        const u32 e = base + lane;
+        u32 key = MCQ_EMPTY, hits = 0;
+        const u32 lk = __shfl(lkey, (int)((e - nheads) & 63), 64);     // (by every lane: a shuffle inside a branch cannot read the lanes outside it)
+        if (e < nheads) { const u32 v = H[e]; key = SK[JMASK - (v & JMASK)]; hits = v >> JB; }
+        else if (e < NE) { key = lk; hits = 1; }
+        const u32 tgt = lf.tgt(hits ? key : SK[0]);               // (idle lanes look up a real word)
+        u32 tax = MCQ_EMPTY;
+        if (hits && tgt < db.n_targets) tax = db.tgt2tax[tgt];
+        if (e < NE) {
+            EW[e] = (hits && tax != MCQ_EMPTY) ? (((unsigned long long)hits << 32) | (u32)~key) : 0ull;
+            ET[e] = tax; ER[e] = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+        }
+    }
+    wave_sync();
+    const u32 rl = lane / seg, li = lane - rl * seg;
+    const bool lslot = (li < M) && (rl < P);
+    u32 Ltax = MCQ_EMPTY; unsigned long long Lw = 0;
+    for (u32 i = 0; i < M; ++i) {
+        mx[lane] = 0;
+        wave_sync();
+        for (u32 e = lane; e < NE; e += 64) { const unsigned long long w = EW[e]; if (w != 0) atomicMax(&mx[ER[e]], w); }
+        wave_sync();
+        for (u32 e = lane; e < NE; e += 64) { const unsigned long long w = EW[e]; if (w != 0 && w == mx[ER[e]]) wt[ER[e]] = ET[e]; }
+        wave_sync();
+        const unsigned long long ml = mx[rl];
+        const u32 wtl = wt[rl];
+        if (lslot && li == i && ml != 0) { Ltax = wtl; Lw = ml; }
+        for (u32 e = lane; e < NE; e += 64) if (EW[e] != 0 && ET[e] == wt[ER[e]]) EW[e] = 0;
+        wave_sync();
+    }
+    if (light_omitted) {
+        const bool last = lslot && li == M - 1;
+        const bool ok = Lw != 0 && ((u32)(Lw >> 32) >= 2 || (u32)~(u32)Lw < theta);
+        if (__ballot(last && !ok)) return ~0u;
+    }
+    u32* mx32 = scr; u32* wt32 = scr + 64;
+    wave_sync();
+    if (P > 1) return fold_lists_write<u32, u32, JB>(db, opt, out, SK, Ltax, (u32)(Lw >> 32) << JB, numWindows, lf, q, lane, mx32, wt32);
     const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lw != 0));
     if (lane < n) {
         const u32 key = ~(u32)Lw, hits = (u32)(Lw >> 32);

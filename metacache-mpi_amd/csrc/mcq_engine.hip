@@ -923,12 +923,31 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     u32* feat = hits + 64;
     const u32 nwaves = gridDim.x * 4;
     const u32 n_mid = ctr->ovf_mid_count;
-    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_retry = 0;
+    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_retry = 0, st_narrow = 0;
     u32 fq_next = 0, fq_left = 0;                      // this wave's reservation in the front queue (wide reads with > 1024 locations)
     // size of the space the location words live in (for the light-word threshold of the two-class tail)
     float word_space;
     if constexpr (GW) word_space = (float)gwd.off[db.n_targets];
     else word_space = (db.wb < 32 && ((u64)db.n_targets << db.wb) < 0xFFFFFFFFull) ? (float)((u64)db.n_targets << db.wb) : 4294967040.0f;
+    // How many queries with narrow window ranges wait in the front queue (the two-class workgroup kernel's share)?  Counted
+    // here, one entry per lane, for what the first stage queued -- in that kernel the count cost 0.7 % of configs[1] -- and
+    // below for what this kernel passes on.  (Entries this kernel appends meanwhile may be seen twice: the count only decides
+    // whether that kernel is worth running, and both workgroup kernels read the same final value.)
+    if (opt.tc_limit) {
+        const u32 n_front = ctr->ovf_count;
+        u32 cnt = 0;
+        for (u32 i = (blockIdx.x * 4 + wave) * 64 + lane; i < n_front; i += nwaves * 64) {
+            const u32 qf = ovf_list[i];
+            if (qf == MCQ_EMPTY) continue;
+            const u64 a = b.paired ? 2ull * qf : qf;
+            u64 o0, e0, o1 = 0, e1 = 0;
+            seq_bounds(b.seq_off, b.ranges, a, o0, e0);
+            if (b.paired) seq_bounds(b.seq_off, b.ranges, a + 1, o1, e1);
+            cnt += (e0 - o0) + (e1 - o1) < opt.tc_limit ? 1u : 0u;
+        }
+        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        st_narrow += cnt;
+    }
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
         const u32 q32 = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
         if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
@@ -976,6 +995,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             }
             if (lane == 0) ovf_list[fq_next] = q32;
             ++fq_next; --fq_left;
+            st_narrow += g.qlen < opt.tc_limit ? 1 : 0;
             continue;
         }
         st_loc += T;
@@ -1021,6 +1041,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
                     }
                     if (lane == 0) ovf_list[fq_next] = q32;
                     ++fq_next; --fq_left;
+                    st_narrow += g.qlen < opt.tc_limit ? 1 : 0;
                     wave_sync();
                     continue;
                 }
@@ -1039,6 +1060,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
     if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
     if (lane == 0 && st_retry) atomicAdd(&ctr->n_two_class_retry, st_retry);
+    if (lane == 0 && st_narrow) atomicAdd(&ctr->n_narrow, st_narrow);
     if (lane == 0 && (st_feat | st_loc | st_hit)) {
         if (st_feat) atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);
@@ -1074,17 +1096,18 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
 // Tail of the workgroup path: fill B[0..n2p) through `load(t)`, sort, sweep, top lists.
 // HT/JB: packed (hits << JB | index) word of the sweep: u32 with JB = 13 when the list fits the workgroup's LDS
 // (<= 8192 entries, hits <= 8192), u64 with JB = 32 in global scratch
+// filled: B[0..T) holds the unsorted list already
 template <class KeyT, class HT, int JB, bool BIG, class LF, class Fill>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
                                            KeyT* B, HT* H, u32 T, u32 numWindows, const LF& lf, u64 q, u32 tid,
-                                           const DebugDev& dbg, u32* biglist, Fill fill) {
+                                           const DebugDev& dbg, u32* biglist, Fill fill, bool filled = false) {
     const u32 n2p = pow2ceil(T), NTB = blockDim.x;
 #ifdef MCQ_SORT_PAD_FULL                                       // tuning knob (A/B): the whole power-of-two network
     const u32 npad = n2p;
 #else
     const u32 npad = n2p < 256 ? n2p : ((T + 127u) & ~127u);  // padded to whole 128-key chunks (see bitonic_sort_block)
 #endif
-    fill(B);                                                   // B[0..T) = the unsorted match list
+    if (!filled) fill(B);                                      // B[0..T) = the unsorted match list
     for (u32 t = T + tid; t < npad; t += NTB) B[t] = key_pad<KeyT>();
     __syncthreads();
     bitonic_sort_block(B, n2p, npad, tid, NTB, [] { __syncthreads(); });
@@ -1098,11 +1121,114 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
     __syncthreads();
 }
 
+// ---- the two-class tail of the workgroup kernel (32-bit words, the list in LDS) ---------------------------------------
+// Long reads and the short reads of a RefSeq-scale table that outgrow the wave stages: a few thousand locations, most of
+// them chance hits alone on their target.  Same split as in the wave stage (mcq_device.hpp, "rows 8-11 in two classes"), by
+// the whole workgroup: the list B[0..T) is filled as before; the hit words' LDS holds the two cell maps (2^17 cells each);
+// every thread classifies its words; the heavy ones are packed into the hit words' segment, sorted there (a 2430-word list
+// of an 8 kb read keeps ~1050 of them), swept with the packed heads in B's segment; and ONE wave builds the lists from
+// the heads that matter and the light prefix (topk_two_class_lds: entries in B's segment).  Returns TC_DONE when the query is
+// answered; else the caller runs the exact tail (filling B again unless TC_HEAVY left it intact).
+#define MCQ_TC_MAX_WINDOWS 16u          // widest window range the workgroup kernel's two-class tail takes (see k_query_block)
+#define MCQ_TC_MIN_QUEUED 4096ull       // fewest narrow queries in the front queue that get the two-class workgroup kernel
+enum { TC_NOT_TRIED = 0, TC_DONE = 1, TC_HEAVY = 2, TC_FAILED = 3 };      // TC_HEAVY: given up early, B is filled and intact
+template <int LCAPB, class LF, class Fill>
+__device__ __forceinline__ int block_two_class(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr, u32* B, u32* HW, u32 T,
+                                               u32 numWindows, float word_space, const LF& lf, u64 q, u32 tid, u32* s_x /* 8 words */, Fill fill) {
+    constexpr u32 LOG = 31u - __builtin_clz((u32)LCAPB) + 4;               // both maps fill the LCAPB hit words: 2 x 2^(LOG - 5) words
+    constexpr u32 MAPW = 1u << (LOG - 5), NPRE = 64, JB = 13;
+    static_assert(2 * MAPW <= (u32)LCAPB && LCAPB <= 8192, "cell maps live in the hit words; 13 index bits");
+    const u32 NTB = blockDim.x, lane = tid & 63;
+    // (numWindows > 16 = long reads: their locations are clusters around the strains' loci, hundreds of words per cell -- the
+    // LDS atomics of the maps collide on a few words and the tail, measured on 8 kb reads, costs 5 % instead of saving)
+    if (T > (u32)LCAPB - 256u || numWindows > MCQ_TC_MAX_WINDOWS) return TC_NOT_TRIED;          // (P x M and the hook: decided by the host, which launches this kernel or not)
+    u32* occ = HW; u32* multi = HW + MAPW;
+    fill(B);
+    __syncthreads();                                         // every wave has read the list starts (they live where the maps go)
+    cells_clear<LOG>(occ, multi, tid, NTB);
+    if (tid < 8) s_x[tid] = 0;
+    __syncthreads();
+    const u32 cs = cell_shift(numWindows);
+    for (u32 t = tid; t < T; t += NTB) cells_insert<LOG>(B[t], cs, occ, multi);
+    __syncthreads();
+    u32 hm = 0;                                              // bit i: my i-th word is heavy (T <= 8192: at most 8 words per thread)
+    for (u32 t = tid, i = 0; t < T; t += NTB, ++i) hm |= cells_heavy<LOG>(B[t], cs, occ, multi) ? 1u << i : 0u;
+    {   // mostly heavy words (a long read on a small table: every location belongs to a strain's cluster): nothing to gain
+        const u32 mine = (u32)__builtin_popcount(hm);
+        u32 wsum = mine;
+        for (int d = 32; d > 0; d >>= 1) wsum += __shfl_xor(wsum, d, 64);
+        if (lane == 0 && wsum) atomicAdd(&s_x[3], wsum);
+    }
+    __syncthreads();                                         // the maps are dead: heavy words -> HW[0..nH), light prefix -> HW[LCAPB - 64 ..)
+    if (4 * s_x[3] > 3 * T) return TC_HEAVY;
+    const float th = word_space * MCQ_TWO_CLASS_EXPECT * __builtin_amdgcn_rcpf((float)T);
+    const u32 theta = th >= 4294967040.0f ? 0xFFFFFFFEu : (u32)th;
+    u32* pre = HW + (LCAPB - NPRE);
+    for (u32 t0 = 0, i = 0; t0 < T; t0 += NTB, ++i) {        // (uniform trip count: the ballots need every lane)
+        const u32 t = t0 + tid;
+        const bool valid = t < T, heavy = (hm >> i) & 1u;
+        const u32 k = valid ? B[t] : 0u;
+        const u64 bh = __ballot(valid && heavy);
+        u32 base = 0;
+        if (lane == 0 && bh) base = atomicAdd(&s_x[0], (u32)__builtin_popcountll(bh));
+        base = bcast(base, 0);
+        if (valid && heavy) HW[base + lane_rank(bh)] = k;
+        const bool lp = valid && !heavy && k < theta;
+        const u64 bl = __ballot(valid && !heavy), bp = __ballot(lp);
+        u32 pb = 0;
+        if (lane == 0) { if (bl) atomicAdd(&s_x[1], (u32)__builtin_popcountll(bl)); if (bp) pb = atomicAdd(&s_x[2], (u32)__builtin_popcountll(bp)); }
+        pb = bcast(pb, 0);
+        if (lp) { const u32 i2 = pb + lane_rank(bp); if (i2 < NPRE) pre[i2] = k; }
+    }
+    __syncthreads();
+    const u32 nH = s_x[0], nL = s_x[1], nP = s_x[2];
+    if (nP > NPRE) return TC_FAILED;                         // theta too generous for this read
+    // sort the heavy words in place (padded to whole 128-word chunks), sweep them with the packed heads in B's segment
+    const u32 n2p = pow2ceil(nH), npad = n2p < 256 ? n2p : ((nH + 127u) & ~127u);
+    for (u32 t = nH + tid; t < npad; t += NTB) HW[t] = MCQ_EMPTY;
+    const u32 safe = B[0];
+    __syncthreads();
+    bitonic_sort_block(HW, n2p, npad, tid, NTB, [] { __syncthreads(); });
+    u32* H = B;
+    if (nH) sweep_targets<u32, u32, JB>(HW, H, nH, numWindows, lf, tid, NTB, HW + (LCAPB - 128) /* 17 words behind the sorted words */, [] { __syncthreads(); });
+    __syncthreads();
+    // ONE wave: the run heads that matter (two or more hits, or a word below theta) to the front, then the lists
+    if (tid < 64) {
+        u32 nheads = 0;
+        bool dropped = false;
+        for (u32 base = 0; base < nH; base += 64) {
+            const u32 j = base + lane;
+            const u32 hv = (j < nH) ? H[j] : 0;
+            const u32 h = hv >> JB, jb = ((1u << JB) - 1) - (hv & ((1u << JB) - 1));
+            const bool one = hv != 0 && h == 1u && HW[jb] >= theta;
+            const u64 hb = __ballot(hv != 0 && !one);
+            if (hv != 0 && !one) H[nheads + lane_rank(hb)] = hv;
+            nheads += (u32)__builtin_popcountll(hb);
+            dropped = dropped || __ballot(one) != 0;
+        }
+        wave_sync();
+        if (nH == 0 && lane == 0) HW[0] = safe;              // (idle lanes look up SK[0])
+        wave_sync();
+        u32 n = ~0u;
+        const u32 lkey = lane < nP ? pre[lane] : MCQ_EMPTY;
+        if (nheads <= 1024) n = topk_two_class_lds<JB, 1088>(db, opt, out, HW, nH, H, nheads, lkey, nP, nL > nP || dropped, theta, numWindows, lf, q, lane, H + 1024);
+        if (lane == 0) { s_x[7] = n; if (n != ~0u) { atomicAdd(&ctr->n_cands, (unsigned long long)n); atomicAdd(&ctr->n_two_class, 1ull); } else atomicAdd(&ctr->n_two_class_retry, 1ull); }
+    }
+    __syncthreads();
+    const bool done = s_x[7] != ~0u;
+    __syncthreads();
+    return done ? TC_DONE : TC_FAILED;
+}
+
 // NT threads per workgroup; LCAPB entries of the match list fit its LDS (longer lists are sorted in global scratch).
 // 32-bit keys: 8192 x (4 + 4) B = 64 KB of LDS and 64 VGPRs, so two 1024-thread workgroups share a CU -- the phases
 // of a query are serialised by workgroup barriers, and the second workgroup fills the gaps (+45 % on 8 kb reads;
 // <4096, 512> with four per CU is slower: 15 % of those reads then sort in global scratch).
-template <class KeyT, int LCAPB, int NT, bool BIG = false, bool SH = false, bool GW = false>
+// TC: the instantiation with the two-class tail.  Merely carrying that code costs the kernel 10 % on long reads (register
+// allocation: 20 spilled VGPRs around the query loop), which never take it -- so it is a kernel of its own, launched behind the
+// plain one over the same queue: queries with narrow window ranges (numWindows <= 16: short reads and pairs whose lists
+// outgrew the wave stages) are left to it (OptDev::hooks bit 16 tells the plain kernel), everything else to the plain one.
+template <class KeyT, int LCAPB, int NT, bool BIG = false, bool SH = false, bool GW = false, bool TC = false>
 __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                       CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg, ShardDev sh, GwDev gwd) {
     static_assert(LCAPB <= 8192, "packed sweep word: 13 index bits");
@@ -1123,6 +1249,11 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
     const u32 n_ovf = ctr->ovf_count;
     u32* sk = s_hits + wave * 128;                             // per-wave sketch scratch (hit words unused yet)
+    u32 tc_skip = 0;                                           // queries for which the two-class tail is not attempted (uniform)
+    // a kernel of its own for the narrow queries only pays when there are enough of them (a batch of long reads has a few
+    // hundred short ones: the plain kernel takes them along, the other one returns at once)
+    const bool tc_worth = ctr->n_narrow >= MCQ_TC_MIN_QUEUED;
+    if (TC && !tc_worth) return;
 
     for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
         const u32 q32 = ovf_list[ovf_visit(it, n_ovf)];
@@ -1135,6 +1266,9 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         const u64 n1 = e0 - o0, n2 = e1 - o1;
         const u32 nw1 = num_windows(n1, W, S), nw2 = b.paired ? num_windows(n2, W, S) : 0;
         const u64 NW = (u64)nw1 + nw2;
+        // which of the two workgroup kernels takes this query (uniform): narrow window ranges = short queries (opt.tc_limit: the
+        // first length with numWindows > MCQ_TC_MAX_WINDOWS, 0 = no two-class kernel behind this one)
+        if (((n1 + n2 < opt.tc_limit) && tc_worth) != TC) continue;
         if (NW * db.s > sc.fmax) {                        // beyond the workspace: flag, no result
             if (tid == 0) { out.ncand[q] = 0; atomicAdd(&ctr->err_count, 1u); if (dbg.mode == 1) dbg.match_cnt[q] = 0; }
             continue;
@@ -1230,7 +1364,29 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             }
         };
         // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
-        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
+        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) {
+            int tc = TC_NOT_TRIED;
+            if constexpr (TC) {
+                // (reads of one batch are alike: after a query that was mostly heavy words the workgroup skips the attempt for
+                // the next 15 -- results are the same either way)
+                if (dbg.mode == 0 && tc_skip == 0) {
+                    // the two-class tail keeps its cell maps where the query's list starts live (LDS case): a copy in global
+                    // scratch lets the exact tail fill the list again, should the lists not be provable
+                    if (f_lds) {
+                        for (u32 i = tid; i < F; i += NT) { g_fpos[i] = fpos[i]; g_foff[i] = foff[i]; }
+                        __syncthreads();
+                    }
+                    // size of the space the location words live in (light-word threshold)
+                    float word_space;
+                    if constexpr (GW) word_space = (float)gwd.off[db.n_targets];
+                    else word_space = (db.wb < 32 && ((u64)db.n_targets << db.wb) < 0xFFFFFFFFull) ? (float)((u64)db.n_targets << db.wb) : 4294967040.0f;
+                    tc = block_two_class<LCAPB>(db, opt, out, ctr, reinterpret_cast<u32*>(s_buf), s_hits, T, numWindows, word_space, lf, q, tid, s_w, fill);
+                    if (tc != TC_DONE && f_lds) { fpos = g_fpos; foff = g_foff; __threadfence_block(); __syncthreads(); }
+                    if (tc == TC_HEAVY) tc_skip = 15;
+                } else if (tc_skip) --tc_skip;
+            }
+            if (tc != TC_DONE) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill, tc == TC_HEAVY);
+        }
         else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
     }
 }
@@ -2187,7 +2343,7 @@ struct LaunchTimer {
 
 // sh != nullptr: the feature-sharded home side (SH instantiations; dbd = the handle's DbDev with `locs` pointing at the
 // received location buffer); the counters are then zeroed by the caller (the sketch kernel has already counted)
-static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const OptDev& od, const OutDev& o,
+static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const OptDev& od_in, const OutDev& o,
                         hipStream_t st, int force_block, const DebugDev& dbg, const ShardDev* shp = nullptr, const DbDev* dbd = nullptr) {
     if (!shp) HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
     if (b.nq == 0) return MCQ_OK;
@@ -2201,6 +2357,14 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     LaunchTimer tm(ws, st);
     int rc = tm.begin(); if (rc) return rc;
     const bool tap = dbg.mode != 0;     // mcq_debug_matches: the instantiations that also write the sorted match lists
+    // The workgroup kernel exists twice: plain, and with the two-class tail for queries with narrow window ranges (short reads
+    // whose lists outgrew the wave stages; see k_query_block).  The second one is launched when its lists can be proven (32-bit
+    // words, P x M <= 16): range_width = 2 + max(len, insert_size_max) / stride <= MCQ_TC_MAX_WINDOWS  <=>  max(len,
+    // insert_size_max) < (MCQ_TC_MAX_WINDOWS - 1) x stride = tc_limit; the queueing kernels count the queries below it.
+    const u64 tc_len = (u64)(MCQ_TC_MAX_WINDOWS - 1) * D.tgt_winstride;
+    const bool with_tc = db->d.compact && !od_in.big && !tap && od_in.P * od_in.max_cand <= MCQ_TWO_CLASS_MAX_PM && !(od_in.hooks & 8u) && od_in.insert_size_max < tc_len;
+    OptDev od = od_in;
+    od.tc_limit = with_tc ? tc_len : 0;
     const bool gw = db->g.on != 0;      // 32-bit locations in the global-window form: the GW instantiations
     const bool b64 = db->d.bsh != 0;    // table layout: the wave kernels are instantiated per layout (taps and the sharded home side: run-time / unused)
 #define MCQ_LAUNCH_WAVE(KT, TAPV, SHV, GWV, BSHV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV, SHV, GWV, BSHV>), dim3(grid), dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg, sh, db->g)
@@ -2222,7 +2386,7 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
 #undef MCQ_LAUNCH_WAVE16
     }
     rc = tm.mark(); if (rc) return rc;
-#define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV, SHV, GWV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV, SHV, GWV>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, D, b, od, o, ws->ctr, \
+#define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV, SHV, GWV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV, SHV, GWV, false>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, D, b, od, o, ws->ctr, \
                                                              (const u32*)ws->ovf_list, ws->sc, dbg, sh, db->g)
 #define MCQ_LAUNCH_BLOCK2(KT, LC, NTH, SHV, GWV) do { if (od.big) MCQ_LAUNCH_BLOCK(KT, LC, NTH, true, SHV, GWV); else MCQ_LAUNCH_BLOCK(KT, LC, NTH, false, SHV, GWV); } while (0)
 #define MCQ_LAUNCH_BLOCK32(SHV) do { if (gw) MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, SHV, true); else MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, SHV, false); } while (0)
@@ -2231,6 +2395,13 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
 #undef MCQ_LAUNCH_BLOCK32
 #undef MCQ_LAUNCH_BLOCK2
 #undef MCQ_LAUNCH_BLOCK
+    if (with_tc) {
+#define MCQ_LAUNCH_TC(SHV, GWV) hipLaunchKernelGGL((k_query_block<u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, false, SHV, GWV, true>), dim3(ws->n_block_wgs), dim3(MCQ_BLOCK_NT), 0, st, \
+                                                   D, b, od, o, ws->ctr, (const u32*)ws->ovf_list, ws->sc, dbg, sh, db->g)
+        if (shp) { if (gw) MCQ_LAUNCH_TC(true, true); else MCQ_LAUNCH_TC(true, false); }
+        else     { if (gw) MCQ_LAUNCH_TC(false, true); else MCQ_LAUNCH_TC(false, false); }
+#undef MCQ_LAUNCH_TC
+    }
     rc = tm.end(); if (rc) return rc;
     HIPCHK(hipGetLastError());
     ws->last_nq = b.nq;
@@ -2376,6 +2547,7 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
         stats->n_locations = ws->ctr_host->n_locations; stats->n_cands = ws->ctr_host->n_cands;
         stats->n_overflow = ws->ctr_host->n_ovf;
         stats->n_two_class = ws->ctr_host->n_two_class; stats->n_two_class_retry = ws->ctr_host->n_two_class_retry;
+        stats->n_narrow_queued = ws->ctr_host->n_narrow;
     }
     if (ws->ctr_host->err_count)
         return fail(MCQ_E_CAPACITY, std::to_string(ws->ctr_host->err_count) + " queries exceeded the workspace's per-query capacity");

@@ -281,6 +281,12 @@ struct mcq_shard {
     mcq_exchange_fn xfn; void* xuser;
     u64 last_nq;
     u64 seen_features, seen_locations;    // exact mode: the largest per-peer counts of the batch (sizes the padded mode's blocks)
+    // accounting of the exchanges (mcq_shard_exchange_bytes): bytes handed to the transport for OTHER ranks, and of the rank's own blocks
+    u64 xb_batches, xb_x1, xb_x2r, xb_x2l, xb_self;
+    // stage timing (mcq_shard_timing): per buffer set the events around S1 (on the stream it ran on) and X1 / S2 / X2 (on xs)
+    hipEvent_t tv[MCQ_SHARD_SETS][6]; bool tv_pending[MCQ_SHARD_SETS]; bool tv_s1[MCQ_SHARD_SETS]; bool tv_ready;
+    u64 st_n_s1;
+    double st_ms[4]; u64 st_n;
 };
 static u64 rblk_words(const mcq_shard* c) { return (u64)MCQ_SHARD_HDR + c->capT + c->capF; }
 static u64 fblk_words(const mcq_shard* c) { return (u64)MCQ_SHARD_HDR + c->capF; }
@@ -288,8 +294,9 @@ static u64 fblk_words(const mcq_shard* c) { return (u64)MCQ_SHARD_HDR + c->capF;
 // moves send_bytes[p] bytes from send_base + p*send_stride to rank p and receives recv_bytes[p] bytes from it at
 // recv_base + p*recv_stride
 static int shard_exchange(mcq_shard* c, const void* send_base, u64 send_stride, const u64* send_bytes,
-                          void* recv_base, u64 recv_stride, const u64* recv_bytes, hipStream_t st) {
+                          void* recv_base, u64 recv_stride, const u64* recv_bytes, hipStream_t st, u64* account = nullptr) {
     const u32 n = c->n;
+    if (account) for (u32 p = 0; p < n; ++p) { if (p == c->rank) c->xb_self += send_bytes[p]; else *account += send_bytes[p]; }
     if (c->xfn) {                         // caller's transport (host-staged in the tests): synchronous
         HIPCHK(hipStreamSynchronize(st));
         std::vector<u64> so(n), ro(n);
@@ -338,6 +345,7 @@ extern "C" int mcq_shard_destroy(mcq_shard* c) {
     for (auto e : c->ev_done) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev_x) if (e) (void)hipEventDestroy(e);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    for (auto& set : c->tv) for (auto e : set) if (e) (void)hipEventDestroy(e);
     (void)mcq_ws_destroy(c->ws);
     delete c;
     return MCQ_OK;
@@ -394,6 +402,8 @@ extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, m
     SCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     for (auto& e : c->ev_prep) SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : c->ev_done) SCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& set : c->tv) for (auto& e : set) SCHK(hipEventCreate(&e));
+    c->tv_ready = true;
 #undef SCHK
     *out = c;
     return MCQ_OK;
@@ -432,9 +442,26 @@ extern "C" int mcq_shard_get_caps(const mcq_shard* c, uint64_t* features_per_pee
     return MCQ_OK;
 }
 
+// stage times of the batch that last used buffer set k (its events are about to be recorded again)
+static int shard_harvest(mcq_shard* c, int k) {
+    if (!c->tv_pending[k]) return MCQ_OK;
+    HIPCHK(hipEventSynchronize(c->tv[k][5]));
+    const int pair[4][2] = {{0, 1}, {2, 3}, {3, 4}, {4, 5}};        // S1, X1, S2, X2
+    for (int i = 0; i < 4; ++i) {
+        if (i == 0 && !c->tv_s1[k]) continue;            // (this batch's S1 ran before timing was switched on)
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->tv[k][pair[i][0]], c->tv[k][pair[i][1]]));
+        c->st_ms[i] += ms;
+    }
+    c->st_n += 1; c->st_n_s1 += c->tv_s1[k] ? 1 : 0;
+    c->tv_pending[k] = false; c->tv_s1[k] = false;
+    return MCQ_OK;
+}
+
 // S1 of a batch into buffer slot k, on stream st
 static int shard_prepare(mcq_shard* c, int k, const mcq_batch* in, hipStream_t st) {
     ShardBuf& b = c->sb[k];
+    if (c->ws->timing) { int rch = shard_harvest(c, k); if (rch) return rch; HIPCHK(hipEventRecord(c->tv[k][0], st)); }
     int rc = mcq_count_windows(c->db, in, b.win_off, st); if (rc) return rc;
     hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendF, fblk_words(c), c->n);
     HIPCHK(hipMemsetAsync(b.feat_cnt, 0, 8, st));
@@ -449,6 +476,7 @@ static int shard_prepare(mcq_shard* c, int k, const mcq_batch* in, hipStream_t s
                            b.slot_pos, c->max_slots, b.feat_cnt, c->err + 1 + k);
     }
     HIPCHK(hipGetLastError());
+    if (c->ws->timing) { HIPCHK(hipEventRecord(c->tv[k][1], st)); c->tv_s1[k] = true; }
     return MCQ_OK;
 }
 
@@ -481,6 +509,8 @@ static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
     std::vector<u64> sbytes(n), rbytes(n), cnt_mine(n), cnt_theirs(n);
     int rc;
     // ---- X1: feature blocks to their owners
+    if (c->ws->timing) HIPCHK(hipEventRecord(c->tv[k][2], st));
+    c->xb_batches += 1;
     u32 capFx = c->capFx; u64 capLx = c->capLx;
     if (exact) {
         HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, b.sendF, fblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
@@ -494,7 +524,9 @@ static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
     } else {
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = ((u64)MCQ_SHARD_HDR + capFx) * 4;
     }
-    if (!alias) { rc = shard_exchange(c, b.sendF, fblk_words(c) * 4, sbytes.data(), recvF, fblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
+    if (alias) c->xb_self += sbytes[0];
+    else { rc = shard_exchange(c, b.sendF, fblk_words(c) * 4, sbytes.data(), recvF, fblk_words(c) * 4, rbytes.data(), st, &c->xb_x1); if (rc) return rc; }
+    if (c->ws->timing) HIPCHK(hipEventRecord(c->tv[k][3], st));
 
     // ---- S2: owner side
     hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendR, rblk_words(c), n);
@@ -506,12 +538,14 @@ static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
                                                  b.sendR, (u64*)b.sendL, c->capL, err);
     }
     HIPCHK(hipGetLastError());
+    if (c->ws->timing) HIPCHK(hipEventRecord(c->tv[k][4], st));
 
     // ---- X2: list ends + tile starts, and the location blocks, back to the requesters
     if (exact) {
         // ends of the features each peer sent (counts known from X1), locations served to each peer (cursor word of its R block)
         for (u32 p = 0; p < n; ++p) { sbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_theirs[p]) * 4; rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_mine[p]) * 4; }
-        if (!alias) { rc = shard_exchange(c, b.sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
+        if (alias) c->xb_self += sbytes[0];
+        else { rc = shard_exchange(c, b.sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st, &c->xb_x2r); if (rc) return rc; }
         HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, b.sendR, rblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         u64 mx = 0;
@@ -519,21 +553,27 @@ static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
         for (u32 p = 0; p < n; ++p) { served[p] = std::min<u64>(c->cnt_host[p], c->capL); mx = std::max(mx, served[p]); }
         rc = shard_exchange_counts(c, served.data(), coming.data(), st); if (rc) return rc;
         for (u32 p = 0; p < n; ++p) { sbytes[p] = served[p] * c->locb; rbytes[p] = coming[p] * c->locb; mx = std::max(mx, coming[p]); }
-        if (!alias) { rc = shard_exchange(c, b.sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
+        if (alias) c->xb_self += sbytes[0];
+        else { rc = shard_exchange(c, b.sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st, &c->xb_x2l); if (rc) return rc; }
         c->seen_locations = mx;
-        // learn the padded mode's block sizes: the largest count any rank saw this batch, plus a quarter
+        // learn the padded mode's block sizes: the largest count any rank saw this batch, plus a sixteenth (counts of millions of
+        // uniformly hashed features vary by well under a percent from batch to batch; a block that still overflows is reported,
+        // and the exact mode answers it)
         std::vector<u64> mine2(n, (c->seen_features << 32) | std::min<u64>(c->seen_locations, 0xFFFFFFFFull)), all2(n);
         rc = shard_exchange_counts(c, mine2.data(), all2.data(), st); if (rc) return rc;
         u64 gf = 0, gl = 0;
         for (u32 p = 0; p < n; ++p) { gf = std::max<u64>(gf, all2[p] >> 32); gl = std::max<u64>(gl, all2[p] & 0xFFFFFFFFull); }
-        c->capFx = std::max<u32>(c->capFx, (u32)std::min<u64>(c->capF, (gf + gf / 4 + 4096 + MCQ_SHARD_TILE - 1) / MCQ_SHARD_TILE * MCQ_SHARD_TILE));
-        c->capLx = std::max<u64>(c->capLx, std::min<u64>(c->capL, gl + gl / 4 + 65536));
+        c->capFx = std::max<u32>(c->capFx, (u32)std::min<u64>(c->capF, (gf + gf / 16 + 4096 + MCQ_SHARD_TILE - 1) / MCQ_SHARD_TILE * MCQ_SHARD_TILE));
+        c->capLx = std::max<u64>(c->capLx, std::min<u64>(c->capL, gl + gl / 16 + 65536));
     } else {
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + capFx) * 4;
-        if (!alias) { rc = shard_exchange(c, b.sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st); if (rc) return rc; }
+        if (alias) c->xb_self += sbytes[0];
+        else { rc = shard_exchange(c, b.sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st, &c->xb_x2r); if (rc) return rc; }
         for (u32 p = 0; p < n; ++p) sbytes[p] = rbytes[p] = capLx * c->locb;
-        if (!alias) { rc = shard_exchange(c, b.sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st); if (rc) return rc; }
+        if (alias) c->xb_self += sbytes[0];
+        else { rc = shard_exchange(c, b.sendL, c->capL * c->locb, sbytes.data(), recvL, c->capL * c->locb, rbytes.data(), st, &c->xb_x2l); if (rc) return rc; }
     }
+    if (c->ws->timing) { HIPCHK(hipEventRecord(c->tv[k][5], st)); c->tv_pending[k] = true; }
     // what this rank lost, flagged on this rank (exact mode: the buffers' capacities; padded mode: the sizes that travelled)
     hipLaunchKernelGGL(k_shard_check, dim3(1), dim3(64), 0, st, (const u32*)recvR, rblk_words(c), (const u32*)b.sendF, fblk_words(c), n,
                        exact ? c->capL : capLx, exact ? c->capF : capFx, err);
@@ -623,5 +663,31 @@ extern "C" int mcq_shard_sync(mcq_shard* c, void* stream, mcq_stats* stats) {
     return rc;
 }
 
-extern "C" int mcq_shard_timing(mcq_shard* c, int enable) { return c ? mcq_ws_timing(c->ws, enable) : fail(MCQ_E_ARG, "null argument"); }
+extern "C" int mcq_shard_timing(mcq_shard* c, int enable) {
+    if (!c) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    for (int k = 0; k < MCQ_SHARD_SETS; ++k) { if (enable) { c->tv_pending[k] = false; c->tv_s1[k] = false; } else { int rc = shard_harvest(c, k); if (rc) return rc; } }
+    if (enable) { for (auto& m : c->st_ms) m = 0; c->st_n = 0; c->st_n_s1 = 0; }
+    return mcq_ws_timing(c->ws, enable);
+}
+// milliseconds, summed over the batches since timing was enabled, of S1 (window count + sketch + route, on whichever stream it
+// ran), X1 (feature blocks out), S2 (owner-side lookup), X2 (list ends + locations back); n = batches harvested
+extern "C" int mcq_shard_stage_times(mcq_shard* c, double* ms, uint64_t* n_batches) {
+    if (!c) return fail(MCQ_E_ARG, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    for (int k = 0; k < MCQ_SHARD_SETS; ++k) { int rc = shard_harvest(c, k); if (rc) return rc; }
+    if (ms) for (int i = 0; i < 4; ++i) ms[i] = c->st_ms[i];
+    if (ms && c->st_n_s1 && c->st_n_s1 != c->st_n) ms[0] *= (double)c->st_n / (double)c->st_n_s1;      // (S1 of the first batches ran untimed)
+    if (n_batches) *n_batches = c->st_n;
+    return MCQ_OK;
+}
+// out[0] batches, [1] X1 bytes handed to the transport for other ranks, [2] X2 list ends + tile starts, [3] X2 locations,
+// [4] bytes of this rank's own blocks (never travel at n_ranks = 1; over RCCL they are a local copy), [5] ranks of the RCCL
+// communicator (0 = no RCCL transport), [6] / [7] the padded mode's block sizes in features / locations per peer
+extern "C" int mcq_shard_exchange_bytes(const mcq_shard* c, uint64_t* out) {
+    if (!c || !out) return fail(MCQ_E_ARG, "null argument");
+    out[0] = c->xb_batches; out[1] = c->xb_x1; out[2] = c->xb_x2r; out[3] = c->xb_x2l; out[4] = c->xb_self;
+    out[5] = c->have_comm ? c->n : 0; out[6] = c->capFx; out[7] = c->capLx;
+    return MCQ_OK;
+}
 extern "C" int mcq_shard_kernel_times(mcq_shard* c, double* ms, uint64_t* n_batches) { return c ? mcq_ws_kernel_times(c->ws, ms, n_batches) : fail(MCQ_E_ARG, "null argument"); }

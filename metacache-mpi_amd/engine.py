@@ -74,7 +74,7 @@ class Result(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("n_features", C.c_uint64), ("n_hit_features", C.c_uint64),
-                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64), ("n_two_class", C.c_uint64), ("n_two_class_retry", C.c_uint64)]
+                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64), ("n_two_class", C.c_uint64), ("n_two_class_retry", C.c_uint64), ("n_narrow_queued", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
@@ -156,6 +156,8 @@ def lib():
         L.mcq_shard_get_caps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.mcq_shard_timing.argtypes = [C.c_void_p, C.c_int]
         L.mcq_shard_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mcq_shard_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        L.mcq_shard_exchange_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -428,6 +430,17 @@ class Shard:
         ms, n = (C.c_double * 3)(), C.c_uint64(0)
         _chk(lib().mcq_shard_kernel_times(self.h, ms, C.byref(n)))
         return [float(x) for x in ms], int(n.value)
+
+    def stage_times(self):
+        """({'S1': ms, 'X1': ms, 'S2': ms, 'X2': ms} summed over the batches, n batches)"""
+        ms, n = (C.c_double * 4)(), C.c_uint64(0)
+        _chk(lib().mcq_shard_stage_times(self.h, ms, C.byref(n)))
+        return dict(zip(("S1", "X1", "S2", "X2"), [float(x) for x in ms])), int(n.value)
+
+    def exchange_bytes(self):
+        out = (C.c_uint64 * 8)()
+        _chk(lib().mcq_shard_exchange_bytes(self.h, out))
+        return dict(zip(("batches", "x1", "x2_ends", "x2_locations", "own_blocks", "rccl_ranks", "block_features", "block_locations"), [int(x) for x in out]))
 
     def close(self):
         if getattr(self, "h", None):

@@ -17,7 +17,7 @@ try:
     d=json.loads(open('gpurun_out/ab_%s_%s.json'%(label,r)).read().strip().splitlines()[-1])
     rf=d['roofline']; c=d['config']; lay=c.get('db_layout',{})
     print('%-22s round %s  ms/step %.4f  kernels %s  T/read %.1f ovf %.3f  %s/%s  db %.1f GB' % (label, r, d['ms_per_step'],
-          ' '.join('%.3f'%v for v in rf['kernel_ms'].values()) + ' two-class %s retry %s' % (rf['per_launch'].get('n_two_class'), rf['per_launch'].get('n_two_class_retry')), rf['per_launch']['n_locations']/ (c['reads_total']/d['steps']/d['n_gpus']),
+          ' '.join('%.3f'%v for v in rf['kernel_ms'].values()) + ' two-class %s retry %s narrow %s' % (rf['per_launch'].get('n_two_class'), rf['per_launch'].get('n_two_class_retry'), rf['per_launch'].get('n_narrow_queued')), rf['per_launch']['n_locations']/ (c['reads_total']/d['steps']/d['n_gpus']),
           rf['per_launch']['n_overflow']/(c['reads_total']/d['steps']/d['n_gpus']), lay.get('loc_format'), lay.get('bucket_bytes'), c['db_hbm_bytes']/1e9))
 except Exception as e:
     print(label, 'round', r, 'rc', rc, 'unreadable:', e)
