@@ -377,6 +377,13 @@ def main():
         if kind == "fused" and not a.small and n_species == 50:
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.workload)))
+                # counters belong to the kernels they were collected from: another state of csrc/ -> no figure, said so
+                fresh = tj.get("csrc_digest") == pkg.source_digest()
+                rf["traffic_fresh"] = fresh
+                if not fresh:
+                    rf["traffic_source"] = "STALE, not quoted: profiles/pmc_traffic_%s.json was collected from csrc digest %s, this run is %s (scripts/profile.sh + scripts/pmc_traffic.py renew it)" % (
+                        a.workload, tj.get("csrc_digest"), pkg.source_digest())
+                    raise LookupError("stale")
                 rf["traffic"] = tj["hbm_bytes_per_launch"] * B / tj["reads_per_launch"]
                 rf["traffic_source"] = "profiles/pmc_traffic_%s.json: %s" % (a.workload, tj.get("source", ""))
                 if tj.get("valu_insts_per_launch"):

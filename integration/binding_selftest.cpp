@@ -24,6 +24,16 @@
 
 using namespace mc;
 
+/* The seam itself, type-checked against the reference's own container: query_batched_parallel2 keeps a block's results in
+ * `tsl::hopscotch_map<uint_least64_t, classification_candidates> allhits` (src/querying.h:733) and fills it from the tree
+ * merge (:1112-1117); gpu_engine::query_block fills the same map instead.  An explicit instantiation: every dependent line
+ * of the template is compiled against the reference's headers (the GPU call behind it is linked, not run, in the build
+ * container; `binding_selftest gpu ...` runs it where there is a GPU). */
+#include <tsl/hopscotch_map.h>
+using reference_result_map = tsl::hopscotch_map<std::uint_least64_t, mc::classification_candidates>;
+template void mcq_binding::gpu_engine::query_block<reference_result_map>(
+    const std::vector<mc::sequence_pair_reader::sequence_pair>&, bool, std::uint32_t, reference_result_map&);
+
 static database read_db(const std::string& file, database::scope what)
 {
     database db;
@@ -162,6 +172,46 @@ static int cmd_map(const std::string& prefix, const std::string& lowest, const s
     return 0;
 }
 
+/* binding_selftest gpu <db prefix> <n ranks> <lowest rank> <max cand> <reads.txt>   (needs a GPU)
+ *      reads.txt: "<header>\t<mate 1>\t<mate 2>" per pair; one block through gpu_engine::query_block into the reference's
+ *      map type, then the reference's own map_candidates_to_targets: the mapping lines go to stdout. */
+static int cmd_gpu(const std::string& prefix, unsigned n_ranks, const std::string& lowest, const std::string& maxcand, const std::string& reads_file)
+{
+    database db = read_db(prefix + ".db_0", database::scope::metadata_only);
+    /* the options of the fixture runs, parsed by the reference itself (as in cmd_map) */
+    args_parser args{std::vector<std::string>{"query", prefix, "-pairfiles", "-lowest", lowest, "-maxcand", maxcand,
+                                              "-hitmin", "4", "-hitdiff", "80", "-tophits", "-taxids-only", "-omit-ranks"}};
+    query_options opt = get_query_options(args, {});
+    mcq_binding::gpu_engine eng(db, prefix, n_ranks, opt.classify, 0, 1 << 20, 1ull << 30);
+    std::vector<sequence_pair_reader::sequence_pair> block;
+    std::vector<std::string> headers;
+    std::ifstream is(reads_file);
+    std::string line;
+    std::uint_least64_t idx = 0;
+    while (std::getline(is, line)) {
+        const auto t1 = line.find('\t'), t2 = line.find('\t', t1 + 1);
+        if (t1 == std::string::npos || t2 == std::string::npos) continue;
+        sequence_pair_reader::sequence_pair p;
+        p.first.index = p.second.index = idx++;
+        p.first.header = line.substr(0, t1); p.first.data = line.substr(t1 + 1, t2 - t1 - 1);
+        p.second.header = p.first.header; p.second.data = line.substr(t2 + 1);
+        headers.push_back(p.first.header);
+        block.push_back(std::move(p));
+    }
+    reference_result_map allhits;
+    eng.query_block(block, true, n_ranks, allhits);
+    std::vector<classification_candidates> lists;
+    for (std::uint_least64_t q = 0; q < idx; ++q) {
+        auto it = allhits.find(q);
+        lists.push_back(it == allhits.end() ? classification_candidates{} : it->second);
+    }
+    std::ostringstream devnull;
+    classification_results results{std::cout, devnull, devnull, devnull};
+    map_candidates_to_targets(headers, lists, db, opt, results);
+    results.flush_all_streams();
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     try {
@@ -169,6 +219,7 @@ int main(int argc, char** argv)
         if (cmd == "table" && argc == 4) return cmd_table(argv[2], static_cast<unsigned>(std::stoul(argv[3])));
         if (cmd == "keys" && argc == 4) return cmd_keys(argv[2], argv[3]);
         if (cmd == "map" && argc == 6) return cmd_map(argv[2], argv[3], argv[4], argv[5]);
+        if (cmd == "gpu" && argc == 7) return cmd_gpu(argv[2], static_cast<unsigned>(std::stoul(argv[3])), argv[4], argv[5], argv[6]);
         std::cerr << "usage: binding_selftest table|keys|map ...\n";
         return 2;
     } catch (std::exception& e) {

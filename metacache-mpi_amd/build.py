@@ -39,6 +39,18 @@ def mpi_lib_dir():
     return os.path.join(_HERE, "_mpilib")
 
 
+def source_digest():
+    """sha256 (first 16 hex digits) over the kernel sources: profiles taken from one state of the kernels (PMC traffic,
+    profiles/pmc_traffic_*.json) carry it, and bench.py refuses to quote them for another"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(os.path.join(_HERE, "csrc"))):
+        if f.endswith((".hip", ".hpp")):
+            with open(os.path.join(_HERE, "csrc", f), "rb") as fh:
+                h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_host(force=False, verbose=False):
     """libmcq_host.so (shard reader, taxonomy keys, classify; g++, no GPU) and the
     mcq_query_cli binary (links both libraries)."""

@@ -24,7 +24,7 @@ def main():
     eng = importlib.import_module("metacache-mpi_amd.engine")
     dbbuild = importlib.import_module("dbbuild_torch")
     synth = importlib.import_module("metacache-mpi_amd.synth")
-    sharded = importlib.import_module("metacache-mpi_amd.sharded")
+    sharded = importlib.import_module("sharded_staged")
     P, M = 4, 4
     gb, goff, species = synth.make_genomes(5, 8, 150_000, 250_000, 0.02, seed=21, device=dev)
     keys, off, locs, _ = dbbuild.build_table(gb, goff, emulate_ranks=P)

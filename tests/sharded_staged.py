@@ -1,4 +1,9 @@
-"""Feature-sharded multi-GPU query path over torch.distributed.
+"""TEST CODE (moved out of the product package in round 3): the round-1 form of the feature-sharded query path, a
+torch.distributed loop over the engine's STAGED entry points.  The product path at N > 1 is mcq_shard_* behind the C ABI
+(csrc/mcq_shard.hpp); this loop is kept as an independent second implementation of the routing for the tests
+(tests/test_sharded_gloo.py on CPU with an oracle backend, tests/test_gpu_sharded.py with the staged kernels).
+
+Feature-sharded multi-GPU query path over torch.distributed.
 
 One process per GPU.  The feature -> locations table is partitioned by hash range of
 h2(feature) (engine.owner); reads are split across ranks.  Per batch, every rank
@@ -23,7 +28,9 @@ the CPU gloo test of the routing logic injects its own (tests/test_sharded_gloo.
 import torch
 import torch.distributed as dist
 
-from . import engine
+import importlib
+
+engine = importlib.import_module("metacache-mpi_amd.engine")
 
 EMPTY = -1          # 0xFFFFFFFF as int32
 

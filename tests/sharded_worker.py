@@ -1,4 +1,4 @@
-"""Worker of tests/test_sharded_gloo.py: runs metacache-mpi_amd/sharded.py's routing on CPU
+"""Worker of tests/test_sharded_gloo.py: runs tests/sharded_staged.py's routing on CPU
 tensors over gloo, with the stage functions supplied by the oracle (test infrastructure).
 Launched by torch.distributed.run; writes its ranks' results to <out>.<rank>.npz."""
 import importlib
@@ -91,7 +91,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     eng = importlib.import_module("metacache-mpi_amd.engine")
-    sharded = importlib.import_module("metacache-mpi_amd.sharded")
+    sharded = importlib.import_module("sharded_staged")
     fx = Fixture(tag, P)
     keys, off, locs = dbfile.union_shards(fx.shards)
     be = OracleBackend(keys, off, locs, fx.tgt2tax(), fx.params, world, rank, eng)

@@ -107,3 +107,20 @@ def test_config3_full_batch_of_pairs(c2):
     oc, on = odb.query(rb, ro, True, max_cand=4, emulate_ranks=4, threads=16)
     cands, ncand = ws.query_host(rb, ro, True, max_cand=4, emulate_ranks=4)
     _compare(cands, ncand, oc, on, "configs[3] shape, full batch of pairs")
+
+
+def test_config4_long_reads(c2):
+    """configs[4] shape on one GPU: 16 384 ONT-like reads, lengths log-normal with mean 8 kb, 8 % substitutions, on the 2 Gbp
+    table (~2 400 locations per read: every query in the workgroup kernel) -- every candidate list equals the oracle's"""
+    eng, synth, gb, goff, db, odb = c2
+    n = 1 << 14
+    reads, roff, _ = synth.sample_long_reads(gb, goff, n, 8000, 0.08, seed=1002)
+    rb = reads.cpu().numpy().tobytes(); ro = roff.cpu().numpy().astype(np.uint64)
+    assert 7000 < len(rb) / n < 9000
+    ws = eng.Workspace(db, n, len(rb))
+    for P, M in ((2, 2), (8, 4)):
+        oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, threads=16)
+        cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P)
+        _compare(cands, ncand, oc, on, "configs[4] shape P=%d M=%d" % (P, M))
+    st = ws.sync()
+    assert st["n_overflow"] == n and st["n_locations"] > 1500 * n

@@ -1,0 +1,67 @@
+"""BASELINE.json configs[2] at its stated scale, on ONE GPU: the RefSeq-scale table (a file of its own: the other modules'
+fixtures -- tens of GB of tables -- are gone when it runs)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(cands, ncand, oc, on, what):
+    bad = np.nonzero(ncand != on)[0]
+    assert len(bad) == 0, (what, "ncand differs at", bad[:5], ncand[bad[:5]], on[bad[:5]])
+    mask = np.arange(cands.shape[1])[None, :] < on[:, None]
+    neq = np.any((cands != oc) & mask[:, :, None], axis=(1, 2))
+    bad = np.nonzero(neq)[0]
+    assert len(bad) == 0, (what, "cands differ at", bad[:5], cands[bad[0]], oc[bad[0]])
+
+
+def test_config2_refseq_scale_table_on_one_gpu():
+    """configs[2] shape on ONE GPU: 2 600 species x 10 strains of 2-6 Mbp (>= 100 Gbp), every genome two
+    sequences (>= 2^15 targets), one 16 Mbp chromosome (> 2^17 windows), built with -remove-overpopulated-features in
+    feature-hash parts; the handle must come out in the global-window form (the (target, window) bit fields need 34 bits).
+    A batch of 150 bp reads and a batch of 2 x 150 bp pairs against the CPU oracle, which is given the part of the table
+    each batch can touch (oracle/subtable.py): bit-exact.  Needs ~250 GB of HBM: skipped on a smaller part."""
+    eng = importlib.import_module("metacache-mpi_amd.engine")
+    synth = importlib.import_module("metacache-mpi_amd.synth")
+    from oracle import subtable
+    dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info(dev)[0] < 250e9:
+        pytest.skip("needs 250 GB of free HBM")
+    gb, goff, species = synth.make_genomes_big(2600, 10, 2_000_000, 6_000_000, 0.02, seed=3, device=dev, extra_genome=16_000_000)
+    goff, species = synth.split_targets(goff, species, 2, keep_last_whole=True)
+    n_targets = species.numel()
+    tw = synth.window_counts(goff)
+    assert int(goff[-1].item()) >= 100e9 and n_targets >= (1 << 15) and int(tw.max().item()) > (1 << 17)
+    n = 1 << 18
+    reads, roff, _ = synth.sample_reads(gb, goff, n, 150, 0.005, 0.001, seed=2000)
+    pairs, poff, _ = synth.sample_pairs(gb, goff, n // 2, 150, 300, 500, 0.005, 0.001, seed=2001)
+    parts = eng.Parts(gb.data_ptr(), goff.data_ptr(), n_targets, emulate_ranks=2, flags=eng.MCQ_BUILD_REMOVE_OVERPOPULATED)
+    assert parts.n_parts > 1 and parts.n_locs > 1e10
+    del gb
+    torch.cuda.empty_cache()
+    sp32 = species.to(torch.int32).contiguous()
+    db = parts.database(sp32.data_ptr())
+    parts.close()
+    lay = db.layout()
+    assert lay["loc_format"] == eng.MCQ_LOC_GLOBAL_WINDOW and lay["loc_bytes"] == 4 and lay["bucket_bytes"] == 16, lay
+    sp = species.cpu().numpy().astype(np.uint32)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    for (rd, ro_t, n_seqs, paired) in ((reads, roff, n, False), (pairs, poff, n, True)):
+        nq = n_seqs // 2 if paired else n_seqs
+        ws = eng.Workspace(db, nq, rd.numel())
+        cands = torch.zeros((nq, 2, 4), dtype=torch.int32, device=dev); ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
+        ws.query_device(rd.data_ptr(), ro_t.data_ptr(), n_seqs, paired, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+        stats = ws.sync(st)
+        k_, o_, l_ = subtable.batch_subtable(eng, db, rd.data_ptr(), ro_t.data_ptr(), n_seqs, dev, tw)
+        odb = orc.OracleDb(k_, o_, l_, sp)
+        oc, on = odb.query(rd.cpu().numpy().tobytes(), ro_t.cpu().numpy().astype(np.uint64), paired, max_cand=2, emulate_ranks=2, threads=16)
+        _compare(cands.cpu().numpy().view(np.uint32), ncand.cpu().numpy().view(np.uint32), oc, on, "configs[2] shape on one GPU, paired=%d" % paired)
+        assert stats["n_locations"] > 500 * nq and stats["n_two_class"] > nq // 2, stats        # ~900 locations per read: the two-class tails
+        ws.close()
+    db.close()

@@ -153,6 +153,46 @@ def test_ranks_on_one_gpu_over_gloo(paired, world, locs64):
             assert (z["caps"] > 0).all()
 
 
+def test_two_ranks_on_the_bench_table_pairs_and_long_reads():
+    """world 2 on the configs[1] table (500 genomes, 1.96 Gbp, one hash-range shard per rank): a batch of 2 x 150 bp pairs
+    (configs[3] shape) and a batch of ONT-like reads, mean 8 kb (configs[4] shape: every query in the workgroup kernel),
+    blocks through gloo; every rank's results equal the oracle's on the whole table"""
+    with tempfile.TemporaryDirectory() as d:
+        outp = os.path.join(d, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29977",
+               os.path.join(ROOT, "tests", "shard_native_worker.py"), outp, "1", "0", "c2"]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        files = sorted(glob.glob(outp + ".*.npz"))
+        assert len(files) == 2
+        for f in files:
+            z = np.load(f)
+            assert bool(z["ok"][0]), f
+            assert z["overflow"][1] == 1500, z["overflow"]          # every long read left the wave stages
+            assert (z["locs"] > 0).all()
+
+
+def test_rccl_over_two_gpus_when_the_box_has_them():
+    """mcq_shard_* over REAL RCCL between two GPUs (ncclSend / ncclRecv groups over xGMI): skipped on a one-GPU box, so that
+    the driver's multi-GPU node runs it.  One rank per GPU, each its own reads, padded and exact mode, per-rank oracle check."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    with tempfile.TemporaryDirectory() as d:
+        outp = os.path.join(d, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0", MCQ_TEST_TRANSPORT="rccl")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29978",
+               os.path.join(ROOT, "tests", "shard_native_worker.py"), outp, "0", "0"]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        files = sorted(glob.glob(outp + ".*.npz"))
+        assert len(files) == 2
+        for f in files:
+            assert bool(np.load(f)["ok"][0]), f
+
+
 def test_rccl_transport_with_one_rank(tmp_path):
     """the RCCL code path itself (dlopen of librccl, ncclGetUniqueId, ncclCommInitRank, grouped ncclSend / ncclRecv of
     every block) on a box with one GPU: a communicator of ONE rank whose blocks travel to itself through RCCL

@@ -1,5 +1,5 @@
 """N > 1 path on CPU: world_size 2, 3 and 8 over gloo.  The routing of metacache-mpi_amd/
-sharded.py (bucket by owner, all-to-all out and back, per-query reassembly) runs for
+tests/sharded_staged.py (bucket by owner, all-to-all out and back, per-query reassembly) runs for
 real; the per-stage compute is supplied by the oracle.  The reassembled results must
 equal the reference CLI's output for the fixture."""
 import glob
