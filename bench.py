@@ -31,8 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
-KERNELS = {"fused": ("k_query_wave", "k_query_wave16", "k_query_block"),
-           "sharded": ("k_query_wave<sharded>", "k_query_wave16<sharded>", "k_query_block<sharded>")}
+# the three timed slots of a batch: first wave stage; second + third wave stage (k_query_wave32 runs only where the two-class tail
+# does); the workgroup kernels (plain, and the one with the two-class tail behind it)
+KERNELS = {"fused": ("k_query_wave", "k_query_wave16+k_query_wave32", "k_query_block"),
+           "sharded": ("k_query_wave<sharded>", "k_query_wave16+k_query_wave32<sharded>", "k_query_block<sharded>")}
 EXIT_SHARDED_FAILED = 3        # the line is printed (replicas leg), the exit status says the sharded leg failed
 EXIT_PARITY_FAILED = 4         # GPU result differs from the CPU oracle / the fused kernel
 

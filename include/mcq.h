@@ -293,8 +293,8 @@ uint32_t mcq_owner(uint32_t feature, uint32_t n_shards);
 /* Per-kernel timing of the path's kernels (HIP events between them on the call's stream), for the
  * roofline line of bench.py.  enable != 0 starts recording.  mcq_ws_kernel_times returns, summed over
  * the batches since enabling, the milliseconds of ms[0] the first wave stage (k_query_wave / k_reduce_wave),
- * ms[1] the second wave stage (k_query_wave16 / k_reduce_wave16), ms[2] the workgroup kernel
- * (k_query_block / k_reduce_block), and the number of batches; mcq_ws_kernel_time their total.
+ * ms[1] the second and third wave stages (k_query_wave16 + k_query_wave32 / k_reduce_wave16), ms[2] the workgroup kernels
+ * (k_query_block plain + two-class / k_reduce_block), and the number of batches; mcq_ws_kernel_time their total.
  * Both synchronise the recorded events.                                                   */
 int mcq_ws_timing(mcq_ws* ws, int enable);
 int mcq_ws_kernel_times(mcq_ws* ws, double* ms /* [3] */, uint64_t* n_batches);

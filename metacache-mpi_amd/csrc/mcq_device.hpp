@@ -402,19 +402,27 @@ __device__ __forceinline__ u64 cmpex(u64 v, u64 o, u64 keepmin) {
 #define MCQ_CX2(v, DPP_MIN, DPP_MAX) do { u32 r_; \
     asm("s_nop 1\n\tv_min_u32_dpp %0, %1, %1 " DPP_MIN "\n\tv_max_u32_dpp %0, %1, %1 " DPP_MAX \
         : "=&v"(r_) : "v"(v)); v = r_; } while (0)
+#ifdef MCQ_CX3_SGPR_MASK        // tuning knob (A/B; r03: -382 static SALU, +329 s_nop, +129 spill reloads: no gain): the lane mask as an SGPR-pair operand instead of two s_mov into vcc
+#define MCQ_CX3(v, DPP, MASK32) do { u32 lo_, hi_; const u64 m_ = ((u64)(MASK32##u) << 32) | (MASK32##u); \
+    asm("s_nop 1\n\t" \
+        "v_min_u32_dpp %0, %2, %2 " DPP MCQ_DPP_ALL "\n\tv_max_u32_dpp %1, %2, %2 " DPP MCQ_DPP_ALL "\n\t" \
+        "v_cndmask_b32_e64 %0, %1, %0, %3" \
+        : "=&v"(lo_), "=&v"(hi_) : "v"(v), "s"(m_)); v = lo_; } while (0)
+#else
 #define MCQ_CX3(v, DPP, MASK32) do { u32 lo_, hi_; \
-    asm("s_mov_b32 vcc_lo, " MASK32 "\n\ts_mov_b32 vcc_hi, " MASK32 "\n\t"   /* the two wait states before the DPP reads */ \
+    asm("s_mov_b32 vcc_lo, " #MASK32 "\n\ts_mov_b32 vcc_hi, " #MASK32 "\n\t"   /* the two wait states before the DPP reads */ \
         "v_min_u32_dpp %0, %2, %2 " DPP MCQ_DPP_ALL "\n\tv_max_u32_dpp %1, %2, %2 " DPP MCQ_DPP_ALL "\n\t" \
         "v_cndmask_b32_e32 %0, %1, %0, vcc" \
         : "=&v"(lo_), "=&v"(hi_) : "v"(v) : "vcc"); v = lo_; } while (0)
+#endif
 
 // half-cleaners at lane distance 8, 4, 2, 1 (ascending everywhere)
 __device__ __forceinline__ u32 cx_j8(u32 v) { MCQ_CX2(v, "row_ror:8 row_mask:0xf bank_mask:0x3", "row_ror:8 row_mask:0xf bank_mask:0xc"); return v; }
 __device__ __forceinline__ u32 cx_j4(u32 v) { MCQ_CX2(v, "row_shl:4 row_mask:0xf bank_mask:0x5", "row_shr:4 row_mask:0xf bank_mask:0xa"); return v; }
-__device__ __forceinline__ u32 cx_j2(u32 v) { MCQ_CX3(v, "quad_perm:[2,3,0,1]", "0x33333333"); return v; }
-__device__ __forceinline__ u32 cx_j1(u32 v) { MCQ_CX3(v, "quad_perm:[1,0,3,2]", "0x55555555"); return v; }
+__device__ __forceinline__ u32 cx_j2(u32 v) { MCQ_CX3(v, "quad_perm:[2,3,0,1]", 0x33333333); return v; }
+__device__ __forceinline__ u32 cx_j1(u32 v) { MCQ_CX3(v, "quad_perm:[1,0,3,2]", 0x55555555); return v; }
 // flips of blocks of 4, 8, 16 lanes
-__device__ __forceinline__ u32 cx_flip4(u32 v)  { MCQ_CX3(v, "quad_perm:[3,2,1,0]", "0x33333333"); return v; }
+__device__ __forceinline__ u32 cx_flip4(u32 v)  { MCQ_CX3(v, "quad_perm:[3,2,1,0]", 0x33333333); return v; }
 __device__ __forceinline__ u32 cx_flip8(u32 v)  { MCQ_CX2(v, "row_half_mirror row_mask:0xf bank_mask:0x5", "row_half_mirror row_mask:0xf bank_mask:0xa"); return v; }
 __device__ __forceinline__ u32 cx_flip16(u32 v) { MCQ_CX2(v, "row_mirror row_mask:0xf bank_mask:0x3", "row_mirror row_mask:0xf bank_mask:0xc"); return v; }
 // flip of blocks of 32 lanes: partner = mirrored lane of the neighbouring row.  v_permlane16_swap of two

@@ -98,7 +98,7 @@ struct mcq_ws {
     unsigned long long* probe_buf;   // [(max_queries + MCQ_OVF_TAIL) x 64], see CountersDev
     ScratchDev sc;
     int n_block_wgs;
-    u32 cap_wave, cap_wave16, cap_reduce16;   // resident workgroups of the wave-per-query kernels on this device
+    u32 cap_wave, cap_wave16, cap_reduce16, cap_wave32;   // resident workgroups of the wave-per-query kernels on this device
     // staging for host-pointer calls
     char* d_bases; u64* d_seq_off; u32* d_cands; u32* d_ncand;
     u64 last_nq;
@@ -574,11 +574,12 @@ __device__ __forceinline__ u32 heavy_tail(const DbDev& db, const OptDev& opt, co
         wave_sync();
         u32 k1 = MCQ_EMPTY, incl1 = 0, t1 = 0, tb1 = 0;
         const u32 Dd = dedup_insert<E>(rh, buf, hits, nH, lane);
+        if (E > 16 && Dd > MCQ_DEDUP_MAX_D) return ~1u;       // (32 registers of heavy words with more than 256 distinct ones: not sorted here)
         if (E <= 4 || Dd <= MCQ_DEDUP_MAX_D) {
             D = dedup_finish(Dd, buf, hits, lane, lf, k1, incl1, t1, tb1);
             if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, tb1, H, D, numWindows, lf, lane);
             else sweep_targets_weighted(SK, dedup_wp(hits), H, D, numWindows, lf, lane);
-        } else if constexpr (E > 4) {
+        } else if constexpr (E > 4 && E <= 16) {
             wave_sync();
             wave_regsort<u32, E>(rh, lane);
             SK = buf; H = hits; D = nH; nine = false;
@@ -625,17 +626,18 @@ __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt
                                               float word_space, const LF& lf, u64 q, u32 lane, u32* buf, u32* hits) {
     if (opt.P * opt.max_cand > MCQ_TWO_CLASS_MAX_PM || (opt.hooks & 8u)) return ~0u;
     const u32 cs = cell_shift(numWindows);
+    constexpr u32 LOG = E > 16 ? 16u : MCQ_CELL_LOG;         // each map fills one LDS segment (64 x E words)
     u32* occ = buf; u32* multi = hits;
-    cells_clear(occ, multi, lane, 64);
+    cells_clear<LOG>(occ, multi, lane, 64);
     wave_sync();
     // (tried: every register's atomics issued back to back without a branch, zeros ORed where nothing is to be set -- twice
     // the LDS atomics and 5 spilled VGPRs: second wave stage 5.1 -> 7.5 ms on the RefSeq-scale table)
 #pragma unroll
-    for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T) cells_insert(r[e], cs, occ, multi);
+    for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T) cells_insert<LOG>(r[e], cs, occ, multi);
     wave_sync();
     u32 hm = 0;                                              // bit e: r[e] is heavy
 #pragma unroll
-    for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T && cells_heavy(r[e], cs, occ, multi)) hm |= 1u << e;
+    for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T && cells_heavy<LOG>(r[e], cs, occ, multi)) hm |= 1u << e;
     wave_sync();                                             // the maps are dead: heavy words -> hits[0..nH), light prefix -> buf[0..nP)
     const float th = word_space * MCQ_TWO_CLASS_EXPECT * __builtin_amdgcn_rcpf((float)T);
     const u32 theta = th >= 4294967040.0f ? 0xFFFFFFFEu : (u32)th;
@@ -663,7 +665,8 @@ __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt
     if (nH <= 128) return heavy_tail<2>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
     if (nH <= 256) return heavy_tail<4>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
     if (nH <= 512) return heavy_tail<8>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
-    if constexpr (E > 8) return heavy_tail<16>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
+    if constexpr (E > 8) { if (nH <= 1024) return heavy_tail<16>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits); }
+    if constexpr (E > 16) return heavy_tail<32>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
     return ~1u;
 }
 
@@ -923,31 +926,12 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     u32* feat = hits + 64;
     const u32 nwaves = gridDim.x * 4;
     const u32 n_mid = ctr->ovf_mid_count;
-    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_retry = 0, st_narrow = 0;
+    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_retry = 0;
     u32 fq_next = 0, fq_left = 0;                      // this wave's reservation in the front queue (wide reads with > 1024 locations)
     // size of the space the location words live in (for the light-word threshold of the two-class tail)
     float word_space;
     if constexpr (GW) word_space = (float)gwd.off[db.n_targets];
     else word_space = (db.wb < 32 && ((u64)db.n_targets << db.wb) < 0xFFFFFFFFull) ? (float)((u64)db.n_targets << db.wb) : 4294967040.0f;
-    // How many queries with narrow window ranges wait in the front queue (the two-class workgroup kernel's share)?  Counted
-    // here, one entry per lane, for what the first stage queued -- in that kernel the count cost 0.7 % of configs[1] -- and
-    // below for what this kernel passes on.  (Entries this kernel appends meanwhile may be seen twice: the count only decides
-    // whether that kernel is worth running, and both workgroup kernels read the same final value.)
-    if (opt.tc_limit) {
-        const u32 n_front = ctr->ovf_count;
-        u32 cnt = 0;
-        for (u32 i = (blockIdx.x * 4 + wave) * 64 + lane; i < n_front; i += nwaves * 64) {
-            const u32 qf = ovf_list[i];
-            if (qf == MCQ_EMPTY) continue;
-            const u64 a = b.paired ? 2ull * qf : qf;
-            u64 o0, e0, o1 = 0, e1 = 0;
-            seq_bounds(b.seq_off, b.ranges, a, o0, e0);
-            if (b.paired) seq_bounds(b.seq_off, b.ranges, a + 1, o1, e1);
-            cnt += (e0 - o0) + (e1 - o1) < opt.tc_limit ? 1u : 0u;
-        }
-        for (int d = 32; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-        st_narrow += cnt;
-    }
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
         const u32 q32 = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
         if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
@@ -995,7 +979,6 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
             }
             if (lane == 0) ovf_list[fq_next] = q32;
             ++fq_next; --fq_left;
-            st_narrow += g.qlen < opt.tc_limit ? 1 : 0;
             continue;
         }
         st_loc += T;
@@ -1034,6 +1017,10 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
                 const u32 n2 = two_class_tail<16>(db, opt, out, r, T, numWindows, word_space, lf, q, lane, buf, hits);
                 if (n2 == ~1u) {                        // given up after the registers were spent: the workgroup kernel takes it
                     st_loc -= T; st_retry += 1;
+                    if (g.wide) {                       // (the workgroup kernel counts them again)
+                        if constexpr (!SH) st_feat -= nfeat;
+                        st_hit -= (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
+                    }
                     if (fq_left == 0) {
                         u32 base = 0;
                         if (lane == 0) base = atomicAdd(&ctr->ovf_count, MCQ_OVF_CHUNK);
@@ -1041,7 +1028,6 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
                     }
                     if (lane == 0) ovf_list[fq_next] = q32;
                     ++fq_next; --fq_left;
-                    st_narrow += g.qlen < opt.tc_limit ? 1 : 0;
                     wave_sync();
                     continue;
                 }
@@ -1060,6 +1046,89 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
     if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
     if (lane == 0 && st_retry) atomicAdd(&ctr->n_two_class_retry, st_retry);
+    if (lane == 0 && (st_feat | st_loc | st_hit)) {
+        if (st_feat) atomicAdd(&ctr->n_features, st_feat);
+        atomicAdd(&ctr->n_hit_features, st_hit);
+        atomicAdd(&ctr->n_locations, st_loc);
+        atomicAdd(&ctr->n_cands, st_cand);
+    }
+}
+
+// ------------------------------------------------------------------ kernel: wave per query, 32 keys per lane (two-class tail only)
+// Third wave stage, for what a RefSeq-scale table does to short reads: 1025..2048 locations for at most 128 features -- one
+// read in five there -- which until round 3 took a 1024-thread workgroup each (67 us per read; the second wave stage takes
+// 6 us).  It walks the FRONT queue before the workgroup kernels do: an entry it can answer -- few features, a list that fits
+// 32 registers per lane, lists provable by the two-class tail -- is answered and overwritten with the empty marker; every
+// other entry stays for the workgroup kernels, and the narrow ones among those are counted for them (see k_query_block).
+// Sketch and probe again (no hand-over: ~8 us of the ~50), two features per lane as in the second stage.  16 KB of LDS per
+// wave, two waves per SIMD.  Launched only when the two-class tail is (32-bit words, P x M <= 16).
+template <bool SH = false, bool GW = false, int BSH = -1>
+__global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, OptDev opt, OutDev out, CountersDev* ctr, u32* ovf_list,
+                                                         ShardDev sh, GwDev gwd) {
+    constexpr int LCAP = 2048;
+    const typename LocOf<u32, GW>::type lf = loc_format<u32, GW>(db, gwd);
+    __shared__ u32 s_buf[4][LCAP];
+    __shared__ u32 s_hits[4][LCAP];
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    u32* buf = s_buf[wave];
+    u32* hits = s_hits[wave];
+    u32* sk_tmp = hits;
+    u32* feat = hits + 64;
+    const u32 nwaves = gridDim.x * 4;
+    const u32 n_front = ctr->ovf_count;                // (nothing appends to the front queue while this kernel runs)
+    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_narrow = 0;
+    float word_space;
+    if constexpr (GW) word_space = (float)gwd.off[db.n_targets];
+    else word_space = (db.wb < 32 && ((u64)db.n_targets << db.wb) < 0xFFFFFFFFull) ? (float)((u64)db.n_targets << db.wb) : 4294967040.0f;
+    for (u32 it = blockIdx.x * 4 + wave; it < n_front; it += nwaves) {
+        const u32 slot = ovf_visit(it, n_front);
+        const u32 q32 = ovf_list[slot];
+        if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
+        const u64 q = q32;
+        const ReadGeom g = read_geom(db, b, q, 0);
+        const u32 narrow = g.qlen < opt.tc_limit ? 1u : 0u;
+        if (g.ovf && !g.wide) { st_narrow += narrow; continue; }      // more than 128 features: a workgroup's
+        u32 nfeat = 0;
+        bool two = false;
+        u64 off0 = 0, off1 = 0; u32 len0 = 0, len1 = 0;
+        if constexpr (SH) {
+            nfeat = (g.nw1 + g.nw2) * db.s;
+            two = nfeat > 64;
+            const u64 sb = sh.win_off[b.paired ? 2 * q : q] * db.s;
+            if (lane < nfeat) shard_fetch(sh, sb + lane, off0, len0);
+            if (two && 64 + lane < nfeat) shard_fetch(sh, sb + 64 + lane, off1, len1);
+        } else {
+            for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
+                u64 at; u32 wl;
+                window_span(db, g, w, at, wl);
+                nfeat += wave_sketch_b(b, at, wl, db.k, db.s, lane, sk_tmp, feat + nfeat);
+            }
+            two = nfeat > 64;                          // wave-uniform
+            const u32 myf0 = lane < nfeat ? feat[lane] : MCQ_EMPTY;
+            const u32 myf1 = (two && 64 + lane < nfeat) ? feat[64 + lane] : MCQ_EMPTY;
+            probe<BSH>(db, myf0, off0, len0);
+            if (two) probe<BSH>(db, myf1, off1, len1);
+        }
+        const u32 incl0 = wave_incl_scan_dpp(len0);
+        const u32 T0 = bcast(incl0, 63);
+        const u32 incl1 = wave_incl_scan_dpp(len1) + T0;
+        const u32 pos0 = incl0 - len0, pos1 = incl1 - len1;
+        const u32 T = bcast(incl1, 63);
+        if (T > (u32)LCAP || T == 0) { st_narrow += narrow; continue; }          // (an empty list: the workgroup kernel writes the zero)
+        wave_sync();                                   // feat[] (aliasing hits) has been consumed
+        const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
+        u32 r[32];
+        gather_regs2<32>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, hits);
+        const u32 n2 = two_class_tail<32>(db, opt, out, r, T, numWindows, word_space, lf, q, lane, buf, hits);
+        wave_sync();
+        if (n2 >= ~1u) { st_narrow += narrow; continue; }             // not taken / not provable: the entry stays
+        if (lane == 0) ovf_list[slot] = MCQ_EMPTY;                    // answered
+        if constexpr (!SH) st_feat += nfeat;
+        st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
+        st_loc += T; st_cand += n2; st_two += 1;
+    }
+    if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
     if (lane == 0 && st_narrow) atomicAdd(&ctr->n_narrow, st_narrow);
     if (lane == 0 && (st_feat | st_loc | st_hit)) {
         if (st_feat) atomicAdd(&ctr->n_features, st_feat);
@@ -2202,6 +2271,7 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     ws->cap_wave16 = db->g.on ? resident_blocks(k_query_wave16<false, false, true, 2>, 256, db->device)
                               : resident_blocks(k_query_wave16<false, false, false, 2>, 256, db->device);
     ws->cap_reduce16 = db->g.on ? resident_blocks(k_reduce_wave16<true>, 256, db->device) : resident_blocks(k_reduce_wave16<false>, 256, db->device);
+    ws->cap_wave32 = db->g.on ? resident_blocks(k_query_wave32<false, true, 2>, 256, db->device) : resident_blocks(k_query_wave32<false, false, 2>, 256, db->device);
     const u64 nb = (u64)ws->n_block_wgs;
 #define WSCHK(expr) HIPCHK_OR(expr, (void)mcq_ws_destroy(ws))
     WSCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
@@ -2384,6 +2454,14 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
         else if (gw)  { if (b64) MCQ_LAUNCH_WAVE16(false, false, true, 2); else MCQ_LAUNCH_WAVE16(false, false, true, 0); }
         else          { if (b64) MCQ_LAUNCH_WAVE16(false, false, false, 2); else MCQ_LAUNCH_WAVE16(false, false, false, 0); }
 #undef MCQ_LAUNCH_WAVE16
+    }
+    if (with_tc) {          // third wave stage: front-queue entries of up to 2048 locations (see k_query_wave32); counts the narrow ones it leaves
+        const dim3 g32(grid_for(ws->cap_wave32, want));
+#define MCQ_LAUNCH_WAVE32(SHV, GWV, BSHV) hipLaunchKernelGGL((k_query_wave32<SHV, GWV, BSHV>), g32, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, sh, db->g)
+        if (shp)     { if (gw) MCQ_LAUNCH_WAVE32(true, true, -1); else MCQ_LAUNCH_WAVE32(true, false, -1); }
+        else if (gw) { if (b64) MCQ_LAUNCH_WAVE32(false, true, 2); else MCQ_LAUNCH_WAVE32(false, true, 0); }
+        else         { if (b64) MCQ_LAUNCH_WAVE32(false, false, 2); else MCQ_LAUNCH_WAVE32(false, false, 0); }
+#undef MCQ_LAUNCH_WAVE32
     }
     rc = tm.mark(); if (rc) return rc;
 #define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV, SHV, GWV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV, SHV, GWV, false>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, D, b, od, o, ws->ctr, \
