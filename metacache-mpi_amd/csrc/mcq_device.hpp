@@ -1358,6 +1358,125 @@ __device__ __forceinline__ u32 topk_all_lds(const DbDev& db, const OptDev& opt, 
     return fold_lists_write<u32, u32, JB>(db, opt, out, buf, Ltax, Lhv, numWindows, lf, q, lane, mx, wt);
 }
 
+// ---- rows 10-11 with more lists than lanes (the reference's mpiexec -n 32 / -n 64 with -maxcand 4) ---------------------------
+// pow2ceil(P) x seg list slots, seg = pow2ceil(M) lanes per list, wrap over NL registers per lane: slot s = j * 64 + lane of
+// register j belongs to list s / seg, entry s % seg.  Same selection rounds and the same fold as the one-register forms
+// above (whose code the hot instantiations keep unchanged); NL = 4 covers P x M <= 256.
+template <int NL>
+struct ListSlots {
+    u32 tax[NL]; u32 hv[NL];
+};
+template <class KeyT, int JB, int NL, class LF>
+__device__ __forceinline__ u32 fold_lists_write_n(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* buf, ListSlots<NL>& L,
+                                                  u32 numWindows, const LF& lf, u64 q, u32 lane, u32* mx, u32* wt) {
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    u32 rl[NL], li[NL]; bool lslot[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { const u32 s = j * 64 + lane; rl[j] = s / seg; li[j] = s - rl[j] * seg; lslot[j] = li[j] < M && rl[j] < P; }
+    if (P > 1) {
+        u32 lb = 0;
+        for (u32 Lv = 0; Lv < opt.n_levels; ++Lv) {
+            const u32 le = opt.level_end[Lv];
+            u32 my_rcv[NL], fk[NL], Ntax[NL], Nhv[NL]; bool part[NL], is_snd[NL];
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { my_rcv[j] = 63; part[j] = false; is_snd[j] = false; Ntax[j] = MCQ_EMPTY; Nhv[j] = 0; }
+            for (u32 e = lb; e < le; ++e) {
+                const u32 snd = opt.fold_snd[e], rcv = opt.fold_rcv[e];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    if (rl[j] == snd) { my_rcv[j] = rcv; part[j] = true; is_snd[j] = true; }
+                    if (rl[j] == rcv) { my_rcv[j] = rcv; part[j] = true; }
+                }
+            }
+            lb = le;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                part[j] = part[j] && lslot[j];
+                const bool mine = part[j] && L.hv[j] != 0 && !(opt.quirk_seq_drop && is_snd[j] && (L.tax[j] & 0x80000000u));
+                fk[j] = mine ? ((L.hv[j] >> JB) << 8) | (255u - (is_snd[j] ? M + li[j] : li[j])) : 0u;
+            }
+            for (u32 i = 0; i < M; ++i) {
+                mx[lane] = 0;
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < NL; ++j) if (fk[j] != 0) atomicMax(&mx[my_rcv[j]], fk[j]);
+                wave_sync();
+                u32 m[NL];
+#pragma unroll
+                for (int j = 0; j < NL; ++j) { m[j] = mx[my_rcv[j]]; if (fk[j] != 0 && fk[j] == m[j]) wt[my_rcv[j]] = L.tax[j]; }
+                wave_sync();
+#pragma unroll
+                for (int j = 0; j < NL; ++j) {
+                    const u32 wtax = wt[my_rcv[j]];
+                    if (part[j] && m[j] != 0) {
+                        if (!is_snd[j] && li[j] == i) { Ntax[j] = wtax; Nhv[j] = (m[j] >> 8) << JB; }
+                        if (fk[j] != 0 && L.tax[j] == wtax) fk[j] = 0;
+                    }
+                }
+                wave_sync();
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) if (part[j]) { L.tax[j] = Ntax[j]; L.hv[j] = Nhv[j]; }
+        }
+    }
+    // list 0 is the result: entries 0..M-1 = lanes 0..M-1 of register 0
+    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && L.hv[0] != 0));
+    if (lane < n) {
+        u32 beg = 0, end = 0;
+        if (P == 1) best_range<KeyT, u32, JB>(buf, L.hv[0], numWindows, lf, beg, end);
+        reinterpret_cast<uint4*>(out.cands)[q * M + lane] = make_uint4(L.tax[0], L.hv[0] >> JB, beg, end);
+    }
+    if (lane == 0) out.ncand[q] = n;
+    return n;
+}
+// all run heads at once (as topk_all_lds): H[0..nheads) compacted packed words, nheads <= 64 * NC
+template <int JB, int NC, int NL, class LF>
+__device__ __forceinline__ u32 topk_all_lds_n(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* buf, const u32* H, u32 nheads,
+                                              u32 numWindows, const LF& lf, u64 q, u32 lane, u32* scr) {
+    static_assert(JB <= 10, "hits << JB stays below bit 26");
+    const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
+    const bool p2 = (P & (P - 1)) == 0;
+    const u32 JMASK = (1u << JB) - 1, VMASK = (1u << 26) - 1;
+    u32* mx = scr; u32* wt = scr + 64;
+    u32 cv[NC], ctax[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        cv[c] = 0; ctax[c] = MCQ_EMPTY;
+        if ((u32)(c * 64) >= nheads) continue;               // wave-uniform
+        const u32 k = c * 64 + lane;
+        const u32 v = (k < nheads) ? H[k] : 0;
+        const u32 tgt = lf.tgt(buf[v ? JMASK - (v & JMASK) : 0]);
+        if (v != 0 && tgt < db.n_targets) ctax[c] = db.tgt2tax[tgt];
+        const u32 cr = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
+        cv[c] = v | (cr << 26);
+        if (v == 0 || ctax[c] == MCQ_EMPTY) cv[c] = 0;
+    }
+    ListSlots<NL> L;
+    u32 rl[NL], li[NL]; bool lslot[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) { const u32 s = j * 64 + lane; rl[j] = s / seg; li[j] = s - rl[j] * seg; lslot[j] = li[j] < M && rl[j] < P; L.tax[j] = MCQ_EMPTY; L.hv[j] = 0; }
+    for (u32 i = 0; i < M; ++i) {
+        mx[lane] = 0;
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (cv[c] != 0) atomicMax(&mx[cv[c] >> 26], cv[c]);
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (cv[c] != 0 && cv[c] == mx[cv[c] >> 26]) wt[cv[c] >> 26] = ctax[c];   // packed words are unique
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const u32 r = rl[j] < 64 ? rl[j] : 63;
+            const u32 ml = mx[r], wtl = wt[r];
+            if (lslot[j] && li[j] == i && ml != 0) { L.tax[j] = wtl; L.hv[j] = ml & VMASK; }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) if (cv[c] != 0 && ctax[c] == wt[cv[c] >> 26]) cv[c] = 0;
+        wave_sync();
+    }
+    return fold_lists_write_n<u32, JB, NL>(db, opt, out, buf, L, numWindows, lf, q, lane, mx, wt);
+}
+
 // ---- rows 8-11 in two classes (large tables: most of a read's locations are chance hits on unrelated targets) ------
 // On a RefSeq-scale table a 150-base read gathers ~900 locations of which ~700 are single chance hits, each alone on its
 // target; sorting and sweeping all of them to find the dozen targets that matter is most of the work.  The window space is

@@ -98,7 +98,7 @@ struct mcq_ws {
     unsigned long long* probe_buf;   // [(max_queries + MCQ_OVF_TAIL) x 64], see CountersDev
     ScratchDev sc;
     int n_block_wgs;
-    u32 cap_wave, cap_wave16, cap_reduce16, cap_wave32;   // resident workgroups of the wave-per-query kernels on this device
+    u32 cap_wave, cap_wave16, cap_reduce16, cap_wave32, cap_wave_many;   // resident workgroups of the wave-per-query kernels on this device
     // staging for host-pointer calls
     char* d_bases; u64* d_seq_off; u32* d_cands; u32* d_ncand;
     u64 last_nq;
@@ -730,6 +730,25 @@ __device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, co
     return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, nheads, numWindows, lf, q, lane);
 }
 
+// Top lists when the P lists do not fit the 64 lanes of a wave (NL list registers per lane: the reference's -n 32 / -n 64
+// with -maxcand 4): the run heads to the front of H, all of them at once through the LDS maxima.  ~0u: more than 256 heads
+// -- the caller hands the query to the workgroup kernel.  scr: 128 words of LDS behind the heads.
+template <int NL, class LF>
+__device__ __forceinline__ u32 topk_many_lists(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* sk, u32* H, u32 D,
+                                               u32 numWindows, const LF& lf, u64 q, u32 lane, u32* scr) {
+    u32 nheads = 0;
+    for (u32 base = 0; base < D; base += 64) {                  // in place: writes trail reads
+        const u32 j = base + lane;
+        const u32 hv = (j < D) ? H[j] : 0;
+        const u64 hm = __ballot(hv != 0);
+        if (hv != 0) H[nheads + lane_rank(hm)] = hv;
+        nheads += (u32)__builtin_popcountll(hm);
+    }
+    wave_sync();
+    if (nheads > 256) return ~0u;
+    return topk_all_lds_n<9, 4, NL>(db, opt, out, sk, H, nheads, numWindows, lf, q, lane, scr);
+}
+
 #ifndef MCQ_WAVE_OCC
 #define MCQ_WAVE_OCC 8          // waves per SIMD the 32-bit-key kernel is compiled for (tuning knob)
 #endif
@@ -752,8 +771,10 @@ __device__ __forceinline__ void tap_distinct(const DebugDev& dbg, const u32* SK,
 // exchange (shard_fetch) instead of sketch + probe, and db.locs is the received location buffer.
 // GW: 32-bit locations in the global-window form (LocGW), else bit fields (LocShift).  BSH: table layout at compile time (2 = 64-B
 // buckets, 0 = 16-B slots; -1 = run-time: the TAP instantiations), see probe()
-template <class KeyT, int LCAP, bool TAP = false, bool SH = false, bool GW = false, int BSH = -1>
-__global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
+// NL > 1: the P virtual-rank lists take NL registers per lane (P x M up to 256; see topk_many_lists): an instantiation of its
+// own, so that the usual one carries none of it
+template <class KeyT, int LCAP, bool TAP = false, bool SH = false, bool GW = false, int BSH = -1, int NL = 1>
+__global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC) : 5) void k_query_wave(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                     CountersDev* ctr, u32* ovf_list, int force_block, DebugDev dbg, ShardDev sh, GwDev gwd) {
     static_assert(LCAP == 512, "wave path: 8 keys per lane at most, entry index packed into 9 bits");
     static_assert(!GW || sizeof(KeyT) == 4, "the global-window form is a 32-bit word");
@@ -870,6 +891,14 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
                     if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, tb1, reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
                     else sweep_targets_weighted(dedup_sk(hits), dedup_wp(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, lane);
                     if (stop == 5) { if (buf[lane] == 0x12345u) out.ncand[q] = 1; wave_sync(); continue; }
+                    if constexpr (NL > 1) {
+                        const u32 nc = topk_many_lists<NL>(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, q, lane, reinterpret_cast<u32*>(buf) + 256);
+                        if (nc == ~0u) {            // (cannot happen here: at most 256 distinct keys) -- the workgroup kernel
+                            if (lane == 0) ovf_push(s_ovf[wave], 0, ctr, ovf_list, b.nq, (u32)q);
+                            if constexpr (!SH) st_feat -= nfeat;
+                            st_hit -= (u32)__builtin_popcountll(__ballot(len > 0)); st_loc -= T;
+                        } else st_cand += nc;
+                    } else
                     st_cand += MCQ_TOPK_DEDUP(db, opt, out, dedup_sk(hits), reinterpret_cast<u32*>(buf), D, numWindows, lf, q, lane, t1);
                     wave_sync();
                     continue;
@@ -889,6 +918,14 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? MCQ_WAVE_OCC : 5) void k_q
         if constexpr (TAP) { if (dbg.mode == 2) tap_sorted<KeyT>(dbg, buf, T, lf, q, lane); }
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, lf, lane);
         if (stop == 5) { if (hits[lane] == 0x12345u) out.ncand[q] = 1; continue; }
+        if constexpr (NL > 1) {
+            const u32 nc = topk_many_lists<NL>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, lf, q, lane, hits + (LCAP - 128));
+            if (nc == ~0u) {                        // more than 256 run heads: the workgroup kernel (lists in its LDS)
+                if (lane == 0) ovf_push(s_ovf[wave], 0, ctr, ovf_list, b.nq, (u32)q);
+                if constexpr (!SH) st_feat -= nfeat;
+                st_hit -= (u32)__builtin_popcountll(__ballot(len > 0)); st_loc -= T;
+            } else st_cand += nc;
+        } else
         if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, lf, q, lane);
         else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
         wave_sync();
@@ -2271,6 +2308,8 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     ws->cap_wave16 = db->g.on ? resident_blocks(k_query_wave16<false, false, true, 2>, 256, db->device)
                               : resident_blocks(k_query_wave16<false, false, false, 2>, 256, db->device);
     ws->cap_reduce16 = db->g.on ? resident_blocks(k_reduce_wave16<true>, 256, db->device) : resident_blocks(k_reduce_wave16<false>, 256, db->device);
+    ws->cap_wave_many = db->g.on ? resident_blocks(k_query_wave<u32, 512, false, false, true, 2, 4>, 256, db->device)
+                               : resident_blocks(k_query_wave<u32, 512, false, false, false, 2, 4>, 256, db->device);
     ws->cap_wave32 = db->g.on ? resident_blocks(k_query_wave32<false, true, 2>, 256, db->device) : resident_blocks(k_query_wave32<false, false, 2>, 256, db->device);
     const u64 nb = (u64)ws->n_block_wgs;
 #define WSCHK(expr) HIPCHK_OR(expr, (void)mcq_ws_destroy(ws))
@@ -2414,7 +2453,7 @@ struct LaunchTimer {
 // sh != nullptr: the feature-sharded home side (SH instantiations; dbd = the handle's DbDev with `locs` pointing at the
 // received location buffer); the counters are then zeroed by the caller (the sketch kernel has already counted)
 static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const OptDev& od_in, const OutDev& o,
-                        hipStream_t st, int force_block, const DebugDev& dbg, const ShardDev* shp = nullptr, const DbDev* dbd = nullptr) {
+                        hipStream_t st, int force_block_in, const DebugDev& dbg, const ShardDev* shp = nullptr, const DbDev* dbd = nullptr) {
     if (!shp) HIPCHK(hipMemsetAsync(ws->ctr, 0, MCQ_CTR_ZEROED, st));
     if (b.nq == 0) return MCQ_OK;
     ShardDev sh; memset(&sh, 0, sizeof(sh));
@@ -2435,12 +2474,26 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     const bool with_tc = db->d.compact && !od_in.big && !tap && od_in.P * od_in.max_cand <= MCQ_TWO_CLASS_MAX_PM && !(od_in.hooks & 8u) && od_in.insert_size_max < tc_len;
     OptDev od = od_in;
     od.tc_limit = with_tc ? tc_len : 0;
+    // P x M beyond a wave's 64 lanes (the reference's mpiexec -n 32 / -n 64 with -maxcand 4): up to pow2ceil(P) x pow2ceil(M) = 256
+    // the first wave stage keeps the lists in four registers per lane (NL instantiation; 32-bit words); what overflows it, and
+    // every other case, takes the workgroup kernel with the lists in its LDS (`big`)
+    const u32 pm_slots = (u32)pow2ceil64(od_in.P) * (u32)pow2ceil64(od_in.max_cand);
+    const bool many = od_in.big && db->d.compact && !tap && !shp && pm_slots <= 256 && !(force_block_in & 1);
+    const int force_block = force_block_in | ((od_in.big && !many) ? 1 : 0) | (many ? 4 : 0);
+    OptDev od_many = od;
+    if (many) { od_many.big = 0; od_many.seg = (u32)pow2ceil64(od_in.max_cand); }
     const bool gw = db->g.on != 0;      // 32-bit locations in the global-window form: the GW instantiations
     const bool b64 = db->d.bsh != 0;    // table layout: the wave kernels are instantiated per layout (taps and the sharded home side: run-time / unused)
 #define MCQ_LAUNCH_WAVE(KT, TAPV, SHV, GWV, BSHV) hipLaunchKernelGGL((k_query_wave<KT, kLcapWave, TAPV, SHV, GWV, BSHV>), dim3(grid), dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, force_block, dbg, sh, db->g)
 #define MCQ_LAUNCH_WAVE_L(KT, GWV) do { if (b64) MCQ_LAUNCH_WAVE(KT, false, false, GWV, 2); else MCQ_LAUNCH_WAVE(KT, false, false, GWV, 0); } while (0)
     if (shp)                { if (!db->d.compact) MCQ_LAUNCH_WAVE(u64, false, true, false, -1); else if (gw) MCQ_LAUNCH_WAVE(u32, false, true, true, -1); else MCQ_LAUNCH_WAVE(u32, false, true, false, -1); }
     else if (tap)           { if (!db->d.compact) MCQ_LAUNCH_WAVE(u64, true, false, false, -1); else if (gw) MCQ_LAUNCH_WAVE(u32, true, false, true, -1); else MCQ_LAUNCH_WAVE(u32, true, false, false, -1); }
+    else if (many) {
+#define MCQ_LAUNCH_MANY(GWV, BSHV) hipLaunchKernelGGL((k_query_wave<u32, kLcapWave, false, false, GWV, BSHV, 4>), dim3(grid_for(ws->cap_wave_many, want)), dim3(256), 0, st, D, b, od_many, o, ws->ctr, ws->ovf_list, force_block, dbg, sh, db->g)
+        if (gw) { if (b64) MCQ_LAUNCH_MANY(true, 2); else MCQ_LAUNCH_MANY(true, 0); }
+        else    { if (b64) MCQ_LAUNCH_MANY(false, 2); else MCQ_LAUNCH_MANY(false, 0); }
+#undef MCQ_LAUNCH_MANY
+    }
     else if (db->d.compact) { if (gw) MCQ_LAUNCH_WAVE_L(u32, true); else MCQ_LAUNCH_WAVE_L(u32, false); }
     else                    MCQ_LAUNCH_WAVE_L(u64, false);
 #undef MCQ_LAUNCH_WAVE_L
@@ -2520,7 +2573,7 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
     if (!dev_out) { o.cands = ws->d_cands; o.ncand = ws->d_ncand; }
     else { o.cands = (u32*)out->cands; o.ncand = out->n_cand; }
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
-    rc = launch_query(db, ws, b, od, o, st, force_bits(opt->flags) | (od.big ? 1 : 0), dbg);
+    rc = launch_query(db, ws, b, od, o, st, force_bits(opt->flags), dbg);
     if (rc) return rc;
     if (!dev_out && nq) {
         HIPCHK(hipMemcpyAsync(out->cands, ws->d_cands, nq * od.max_cand * 16, hipMemcpyDeviceToHost, st));
@@ -2586,7 +2639,7 @@ extern "C" int mcq_query_pipelined(const mcq_db* db, mcq_ws* ws, const mcq_batch
     BatchDev b; rc = batch_dev(&hin, p.d_bases[k], p.d_seq_off[k], b); if (rc) return rc;
     OutDev o; o.cands = p.d_cands[k]; o.ncand = p.d_ncand[k];
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
-    rc = launch_query(db, ws, b, od, o, p.s_k, force_bits(opt->flags) | (od.big ? 1 : 0), dbg); if (rc) return rc;
+    rc = launch_query(db, ws, b, od, o, p.s_k, force_bits(opt->flags), dbg); if (rc) return rc;
     HIPCHK(hipEventRecord(p.ev_k[k], p.s_k));
     // out
     HIPCHK(hipStreamWaitEvent(p.s_out, p.ev_k[k], 0));

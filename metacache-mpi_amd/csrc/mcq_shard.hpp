@@ -628,7 +628,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     BatchDev bd; rc = batch_dev(in, in->bases, in->seq_off, bd); if (rc) return rc;
     OutDev o; o.cands = (u32*)out->cands; o.ncand = out->n_cand;
     DebugDev dbg; memset(&dbg, 0, sizeof(dbg));
-    rc = launch_query(c->db, ws, bd, od, o, st, force_bits(opt->flags) | (od.big ? 1 : 0), dbg, &sh, &dbd); if (rc) return rc;
+    rc = launch_query(c->db, ws, bd, od, o, st, force_bits(opt->flags), dbg, &sh, &dbd); if (rc) return rc;
     hipLaunchKernelGGL(k_shard_add_count, dim3(1), dim3(1), 0, st, &ws->ctr->n_features, (const unsigned long long*)b.feat_cnt);
     HIPCHK(hipEventRecord(c->ev_done[k], st));            // this buffer set may be overwritten
     c->last_nq = nq;

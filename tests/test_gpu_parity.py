@@ -59,7 +59,11 @@ def test_final_vs_reference_cli(eng, tag, P, block, fmt):
     oc, on = odb.query(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=P, quirk_seq_drop=1)
     _same(cands, ncand, oc, on)
     st = ws.sync()
-    assert st["n_overflow"] == (len(fx.names) if (block is True or P * fx.maxcand > 64) else st["n_overflow"])
+    # P x M > 64: the lists take four registers per lane in the first wave stage (32-bit words, up to 256 list slots); only
+    # 64-bit words (and a forced workgroup path) send every query to the workgroup kernel, which keeps the lists in its LDS
+    p2 = 1 << (P - 1).bit_length(); m2 = 1 << (fx.maxcand - 1).bit_length()
+    all_block = block is True or (P * fx.maxcand > 64 and (fmt == "loc64" or p2 * m2 > 256))
+    assert st["n_overflow"] == len(fx.names) if all_block else st["n_overflow"] < len(fx.names)
 
 
 @pytest.mark.parametrize("tag,P", [("mini", 2), ("mini", 8), ("tie", 4)])
