@@ -64,6 +64,9 @@ enum {
                                       instead of the second wave stage                     */
     MCQ_NO_TWO_CLASS = 0x4000u,    /* test hook: long match lists are sorted whole instead of taking the two-class tail
                                       (light / heavy locations: DESIGN.md section 4); same results either way            */
+    MCQ_FOLD_BY_LISTS = 0x8000u,   /* test hook: emulate_ranks > 1 builds the P bounded lists and folds them level by level (the form
+                                      MCQ_QUIRK_SEQ_DROP needs on a table with sequence-level taxa) instead of the one selection
+                                      in the order (hits, rank, position) that gives the same list        */
     MCQ_BUILD_REMOVE_OVERPOPULATED = 0x1000u, /* mcq_build_desc.flags: the build option
                                    -remove-overpopulated-features (src/mode_build.cpp:847-1074): a feature whose
                                    per-rank location counts (after the per-rank limit) sum to more than

@@ -140,6 +140,10 @@ struct OptDev {
     unsigned char fold_snd[MCQ_MAX_FOLD];
     unsigned char fold_rcv[MCQ_MAX_FOLD];
     u64 tc_limit;            // workgroup kernels: queries shorter than this belong to the two-class kernel (0 = there is none)
+    u32 lin;                 // P > 1 as ONE selection in the order (hits, rank, position) instead of P lists and the tree fold
+                             // (topk_lin_write; seg = 64, big = 0, no fold schedule); not with MCQ_QUIRK_SEQ_DROP on a table
+                             // that has sequence-level taxa
+    u32 keep;                // lin: the ranks the tree routes to rank 0 = [0, keep), keep = 2^floor(log2 P)
 };
 
 struct OutDev {
@@ -1184,6 +1188,76 @@ __device__ __forceinline__ u32 topk_fold_write(const DbDev& db, const OptDev& op
     return n;
 }
 
+// ---- rows 10-11 as ONE selection (OptDev::lin) ----------------------------------------------------------------------
+// The P bounded lists and their tree fold (src/querying.h:867-1073) lose nothing the final M entries could contain: an
+// entry that misses its rank's list has M better distinct taxa (or a better entry of its own taxon) in that rank alone, a
+// fold step is the same bounded insert on receiver-list ++ sender-list, and the tree concatenates the ranks in ascending
+// order (the ranks >= 2^floor(log2 P) of a non-power-of-two P never reach rank 0).  So the folded list is the first M
+// distinct taxa of ALL candidates of the ranks < keep in the order (hits descending, rank ascending, position ascending):
+// tests/test_toplist_theorem.py checks exactly this against the restated insert() + tree.  The rank goes into the packed
+// word between hits and position (6 bits), M selection rounds per 64 run heads with DPP maxima, no lists, no fold levels
+// -- the same cost for -n 64 as for -n 2.  Not under MCQ_QUIRK_SEQ_DROP on a table with sequence-level taxa (a dropped entry
+// has held a slot of an intermediate list: the lists and the levels are carried out then).
+#ifdef MCQ_LIN_ONLY                     // tuning knob (A/B): the wave kernels without the code of the lists (wrong results where they are needed)
+#define MCQ_OPT_LIN(opt) true
+#else
+#define MCQ_OPT_LIN(opt) ((opt).lin != 0)
+#endif
+template <class HT, int JB>
+__device__ __forceinline__ HT lin_word(HT cv, u32 cr) {
+    return ((cv >> JB) << (JB + 6)) | ((HT)(63u - cr) << JB) | (cv & (((HT)1 << JB) - 1));
+}
+__device__ __forceinline__ u32 lin_rank(const OptDev& opt, u32 tgt) {
+    const u32 P = opt.P;
+    return (P & (P - 1)) == 0 ? (tgt & (P - 1)) : (tgt % P);
+}
+// H[0..nheads): the compacted packed words (hits << JB | JMASK - j) of the run heads, j indexing buf; REGT as below
+template <class KeyT, int JB, bool REGT = false, class LF>
+__device__ __forceinline__ u32 topk_lin_write(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* buf, const u32* H, u32 nheads,
+                                              const LF& lf, u64 q, u32 lane, u32 t1 = 0) {
+    const u32 M = opt.max_cand;
+    const u32 JMASK = (1u << JB) - 1;
+    u32 Ltax = MCQ_EMPTY, Lk = 0;                       // lanes < M: the list so far (linear words)
+    for (u32 base = 0; base < nheads; base += 64) {
+        const u32 k = base + lane;
+        const u32 cv = (k < nheads) ? H[k] : 0;
+        const u32 jb = JMASK - (cv & JMASK);
+        u32 tgt;
+        if constexpr (REGT) tgt = __shfl(t1, (int)(cv ? jb : 0), 64);
+        else tgt = lf.tgt(buf[cv ? jb : 0]);
+        u32 ctax = MCQ_EMPTY;
+        if (cv != 0 && tgt < db.n_targets) ctax = db.tgt2tax[tgt];
+        const u32 cr = lin_rank(opt, tgt);
+        u32 ck = (ctax == MCQ_EMPTY || cr >= opt.keep) ? 0u : lin_word<u32, JB>(cv, cr);
+        u32 lk = Lk, Ntax = MCQ_EMPTY, Nk = 0;
+        for (u32 i = 0; i < M; ++i) {
+            const u32 v = ck > lk ? ck : lk;
+            const u32 m = wave_max_u32(v);
+            if (m == 0) break;
+            const u32 src = (u32)__builtin_ctzll(__ballot(v == m));       // linear words are unique: one winner
+            const u32 wtax = bcast(ck == m ? ctax : Ltax, src);
+            if (lane == i) { Ntax = wtax; Nk = m; }
+            if (ctax == wtax) ck = 0;                                     // every head of the winner's taxon retires
+            if (Ltax == wtax) lk = 0;
+        }
+        Ltax = Ntax; Lk = Nk;
+    }
+    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lk != 0));
+    if (lane < n) {
+        u32 ln = lane;
+        asm volatile("" : "+v"(ln));               // (see topk_fold_write)
+        reinterpret_cast<uint4*>(out.cands)[q * M + ln] = make_uint4(Ltax, Lk >> (JB + 6), 0u, 0u);     // no window ranges after a fold
+    }
+    if (lane == 0) out.ncand[q] = n;
+    return n;
+}
+// lexicographic wave maximum of (hi, lo) pairs: two DPP reductions
+__device__ __forceinline__ unsigned long long wave_max_pair(unsigned long long v) {
+    const u32 hi = wave_max_u32((u32)(v >> 32));
+    const u32 lo = wave_max_u32((u32)(v >> 32) == hi ? (u32)v : 0u);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // Tree fold of the P virtual-rank lists held one entry per lane (list r in lanes [r*seg, r*seg + M)) and the
 // final write of list 0: one round of the tree at a time -- its edges touch disjoint ranks, so every receiver
 // selects from receiver-list ++ sender-list in the same M rounds (positions decide ties).  One wave; mx, wt:
@@ -1516,6 +1590,22 @@ __device__ __forceinline__ bool cells_heavy(u32 key, u32 cs, const u32* occ, con
     return ((multi[bit >> 5] >> (bit & 31)) | (occ[lo >> 5] >> (lo & 31)) | (occ[hi >> 5] >> (hi & 31))) & 1u;
 }
 
+// OptDev::lin: the one list of the two-class forms below sits in lanes [0, M) as (hits << 6 | 63 - rank) << 32 | ~word.  Among
+// the one-hit entries the order is (rank, word): the list is exact when it is full and its last entry has two or more hits or
+// is a rank-0 word below theta (every omitted light word -- one hit, word >= theta -- comes later then).  ~0u: not provable.
+__device__ __forceinline__ u32 two_class_lin_write(const OptDev& opt, const OutDev& out, u32 Ltax, unsigned long long Lw, bool light_omitted,
+                                                   u32 theta, u64 q, u32 lane) {
+    const u32 M = opt.max_cand, hi = (u32)(Lw >> 32);
+    if (light_omitted) {
+        const bool ok = Lw != 0 && ((hi >> 6) >= 2 || ((hi & 63u) == 63u && (u32)~(u32)Lw < theta));
+        if (__ballot(lane == M - 1 && !ok)) return ~0u;
+    }
+    const u32 n = (u32)__builtin_popcountll(__ballot(lane < M && Lw != 0));
+    if (lane < n) reinterpret_cast<uint4*>(out.cands)[q * M + lane] = make_uint4(Ltax, hi >> 6, 0u, 0u);
+    if (lane == 0) out.ncand[q] = n;
+    return n;
+}
+
 // Top lists + fold + write from the heavy run heads (H[0..nheads) packed (hits << JB | JMASK - j), j indexing the sorted
 // distinct heavy words SK) and the light prefix (lkey: this lane's light word, MCQ_EMPTY = none; ascending or not does not
 // matter).  Entries are compared as 64-bit words (hits << 32 | ~word): heavy and light ones in one order.  NC chunks of 64
@@ -1544,6 +1634,28 @@ __device__ __forceinline__ u32 topk_two_class(const DbDev& db, const OptDev& opt
         if (hits && tgt < db.n_targets) tax[c] = db.tgt2tax[tgt];
         rk[c] = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;
         if (hits && tax[c] != MCQ_EMPTY) w[c] = ((unsigned long long)hits << 32) | (u32)~key;
+        if (MCQ_OPT_LIN(opt)) {                                            // one list: (hits, rank, word) in one 64-bit order
+            if (rk[c] >= opt.keep) w[c] = 0;
+            if (w[c] != 0) w[c] = ((unsigned long long)((hits << 6) | (63u - rk[c])) << 32) | (u32)~key;
+        }
+    }
+    if (MCQ_OPT_LIN(opt)) {
+        u32 Ltax = MCQ_EMPTY; unsigned long long Lw = 0;
+        for (u32 i = 0; i < M; ++i) {
+            unsigned long long v = w[0];
+#pragma unroll
+            for (int c = 1; c <= NC; ++c) v = w[c] > v ? w[c] : v;
+            const unsigned long long m = wave_max_pair(v);
+            if (m == 0) break;
+            u32 mt = MCQ_EMPTY;
+#pragma unroll
+            for (int c = 0; c <= NC; ++c) if (w[c] == m) mt = tax[c];
+            const u32 wtax = bcast(mt, (u32)__builtin_ctzll(__ballot(v == m)));           // entries are distinct: one winner
+            if (lane == i) { Ltax = wtax; Lw = m; }
+#pragma unroll
+            for (int c = 0; c <= NC; ++c) if (tax[c] == wtax) w[c] = 0;
+        }
+        return two_class_lin_write(opt, out, Ltax, Lw, light_omitted, theta, q, lane);
     }
     const u32 rl = lane / seg, li = lane - rl * seg;
     const bool lslot = (li < M) && (rl < P);
@@ -1622,6 +1734,24 @@ __device__ __forceinline__ u32 topk_two_class_lds(const DbDev& db, const OptDev&
         }
     }
     wave_sync();
+    if (MCQ_OPT_LIN(opt)) {
+        for (u32 e = lane; e < NE; e += 64) {
+            const unsigned long long w = EW[e];
+            const u32 r = ER[e];
+            EW[e] = (w != 0 && r < opt.keep) ? ((unsigned long long)((((u32)(w >> 32)) << 6) | (63u - r)) << 32) | (u32)w : 0ull;
+        }
+        u32 Ltax = MCQ_EMPTY; unsigned long long Lw = 0;
+        for (u32 i = 0; i < M; ++i) {
+            unsigned long long v = 0; u32 ve = 0;
+            for (u32 e = lane; e < NE; e += 64) { const unsigned long long w = EW[e]; if (w > v) { v = w; ve = e; } }
+            const unsigned long long m = wave_max_pair(v);
+            if (m == 0) break;
+            const u32 wtax = bcast(ET[ve], (u32)__builtin_ctzll(__ballot(v == m)));      // entries are distinct: one winner
+            if (lane == i) { Ltax = wtax; Lw = m; }
+            for (u32 e = lane; e < NE; e += 64) if (ET[e] == wtax) EW[e] = 0;
+        }
+        return two_class_lin_write(opt, out, Ltax, Lw, light_omitted, theta, q, lane);
+    }
     const u32 rl = lane / seg, li = lane - rl * seg;
     const bool lslot = (li < M) && (rl < P);
     u32 Ltax = MCQ_EMPTY; unsigned long long Lw = 0;
@@ -1717,14 +1847,70 @@ __device__ __forceinline__ u32 fold_lists_block(const OptDev& opt, const OutDev&
     return n;
 }
 
-// BIG (a separate instantiation of the workgroup kernels, so that the usual one carries none of it): OptDev::big
-template <class KeyT, class HT, int JB, bool BIG, class LF, class Sync>
+// OptDev::lin in the workgroup kernels: one list (see topk_lin_write).  The workgroup kernels of the query path are
+// instantiated per form (lists / lists in LDS / one selection: they are compiled for 64 VGPRs and 1024 threads, and either
+// form's code inside the other's kernel cost the long reads 8 % in spills whether it ran or not).
+template <class KeyT, class HT, int JB, class LF>
+__device__ __forceinline__ u32 topk_block_lin(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* B, HT* H, u32 T,
+                                              const LF& lf, u64 q, u32 tid, u32 NTB, TopkBlockScratch<HT>* scr) {
+    const u32 M = opt.max_cand;
+    // one list (see topk_lin_write): per round every thread offers its best live head as (hits, 63 - rank, position) in 64
+    // bits, one ds_max per wave; the winner publishes its taxon, every head of that taxon retires
+    constexpr u64 JM = JB >= 32 ? 0xFFFFFFFFull : ((1ull << (JB & 31)) - 1);
+    unsigned long long* gm = reinterpret_cast<unsigned long long*>(scr->fmx);
+    u32 n = 0;
+    for (u32 i = 0; i < M; ++i) {
+        if (tid == 0) gm[0] = 0;
+        __syncthreads();
+        unsigned long long v = 0; u32 vtax = MCQ_EMPTY;
+        for (u32 j = tid; j < T; j += NTB) {
+            const HT hv = H[j];
+            if (hv == 0) continue;
+            const u32 tgt = lf.tgt(B[j]);
+            const u32 tax = tgt < db.n_targets ? db.tgt2tax[tgt] : MCQ_EMPTY;
+            const u32 r = lin_rank(opt, tgt);
+            if (tax == MCQ_EMPTY || r >= opt.keep) { H[j] = 0; continue; }
+            const unsigned long long k = ((unsigned long long)(hv >> JB) << 38) | ((unsigned long long)(63u - r) << 32) | ((unsigned long long)hv & JM);
+            if (k > v) { v = k; vtax = tax; }
+        }
+        const unsigned long long wm = wave_max_pair(v);
+        if ((tid & 63) == 0 && wm != 0) atomicMax(&gm[0], wm);
+        __syncthreads();
+        const unsigned long long m = gm[0];
+        if (m == 0) break;                                      // (uniform)
+        if (v == m) { scr->wt[0] = vtax; scr->ltax[i] = vtax; scr->fwt[i] = (u32)(m >> 38); }       // linear words are unique: one winner
+        __syncthreads();
+        const u32 wtax = scr->wt[0];
+        for (u32 j = tid; j < T; j += NTB) {
+            if (H[j] == 0) continue;
+            if (db.tgt2tax[lf.tgt(B[j])] == wtax) H[j] = 0;
+        }
+        ++n;
+        __syncthreads();
+    }
+    if (tid < n) reinterpret_cast<uint4*>(out.cands)[q * M + tid] = make_uint4(scr->ltax[tid], scr->fwt[tid], 0u, 0u);
+    if (tid == 0) out.ncand[q] = n;
+    return n;
+}
+
+template <class KeyT, class HT, int JB, class LF>
+__device__ __attribute__((noinline)) u32 topk_block_lin_call(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* B, HT* H, u32 T,
+                                                             const LF& lf, u64 q, u32 tid, u32 NTB, TopkBlockScratch<HT>* scr) {
+    return topk_block_lin<KeyT, HT, JB>(db, opt, out, B, H, T, lf, q, tid, NTB, scr);
+}
+
+// FORM (separate instantiations of the workgroup kernels, so that each carries only its own): 0 = the P lists in the lanes
+// of a wave, 1 = OptDev::big, 2 = OptDev::lin.  RTLIN (staged reduce kernels, forms 0 / 1): OptDev::lin is looked at at run
+// time and served by a call.
+template <class KeyT, class HT, int JB, int FORM, bool RTLIN = false, class LF, class Sync>
 __device__ __forceinline__ u32 topk_block(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* B, HT* H,
                                           u32 T, u32 numWindows, const LF& lf, u64 q, u32 tid, u32 NTB,
                                           TopkBlockScratch<HT>* scr, u32* bl, Sync sync) {
+    if constexpr (FORM == 2) return topk_block_lin<KeyT, HT, JB>(db, opt, out, B, H, T, lf, q, tid, NTB, scr);
+    if constexpr (RTLIN) { if (MCQ_OPT_LIN(opt)) return topk_block_lin_call<KeyT, HT, JB>(db, opt, out, B, H, T, lf, q, tid, NTB, scr); }
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
-    constexpr bool big = BIG;
+    constexpr bool big = FORM == 1;
     if (tid < 64) { scr->ltax[tid] = MCQ_EMPTY; scr->lhv[tid] = 0; }
     if constexpr (big) for (u32 i = tid; i < P * M; i += NTB) { bl[i] = 0; bl[MCQ_BIGLIST_MAX + i] = MCQ_EMPTY; }
     for (u32 i = 0; i < M; ++i) {

@@ -73,6 +73,7 @@ struct mcq_db {
     u32 bucket_bytes, slots_per_key;
     u64 n_ext, n_windows;
     u64 bytes;
+    bool seq_taxa;            // tgt2tax holds sequence-level taxa (bit 31; see make_opt)
 };
 
 struct ScratchDev {
@@ -408,6 +409,10 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 template <class LF>
 __device__ __forceinline__ u32 topk_dedup(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* sk, u32* H, u32 D,
                                           u32 numWindows, const LF& lf, u64 q, u32 lane, u32 t1) {
+    if (MCQ_OPT_LIN(opt)) {                                                  // one selection for all ranks (zero words among the heads do no harm)
+        if (D <= 64) return topk_lin_write<u32, 9, LF::lookup>(db, opt, out, sk, H, D, lf, q, lane, t1);
+        return topk_lin_write<u32, 9>(db, opt, out, sk, H, D, lf, q, lane);
+    }
 #ifndef MCQ_TOPK_DEDUP_CHUNKED                                      // tuning knob (A/B)
     if (D > 64) {
         u32 nheads = 0;
@@ -624,7 +629,7 @@ __device__ __forceinline__ u32 heavy_tail(const DbDev& db, const OptDev& opt, co
 template <int E, class LF>
 __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt, const OutDev& out, u32 (&r)[E], u32 T, u32 numWindows,
                                               float word_space, const LF& lf, u64 q, u32 lane, u32* buf, u32* hits) {
-    if (opt.P * opt.max_cand > MCQ_TWO_CLASS_MAX_PM || (opt.hooks & 8u)) return ~0u;
+    if ((opt.lin ? opt.P > 8u : opt.P * opt.max_cand > MCQ_TWO_CLASS_MAX_PM) || (opt.hooks & 8u)) return ~0u;     // (as launch_query's tc_lists)
     const u32 cs = cell_shift(numWindows);
     constexpr u32 LOG = E > 16 ? 16u : MCQ_CELL_LOG;         // each map fills one LDS segment (64 x E words)
     u32* occ = buf; u32* multi = hits;
@@ -720,6 +725,7 @@ __device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, co
         nheads += (u32)__builtin_popcountll(hm);
     }
     wave_sync();
+    if (MCQ_OPT_LIN(opt)) return topk_lin_write<u32, JB>(db, opt, out, buf, hits, nheads, lf, q, lane);
 #ifndef MCQ_TOPK_CHUNKED                                            // tuning knob (A/B): M rounds per 64 heads only
     constexpr int NC = CAP / 128;                                   // register budget: 2 words per 64 heads
     if (nheads <= 64u * NC)
@@ -728,6 +734,14 @@ __device__ __forceinline__ u32 topk_heads(const DbDev& db, const OptDev& opt, co
     if (nheads <= (u32)CAP - 128u)
         return topk_fold_write_lds<JB>(db, opt, out, buf, hits, nheads, numWindows, lf, q, lane, hits + (CAP - 128));
     return topk_fold_write<u32, u32, JB>(db, opt, out, buf, hits, nheads, numWindows, lf, q, lane);
+}
+
+// 64-bit keys: the lists by DPP reductions per rank (topk_fold_write compacts the heads itself), or the one selection
+template <class KeyT, class LF>
+__device__ __forceinline__ u32 topk_heads64(const DbDev& db, const OptDev& opt, const OutDev& out, const KeyT* buf, u32* hits,
+                                            u32 T, u32 numWindows, const LF& lf, u64 q, u32 lane) {
+    if (MCQ_OPT_LIN(opt)) return topk_lin_write<KeyT, 9>(db, opt, out, buf, hits, T, lf, q, lane);
+    return topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
 }
 
 // Top lists when the P lists do not fit the 64 lanes of a wave (NL list registers per lane: the reference's -n 32 / -n 64
@@ -927,7 +941,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
             } else st_cand += nc;
         } else
         if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, lf, q, lane);
-        else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
+        else st_cand += topk_heads64<KeyT>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
         wave_sync();
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, b.nq);
@@ -1203,7 +1217,7 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
 // HT/JB: packed (hits << JB | index) word of the sweep: u32 with JB = 13 when the list fits the workgroup's LDS
 // (<= 8192 entries, hits <= 8192), u64 with JB = 32 in global scratch
 // filled: B[0..T) holds the unsorted list already
-template <class KeyT, class HT, int JB, bool BIG, class LF, class Fill>
+template <class KeyT, class HT, int JB, int BIG, bool RTLIN = false, class LF, class Fill>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
                                            KeyT* B, HT* H, u32 T, u32 numWindows, const LF& lf, u64 q, u32 tid,
                                            const DebugDev& dbg, u32* biglist, Fill fill, bool filled = false) {
@@ -1222,7 +1236,7 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
     }
     __shared__ TopkBlockScratch<HT> s_topk;
     sweep_targets<KeyT, HT, JB>(B, H, T, numWindows, lf, tid, NTB, s_topk.fmx, [] { __syncthreads(); });
-    const u32 n = topk_block<KeyT, HT, JB, BIG>(db, opt, out, B, H, T, numWindows, lf, q, tid, NTB, &s_topk, biglist, [] { __syncthreads(); });
+    const u32 n = topk_block<KeyT, HT, JB, BIG, RTLIN>(db, opt, out, B, H, T, numWindows, lf, q, tid, NTB, &s_topk, biglist, [] { __syncthreads(); });
     if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
     __syncthreads();
 }
@@ -1334,7 +1348,7 @@ __device__ __forceinline__ int block_two_class(const DbDev& db, const OptDev& op
 // allocation: 20 spilled VGPRs around the query loop), which never take it -- so it is a kernel of its own, launched behind the
 // plain one over the same queue: queries with narrow window ranges (numWindows <= 16: short reads and pairs whose lists
 // outgrew the wave stages) are left to it (OptDev::hooks bit 16 tells the plain kernel), everything else to the plain one.
-template <class KeyT, int LCAPB, int NT, bool BIG = false, bool SH = false, bool GW = false, bool TC = false>
+template <class KeyT, int LCAPB, int NT, int BIG = 0, bool SH = false, bool GW = false, bool TC = false>
 __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(DbDev db, BatchDev b, OptDev opt, OutDev out,
                                                       CountersDev* ctr, const u32* ovf_list, ScratchDev sc, DebugDev dbg, ShardDev sh, GwDev gwd) {
     static_assert(LCAPB <= 8192, "packed sweep word: 13 index bits");
@@ -1343,7 +1357,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     __shared__ KeyT s_buf[LCAPB];
     __shared__ u32 s_hits[LCAPB];
     __shared__ u32 s_w[20];
-    __shared__ u32 s_biglist[BIG ? 2 * MCQ_BIGLIST_MAX : 1];       // P lists of M entries when they do not fit a wave (OptDev::big)
+    __shared__ u32 s_biglist[BIG == 1 ? 2 * MCQ_BIGLIST_MAX : 1];  // P lists of M entries when they do not fit a wave (OptDev::big)
     const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 W = db.winlen, S = db.winstride;
@@ -1674,7 +1688,7 @@ __global__ __launch_bounds__(256) void k_reduce_wave(DbDev db, OptDev opt, OutDe
         wave_sync();
         sweep_targets_wave<KeyT>(buf, hits, T, numWindows, lf, lane);
         if constexpr (sizeof(KeyT) == 4) st_cand += topk_heads<9, LCAP>(db, opt, out, reinterpret_cast<const u32*>(buf), hits, T, numWindows, lf, q, lane);
-        else st_cand += topk_fold_write<KeyT, u32, 9>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
+        else st_cand += topk_heads64<KeyT>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
         wave_sync();
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, nq);
@@ -1713,13 +1727,13 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_reduce_wave16(DbDev db,
     if (lane == 0 && st_loc) { atomicAdd(&ctr->n_locations, st_loc); atomicAdd(&ctr->n_cands, st_cand); }
 }
 
-template <class KeyT, int LCAPB, bool BIG = false, bool GW = false>
+template <class KeyT, int LCAPB, int BIG = 0, bool GW = false>
 __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, OutDev out, CountersDev* ctr, const u32* ovf_list,
                                                        ScratchDev sc, const u64* loc_off, const KeyT* locs, const u32* query_len, GwDev gwd) {
     const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db, gwd);
     __shared__ KeyT s_buf[LCAPB];
     __shared__ u32 s_hits[LCAPB];
-    __shared__ u32 s_biglist[BIG ? 2 * MCQ_BIGLIST_MAX : 1];
+    __shared__ u32 s_biglist[BIG == 1 ? 2 * MCQ_BIGLIST_MAX : 1];
     const u32 tid = threadIdx.x;
     KeyT* gbuf = reinterpret_cast<KeyT*>(sc.gbuf + (u64)blockIdx.x * sc.lmax);
     u64* ghits = sc.ghits + (u64)blockIdx.x * sc.lmax;
@@ -1740,8 +1754,8 @@ __global__ __launch_bounds__(1024) void k_reduce_block(DbDev db, OptDev opt, Out
         const u32 numWindows = range_width(query_len[q], opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
         auto fill = [&](KeyT* B) { for (u32 t = tid; t < T; t += 1024) B[t] = locs[b0 + t]; };
         // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
-        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
-        else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
+        if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) block_tail<KeyT, u32, 13, BIG, true>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
+        else                           block_tail<KeyT, u64, 32, BIG, true>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
     }
 }
 
@@ -1987,9 +2001,9 @@ static void fold_schedule(u32 P, std::vector<std::pair<u32, u32>>& sched, std::v
 
 // flags of mcq_query_opts a caller may set (anything else is rejected: a stray bit must not change results silently)
 #ifdef MCQ_PROFILE_HOOKS        // profiling builds only: bits 12..15 = stop the fused kernel after stage 1..5 (results invalid)
-#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16 | MCQ_NO_TWO_CLASS | 0xF000u)
+#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16 | MCQ_NO_TWO_CLASS | MCQ_FOLD_BY_LISTS | 0xF000u)
 #else
-#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16 | MCQ_NO_TWO_CLASS)
+#define MCQ_OPT_FLAGS_KNOWN (MCQ_QUIRK_SEQ_DROP | MCQ_FORCE_BLOCK_PATH | MCQ_FORCE_RAW_SORT | MCQ_NO_WAVE16 | MCQ_NO_TWO_CLASS | MCQ_FOLD_BY_LISTS)
 #endif
 static int force_bits(u32 flags) {
     int f = ((flags & MCQ_FORCE_BLOCK_PATH) ? 1 : 0) | ((flags & MCQ_FORCE_RAW_SORT) ? 2 : 0) | ((flags & MCQ_NO_WAVE16) ? 4 : 0);
@@ -1999,7 +2013,7 @@ static int force_bits(u32 flags) {
     return f;
 }
 
-static int make_opt(const mcq_query_opts* o, OptDev& d) {
+static int make_opt(const mcq_query_opts* o, OptDev& d, const mcq_db* db) {
     if (!o) return fail(MCQ_E_ARG, "opts is null");
     if (o->flags & ~(u32)MCQ_OPT_FLAGS_KNOWN) return fail(MCQ_E_ARG, "unknown bits in mcq_query_opts.flags");
     u32 P = o->emulate_ranks ? o->emulate_ranks : 1;
@@ -2023,6 +2037,18 @@ static int make_opt(const mcq_query_opts* o, OptDev& d) {
     d.n_levels = (u32)level_end.size();
     for (size_t i = 0; i < level_end.size(); ++i) d.level_end[i] = (unsigned char)level_end[i];
     for (size_t i = 0; i < sched.size(); ++i) { d.fold_snd[i] = (unsigned char)sched[i].first; d.fold_rcv[i] = (unsigned char)sched[i].second; }
+    // The P lists and the tree fold as ONE selection (mcq_device.hpp, topk_lin_write) whenever that is the same thing: always
+    // but under MCQ_QUIRK_SEQ_DROP on a table that has sequence-level taxa -- a dropped entry has held a slot of an
+    // intermediate list.  The schedule must concatenate the ranks in ascending order and keep exactly [0, 2^floor(log2 P)).
+    if (P > 1 && !(o->flags & MCQ_FOLD_BY_LISTS) && !(d.quirk_seq_drop && (!db || db->seq_taxa))) {
+        std::vector<std::vector<u32>> seq(P);
+        for (u32 r = 0; r < P; ++r) seq[r].push_back(r);
+        for (auto& e : sched) { auto& a = seq[e.second]; auto& b = seq[e.first]; a.insert(a.end(), b.begin(), b.end()); b.clear(); }
+        u32 keep = 1; while (keep * 2 <= P) keep *= 2;
+        bool ok = seq[0].size() == keep;
+        for (u32 i = 0; ok && i < keep; ++i) ok = seq[0][i] == i;
+        if (ok) { d.lin = 1; d.keep = keep; d.big = 0; d.seg = 64; d.hooks &= ~4u; if (o->flags & MCQ_FORCE_BLOCK_PATH) d.hooks |= 4u; d.n_fold = 0; d.n_levels = 0; }
+    }
     return MCQ_OK;
 }
 
@@ -2140,6 +2166,12 @@ static int create_table(const mcq_db_desc* desc, const std::vector<PartView>& pa
     DBCHK(hipMalloc(&db->tgt2tax, std::max<u32>(1, desc->n_targets) * 4));
     if (desc->n_targets)
         DBCHK(hipMemcpy(db->tgt2tax, desc->tgt2tax, (u64)desc->n_targets * 4, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    {
+        std::vector<u32> t2t(desc->n_targets);
+        if (desc->n_targets) DBCHK(hipMemcpy(t2t.data(), db->tgt2tax, (u64)desc->n_targets * 4, hipMemcpyDeviceToHost));
+        db->seq_taxa = false;
+        for (u32 x : t2t) if (x != MCQ_EMPTY && (x & 0x80000000u)) { db->seq_taxa = true; break; }
+    }
     const u32 bq = bucket_bytes / 16;
     const u64 n_uint4 = nslots * bq;
     hipLaunchKernelGGL(k_fill_slots, dim3((u32)std::min<u64>((n_uint4 + TB - 1) / TB, 1u << 20)), dim3(TB), 0, 0, db->slots, n_uint4);
@@ -2471,7 +2503,8 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     // words, P x M <= 16): range_width = 2 + max(len, insert_size_max) / stride <= MCQ_TC_MAX_WINDOWS  <=>  max(len,
     // insert_size_max) < (MCQ_TC_MAX_WINDOWS - 1) x stride = tc_limit; the queueing kernels count the queries below it.
     const u64 tc_len = (u64)(MCQ_TC_MAX_WINDOWS - 1) * D.tgt_winstride;
-    const bool with_tc = db->d.compact && !od_in.big && !tap && od_in.P * od_in.max_cand <= MCQ_TWO_CLASS_MAX_PM && !(od_in.hooks & 8u) && od_in.insert_size_max < tc_len;
+    const bool tc_lists = od_in.lin ? od_in.P <= 8 : od_in.P * od_in.max_cand <= MCQ_TWO_CLASS_MAX_PM;     // (one list: ~40 / P of the light prefix are rank-0 words)
+    const bool with_tc = db->d.compact && !od_in.big && !tap && tc_lists && !(od_in.hooks & 8u) && od_in.insert_size_max < tc_len;
     OptDev od = od_in;
     od.tc_limit = with_tc ? tc_len : 0;
     // P x M beyond a wave's 64 lanes (the reference's mpiexec -n 32 / -n 64 with -maxcand 4): up to pow2ceil(P) x pow2ceil(M) = 256
@@ -2519,7 +2552,8 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     rc = tm.mark(); if (rc) return rc;
 #define MCQ_LAUNCH_BLOCK(KT, LC, NTH, BIGV, SHV, GWV) hipLaunchKernelGGL((k_query_block<KT, LC, NTH, BIGV, SHV, GWV, false>), dim3(ws->n_block_wgs), dim3(NTH), 0, st, D, b, od, o, ws->ctr, \
                                                              (const u32*)ws->ovf_list, ws->sc, dbg, sh, db->g)
-#define MCQ_LAUNCH_BLOCK2(KT, LC, NTH, SHV, GWV) do { if (od.big) MCQ_LAUNCH_BLOCK(KT, LC, NTH, true, SHV, GWV); else MCQ_LAUNCH_BLOCK(KT, LC, NTH, false, SHV, GWV); } while (0)
+#define MCQ_LAUNCH_BLOCK2(KT, LC, NTH, SHV, GWV) do { if (od.lin) MCQ_LAUNCH_BLOCK(KT, LC, NTH, 2, SHV, GWV); else if (od.big) MCQ_LAUNCH_BLOCK(KT, LC, NTH, 1, SHV, GWV); \
+                                                      else MCQ_LAUNCH_BLOCK(KT, LC, NTH, 0, SHV, GWV); } while (0)
 #define MCQ_LAUNCH_BLOCK32(SHV) do { if (gw) MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, SHV, true); else MCQ_LAUNCH_BLOCK2(u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, SHV, false); } while (0)
     if (db->d.compact) { if (shp) MCQ_LAUNCH_BLOCK32(true); else MCQ_LAUNCH_BLOCK32(false); }
     else               { if (shp) MCQ_LAUNCH_BLOCK2(u64, kLcapBlock, 1024, true, false); else MCQ_LAUNCH_BLOCK2(u64, kLcapBlock, 1024, false, false); }
@@ -2527,10 +2561,12 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
 #undef MCQ_LAUNCH_BLOCK2
 #undef MCQ_LAUNCH_BLOCK
     if (with_tc) {
-#define MCQ_LAUNCH_TC(SHV, GWV) hipLaunchKernelGGL((k_query_block<u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, false, SHV, GWV, true>), dim3(ws->n_block_wgs), dim3(MCQ_BLOCK_NT), 0, st, \
+#define MCQ_LAUNCH_TC1(FORMV, SHV, GWV) hipLaunchKernelGGL((k_query_block<u32, MCQ_BLOCK_LCAP, MCQ_BLOCK_NT, FORMV, SHV, GWV, true>), dim3(ws->n_block_wgs), dim3(MCQ_BLOCK_NT), 0, st, \
                                                    D, b, od, o, ws->ctr, (const u32*)ws->ovf_list, ws->sc, dbg, sh, db->g)
+#define MCQ_LAUNCH_TC(SHV, GWV) do { if (od.lin) MCQ_LAUNCH_TC1(2, SHV, GWV); else MCQ_LAUNCH_TC1(0, SHV, GWV); } while (0)
         if (shp) { if (gw) MCQ_LAUNCH_TC(true, true); else MCQ_LAUNCH_TC(true, false); }
         else     { if (gw) MCQ_LAUNCH_TC(false, true); else MCQ_LAUNCH_TC(false, false); }
+#undef MCQ_LAUNCH_TC1
 #undef MCQ_LAUNCH_TC
     }
     rc = tm.end(); if (rc) return rc;
@@ -2543,7 +2579,7 @@ extern "C" int mcq_query(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, cons
                          mcq_result* out, void* stream) {
     if (!db || !ws || !in || !opt || !out) return fail(MCQ_E_ARG, "null argument");
     OptDev od;
-    int rc = make_opt(opt, od);
+    int rc = make_opt(opt, od, db);
     if (rc) return rc;
     HIPCHK(hipSetDevice(db->device));
     hipStream_t st = (hipStream_t)stream;
@@ -2613,7 +2649,7 @@ extern "C" int mcq_query_pipelined(const mcq_db* db, mcq_ws* ws, const mcq_batch
     if ((in->flags & MCQ_DEVICE_PTRS) || (out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the pipelined call takes host buffers");
     if (in->flags & MCQ_BATCH_RANGES) return fail(MCQ_E_ARG, "MCQ_BATCH_RANGES needs device pointers");
     OptDev od;
-    int rc = make_opt(opt, od); if (rc) return rc;
+    int rc = make_opt(opt, od, db); if (rc) return rc;
     HIPCHK(hipSetDevice(db->device));
     const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
     if (nq > ws->max_queries) return fail(MCQ_E_ARG, "batch has more queries than the workspace allows");
@@ -2700,7 +2736,7 @@ extern "C" int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* 
     if (nbases) HIPCHK(hipMemcpy(ws->d_bases, in->bases, nbases, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ws->d_seq_off, in->seq_off, (in->n_seqs + 1) * 8, hipMemcpyHostToDevice));
     mcq_query_opts qo; qo.max_cand = 1; qo.emulate_ranks = 1; qo.insert_size_max = 0; qo.flags = 0;
-    OptDev od; rc = make_opt(&qo, od); if (rc) return rc;
+    OptDev od; rc = make_opt(&qo, od, db); if (rc) return rc;
     if (in->flags & (MCQ_BATCH_PACKED | MCQ_BATCH_RANGES)) return fail(MCQ_E_ARG, "debug tap takes plain ASCII batches");
     BatchDev b; rc = batch_dev(in, ws->d_bases, ws->d_seq_off, b); if (rc) return rc;
     OutDev o; o.cands = ws->d_cands; o.ncand = ws->d_ncand;
@@ -2841,7 +2877,7 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
     if (!(out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "staged entry points take device pointers");
     if (n_queries > ws->max_queries) return fail(MCQ_E_ARG, "more queries than the workspace allows");
     OptDev od;
-    int rc = make_opt(opt, od);
+    int rc = make_opt(opt, od, db);
     if (rc) return rc;
     HIPCHK(hipSetDevice(db->device));
     hipStream_t st = (hipStream_t)stream;
@@ -2859,9 +2895,9 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
         hipLaunchKernelGGL(k_reduce_wave16<GWV>, dim3(grid_for(ws->cap_reduce16, (n_queries + 3) / 4)), dim3(256), 0, st, db->d, od, o, ws->ctr, \
                            (const u32*)ws->ovf_list, n_queries, loc_off, (const u32*)locs, query_len, db->g); \
         rc = tm.mark(); if (rc) return rc; \
-        if (od.big) hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, true, GWV>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr, \
+        if (od.big) hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, 1, GWV>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr, \
                                        (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len, db->g); \
-        else        hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, false, GWV>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr, \
+        else        hipLaunchKernelGGL((k_reduce_block<u32, kLcapBlock, 0, GWV>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr, \
                                        (const u32*)ws->ovf_list, ws->sc, loc_off, (const u32*)locs, query_len, db->g); } while (0)
     if (db->d.compact) {
         if (db->g.on) MCQ_REDUCE32(true); else MCQ_REDUCE32(false);
@@ -2870,9 +2906,9 @@ extern "C" int mcq_reduce(const mcq_db* db, mcq_ws* ws, uint64_t n_queries, cons
                            n_queries, loc_off, (const u64*)locs, query_len, db->g);
         rc = tm.mark(); if (rc) return rc;
         rc = tm.mark(); if (rc) return rc;
-        if (od.big) hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, true>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+        if (od.big) hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, 1>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
                                        (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len, db->g);
-        else        hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, false>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
+        else        hipLaunchKernelGGL((k_reduce_block<u64, kLcapBlock, 0>), dim3(ws->n_block_wgs), dim3(1024), 0, st, db->d, od, o, ws->ctr,
                                        (const u32*)ws->ovf_list, ws->sc, loc_off, (const u64*)locs, query_len, db->g);
     }
 #undef MCQ_REDUCE32

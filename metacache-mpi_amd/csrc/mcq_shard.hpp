@@ -586,7 +586,7 @@ extern "C" int mcq_shard_query(mcq_shard* c, const mcq_batch* in, const mcq_quer
     if (!(in->flags & MCQ_DEVICE_PTRS) || !(out->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the sharded path takes device pointers");
     if (next && !(next->flags & MCQ_DEVICE_PTRS)) return fail(MCQ_E_ARG, "the sharded path takes device pointers");
     OptDev od;
-    int rc = make_opt(opt, od); if (rc) return rc;
+    int rc = make_opt(opt, od, c->db); if (rc) return rc;
     const u64 nq = in->paired ? in->n_seqs / 2 : in->n_seqs;
     if (nq > c->max_queries || in->n_seqs > c->max_seqs) return fail(MCQ_E_ARG, "batch larger than the context allows");
     const bool exact = (flags & MCQ_SHARD_EXACT) || c->capFx == 0;

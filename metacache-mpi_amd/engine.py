@@ -12,6 +12,7 @@ from .build import lib_path
 
 MCQ_DEVICE_PTRS = 1
 MCQ_QUIRK_SEQ_DROP = 2
+MCQ_FOLD_BY_LISTS = 0x8000
 MCQ_BATCH_RANGES = 8             # seq_off = (begin,end) pairs into `bases` (device pointers only)
 MCQ_BATCH_PACKED = 0x10          # bases in the packed form of mcq_pack_bases (3 bits per base)
 MCQ_FORCE_BLOCK_PATH = 0x100     # debug: send every query down the block-per-query path

@@ -93,6 +93,8 @@ def test_config1_full_batch(c2):
     oc, on = odb.query(rb, ro, False, max_cand=2, emulate_ranks=2, threads=16)
     cands, ncand = ws.query_host(rb, ro, False, max_cand=2, emulate_ranks=2)
     _compare(cands, ncand, oc, on, "configs[1] full batch")
+    cands, ncand = ws.query_host(rb, ro, False, max_cand=2, emulate_ranks=2, flags=eng.MCQ_FOLD_BY_LISTS)
+    _compare(cands, ncand, oc, on, "configs[1] full batch, the two lists and the fold one by one")
     st = ws.sync()
     assert st["n_queries"] == n and st["n_locations"] > 50 * n and st["n_features"] > 30 * n
     assert (on > 0).mean() > 0.99

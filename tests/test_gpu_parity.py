@@ -59,11 +59,21 @@ def test_final_vs_reference_cli(eng, tag, P, block, fmt):
     oc, on = odb.query(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=P, quirk_seq_drop=1)
     _same(cands, ncand, oc, on)
     st = ws.sync()
-    # P x M > 64: the lists take four registers per lane in the first wave stage (32-bit words, up to 256 list slots); only
-    # 64-bit words (and a forced workgroup path) send every query to the workgroup kernel, which keeps the lists in its LDS
+    # A table without sequence-level taxa: the P lists and the tree are one selection (any P x M in the wave stages).  With them,
+    # under the quirk, lists and tree are carried out: P x M > 64 takes four list registers per lane in the first wave stage
+    # (32-bit words, up to 256 list slots), else -- 64-bit words -- every query goes to the workgroup kernel (lists in its LDS)
+    t2t = np.asarray(fx.tgt2tax(), np.uint32)
+    by_lists = bool(np.any((t2t != 0xFFFFFFFF) & (t2t >= 0x80000000)))
     p2 = 1 << (P - 1).bit_length(); m2 = 1 << (fx.maxcand - 1).bit_length()
-    all_block = block is True or (P * fx.maxcand > 64 and (fmt == "loc64" or p2 * m2 > 256))
+    all_block = block is True or (by_lists and P * fx.maxcand > 64 and (fmt == "loc64" or p2 * m2 > 256))
     assert st["n_overflow"] == len(fx.names) if all_block else st["n_overflow"] < len(fx.names)
+    if not by_lists or block is True:
+        return
+    # ... and the same lists without the quirk (one selection) and with MCQ_FOLD_BY_LISTS (lists, no drop) agree with the oracle
+    oc, on = odb.query(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=P, quirk_seq_drop=0)
+    for f2 in (0, eng.MCQ_FOLD_BY_LISTS):
+        cands, ncand = ws.query_host(bases, seq_off, True, max_cand=fx.maxcand, emulate_ranks=P, flags=(flags & ~eng.MCQ_QUIRK_SEQ_DROP) | f2)
+        _same(cands, ncand, oc, on)
 
 
 @pytest.mark.parametrize("tag,P", [("mini", 2), ("mini", 8), ("tie", 4)])

@@ -197,7 +197,7 @@ def test_unknown_query_flag_bits_are_rejected(eng):
     db, _ = _dbs(eng, fx)
     bases, seq_off = orc.pack_reads(fx.interleaved())
     ws = eng.Workspace(db, len(fx.names), len(bases))
-    for bad in (0x1000, 0x2000, 0x8000, 0x10, 0x80000000):
+    for bad in (0x1000, 0x2000, 0x10000, 0x10, 0x80000000):
         with pytest.raises(eng.McqError) as e:
             ws.query_host(bases, seq_off, True, max_cand=2, emulate_ranks=2, flags=bad)
         assert e.value.code == eng.MCQ_E_ARG

@@ -27,6 +27,15 @@ def world():
         odb = orc.OracleDb(keys.cpu().numpy().astype(np.uint32), off.cpu().numpy().astype(np.uint64),
                            locs.cpu().numpy().astype(np.uint64), species.cpu().numpy().astype(np.uint32))
         out[P] = (db, odb)
+        if P == 2:
+            # the same table with every seventh target at sequence level (no taxon of its own: key bit 31, src/candidates.h:240):
+            # under MCQ_QUIRK_SEQ_DROP the P lists and the tree are carried out one by one, without it the one selection
+            sp = species.cpu().numpy().astype(np.uint32)
+            t = np.arange(len(sp), dtype=np.uint32)
+            sq = np.where(t % 7 == 3, np.uint32(0x80000000) | t, sp).astype(np.uint32)
+            out["seq"] = (dbbuild.make_database(keys, off, locs, torch.from_numpy(sq.astype(np.int64)).to(dev)),
+                          orc.OracleDb(keys.cpu().numpy().astype(np.uint32), off.cpu().numpy().astype(np.uint64),
+                                       locs.cpu().numpy().astype(np.uint64), sq))
     return eng, synth, gb, goff, out
 
 
@@ -147,10 +156,34 @@ def test_fold_orders_of_other_rank_counts(world, P, M):
     rb = reads.cpu().numpy().tobytes(); ro = off.cpu().numpy().astype(np.uint64)
     for quirk in (0, 1):
         oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, quirk_seq_drop=quirk, threads=8)
-        for flags in (0, eng.MCQ_FORCE_RAW_SORT):
+        for flags in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_FOLD_BY_LISTS, eng.MCQ_FOLD_BY_LISTS | eng.MCQ_FORCE_RAW_SORT, eng.MCQ_FORCE_BLOCK_PATH):
             cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P,
                                          flags=flags | (eng.MCQ_QUIRK_SEQ_DROP if quirk else 0))
             _compare(cands, ncand, oc, on, "P=%d M=%d quirk=%d flags=%x" % (P, M, quirk, flags))
+
+
+@pytest.mark.parametrize("P,M", [(2, 2), (4, 4), (5, 4), (8, 4), (16, 4), (32, 4), (64, 16)])
+def test_sequence_level_taxa_and_the_wire_quirk(world, P, M):
+    """every seventh target at sequence level: with MCQ_QUIRK_SEQ_DROP a non-root rank's sequence-level entry is dropped when it
+    is sent, after it has held a slot of its rank's list (the lists and the tree level by level); without the flag the whole
+    tree is one selection.  Wave paths, raw sort and the workgroup kernel; 150-base reads and 700-base ones."""
+    eng, synth, gb, goff, dbs = world
+    db, odb = dbs["seq"]
+    for L, n in ((150, 12000), (700, 3000)):
+        reads, off, _ = synth.sample_reads(gb, goff, n, L, 0.01, 0.002, seed=700 + P + L)
+        ws = eng.Workspace(db, n, n * L)
+        rb = reads.cpu().numpy().tobytes(); ro = off.cpu().numpy().astype(np.uint64)
+        differs = 0
+        base = None
+        for quirk in (0, 1):
+            oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, quirk_seq_drop=quirk, threads=8)
+            if quirk == 0: base = (oc.copy(), on.copy())
+            else: differs = int(np.sum(on != base[1])) + int(np.sum(np.any(oc[:, :, :2] != base[0][:, :, :2], axis=(1, 2))))
+            for flags in (0, eng.MCQ_FORCE_RAW_SORT, eng.MCQ_FORCE_BLOCK_PATH, eng.MCQ_FOLD_BY_LISTS):
+                cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P,
+                                             flags=flags | (eng.MCQ_QUIRK_SEQ_DROP if quirk else 0))
+                _compare(cands, ncand, oc, on, "seq-level L=%d P=%d M=%d quirk=%d flags=%x" % (L, P, M, quirk, flags))
+        assert differs > 0, "the quirk changes nothing on this table: the test does not test it"
 
 
 def test_many_strains_cross_every_list_size_boundary():
@@ -371,7 +404,13 @@ def test_two_class_tail_on_chance_hits():
                     cands, ncand = ws.query_host(rb, ro, paired, max_cand=M, emulate_ranks=P, flags=qf)
                     _compare(cands, ncand, oc, on, "two-class dbflags=%x paired=%d P=%d M=%d qf=%x" % (dbflags, paired, P, M, qf))
                     st = ws.sync()
-                    if dbflags != eng.MCQ_DB_LOCS_64 and not qf and P * M <= 16 and not paired:
+                    if dbflags != eng.MCQ_DB_LOCS_64 and not qf and not paired:      # (one list for all ranks: tried up to P = 8)
                         assert st["n_two_class"] > nq // 2, st
-                    if qf or dbflags == eng.MCQ_DB_LOCS_64 or P * M > 16:
+                    if qf or dbflags == eng.MCQ_DB_LOCS_64:
                         assert st["n_two_class"] == 0, st
+                # the P lists and the tree carried out one by one (MCQ_FOLD_BY_LISTS): tried up to P x M = 16
+                cands, ncand = ws.query_host(rb, ro, paired, max_cand=M, emulate_ranks=P, flags=eng.MCQ_FOLD_BY_LISTS)
+                _compare(cands, ncand, oc, on, "two-class by lists dbflags=%x paired=%d P=%d M=%d" % (dbflags, paired, P, M))
+                st = ws.sync()
+                if dbflags == eng.MCQ_DB_LOCS_64 or P * M > 16:
+                    assert st["n_two_class"] == 0, st
