@@ -409,7 +409,9 @@ __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u3
 template <class LF>
 __device__ __forceinline__ u32 topk_dedup(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* sk, u32* H, u32 D,
                                           u32 numWindows, const LF& lf, u64 q, u32 lane, u32 t1) {
-    if (MCQ_OPT_LIN(opt)) {                                                  // one selection for all ranks (zero words among the heads do no harm)
+    // one selection for all ranks (zero words among the heads do no harm).  (Tried: the taxon keys of the <= 64 sorted words
+    // loaded before the sweep and shuffled in here -- one more live register in the 64-VGPR kernel, +1.5 % on configs[1].)
+    if (MCQ_OPT_LIN(opt)) {
         if (D <= 64) return topk_lin_write<u32, 9, LF::lookup>(db, opt, out, sk, H, D, lf, q, lane, t1);
         return topk_lin_write<u32, 9>(db, opt, out, sk, H, D, lf, q, lane);
     }
