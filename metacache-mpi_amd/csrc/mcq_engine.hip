@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <type_traits>
 
 #include "../../include/mcq.h"
 #include "mcq_device.hpp"
@@ -338,22 +339,32 @@ __device__ __forceinline__ void gather_regs(const DbDev& db, KeyT (&r)[E], u32 T
 }
 // The same for up to 128 lists, two per lane (list l of the lane's first feature, list 64 + l of its second):
 // the marks run to 128, and the list's start comes out of the first or the second register set.
+// E > 32 (the 64-register form of the third wave stage): the marks are bytes, so that 4096 of them fit the 2048 words
 template <int E>
 __device__ __forceinline__ void gather_regs2(const DbDev& db, u32 (&r)[E], u32 T, u32 pos0, u32 len0, u64 off0,
                                              u32 pos1, u32 len1, u64 off1, bool two, u32 lane, u32* mark) {
     const u32* __restrict__ locs = static_cast<const u32*>(db.locs);
+    unsigned char* mark8 = reinterpret_cast<unsigned char*>(mark);
+    if constexpr (E > 32) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) mark[e * 64 + lane] = 0;
-    wave_sync();
-    if (len0 > 0) mark[pos0] = lane + 1;
-    if (len1 > 0) mark[pos1] = lane + 65;
+        for (int e = 0; e < E / 4; ++e) mark[e * 64 + lane] = 0;
+        wave_sync();
+        if (len0 > 0) mark8[pos0] = (unsigned char)(lane + 1);
+        if (len1 > 0) mark8[pos1] = (unsigned char)(lane + 65);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) mark[e * 64 + lane] = 0;
+        wave_sync();
+        if (len0 > 0) mark[pos0] = lane + 1;
+        if (len1 > 0) mark[pos1] = lane + 65;
+    }
     wave_sync();
     u32 carry = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const u32 t = e * 64 + lane;
         if (e > 0 && (u32)(e * 64) >= T) { r[e] = MCQ_EMPTY; continue; }      // wave-uniform: nothing up here
-        u32 v = wave_incl_max_dpp(mark[t]);
+        u32 v = wave_incl_max_dpp(E > 32 ? (u32)mark8[t] : mark[t]);
         v = v > carry ? v : carry;
         carry = bcast(v, 63);
         const u32 j = v - 1;                             // v >= 1: the first list starts at slot 0
@@ -642,9 +653,9 @@ __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt
 #pragma unroll
     for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T) cells_insert<LOG>(r[e], cs, occ, multi);
     wave_sync();
-    u32 hm = 0;                                              // bit e: r[e] is heavy
+    typename std::conditional<(E > 32), unsigned long long, u32>::type hm = 0;       // bit e: r[e] is heavy
 #pragma unroll
-    for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T && cells_heavy<LOG>(r[e], cs, occ, multi)) hm |= 1u << e;
+    for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T && cells_heavy<LOG>(r[e], cs, occ, multi)) hm |= (decltype(hm))1 << e;
     wave_sync();                                             // the maps are dead: heavy words -> hits[0..nH), light prefix -> buf[0..nP)
     const float th = word_space * MCQ_TWO_CLASS_EXPECT * __builtin_amdgcn_rcpf((float)T);
     const u32 theta = th >= 4294967040.0f ? 0xFFFFFFFEu : (u32)th;
@@ -654,7 +665,8 @@ __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt
         if ((u32)(e * 64) >= T) break;                       // wave-uniform
         const bool valid = (u32)(e * 64) + lane < T, heavy = (hm >> e) & 1u;
         const u64 bh = __ballot(valid && heavy);
-        if (valid && heavy) hits[nH + lane_rank(bh)] = r[e];
+        if constexpr (E > 32) { if (valid && heavy) { const u32 i = nH + lane_rank(bh); if (i < 2048u) hits[i] = r[e]; } }    // (a segment holds 2048)
+        else if (valid && heavy) hits[nH + lane_rank(bh)] = r[e];
         nH += (u32)__builtin_popcountll(bh);
         nL += (u32)__builtin_popcountll(__ballot(valid && !heavy));
         const bool pre = valid && !heavy && r[e] < theta;
@@ -673,7 +685,7 @@ __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt
     if (nH <= 256) return heavy_tail<4>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
     if (nH <= 512) return heavy_tail<8>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
     if constexpr (E > 8) { if (nH <= 1024) return heavy_tail<16>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits); }
-    if constexpr (E > 16) return heavy_tail<32>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
+    if constexpr (E > 16) { if (nH <= 2048) return heavy_tail<32>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits); }
     return ~1u;
 }
 
@@ -1110,7 +1122,8 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
 // ------------------------------------------------------------------ kernel: wave per query, 32 keys per lane (two-class tail only)
 // Third wave stage, for what a RefSeq-scale table does to short reads: 1025..2048 locations for at most 128 features -- one
 // read in five there -- which until round 3 took a 1024-thread workgroup each (67 us per read; the second wave stage takes
-// 6 us).  It walks the FRONT queue before the workgroup kernels do: an entry it can answer -- few features, a list that fits
+// 6 us); and 2049..4096 locations (one 2 x 150 bp pair in eight there) in 64 registers per lane, same LDS: the gather's marks
+// are bytes, the cell maps keep their 2^16 cells, at most 2048 heavy words.  It walks the FRONT queue before the workgroup kernels do: an entry it can answer -- few features, a list that fits
 // 32 registers per lane, lists provable by the two-class tail -- is answered and overwritten with the empty marker; every
 // other entry stays for the workgroup kernels, and the narrow ones among those are counted for them (see k_query_block).
 // Sketch and probe again (no hand-over: ~8 us of the ~50), two features per lane as in the second stage.  16 KB of LDS per
@@ -1118,10 +1131,15 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
 template <bool SH = false, bool GW = false, int BSH = -1>
 __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, OptDev opt, OutDev out, CountersDev* ctr, u32* ovf_list,
                                                          ShardDev sh, GwDev gwd) {
+    constexpr int LSEG = 2048;                         // words per LDS segment
+#ifdef MCQ_WAVE32_ONLY                                 // tuning knob (A/B): without the 64-register form
     constexpr int LCAP = 2048;
+#else
+    constexpr int LCAP = 4096;
+#endif
     const typename LocOf<u32, GW>::type lf = loc_format<u32, GW>(db, gwd);
-    __shared__ u32 s_buf[4][LCAP];
-    __shared__ u32 s_hits[4][LCAP];
+    __shared__ u32 s_buf[4][LSEG];
+    __shared__ u32 s_hits[4][LSEG];
     const u32 lane = threadIdx.x & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     u32* buf = s_buf[wave];
@@ -1171,9 +1189,20 @@ __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, O
         if (T > (u32)LCAP || T == 0) { st_narrow += narrow; continue; }          // (an empty list: the workgroup kernel writes the zero)
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        u32 r[32];
-        gather_regs2<32>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, hits);
-        const u32 n2 = two_class_tail<32>(db, opt, out, r, T, numWindows, word_space, lf, q, lane, buf, hits);
+        u32 n2;
+        if (T <= 2048u) {                               // wave-uniform
+            u32 r[32];
+            gather_regs2<32>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, hits);
+            n2 = two_class_tail<32>(db, opt, out, r, T, numWindows, word_space, lf, q, lane, buf, hits);
+        } else {
+#ifndef MCQ_WAVE32_ONLY
+            u32 r[64];
+            gather_regs2<64>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, hits);
+            n2 = two_class_tail<64>(db, opt, out, r, T, numWindows, word_space, lf, q, lane, buf, hits);
+#else
+            n2 = ~0u;
+#endif
+        }
         wave_sync();
         if (n2 >= ~1u) { st_narrow += narrow; continue; }             // not taken / not provable: the entry stays
         if (lane == 0) ovf_list[slot] = MCQ_EMPTY;                    // answered
