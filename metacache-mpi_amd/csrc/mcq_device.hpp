@@ -167,6 +167,8 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     // counters above are hammered by atomics, and a load from their line queues behind them.)
     unsigned long long pad_[23];
     unsigned long long* probe_buf;
+    unsigned long long* probe_front;  // the same for FRONT-queue slots of queries with <= 64 features (third wave stage); a lane without
+                                      // a feature holds 0xFFFF
 };
 static_assert(offsetof(CountersDev, probe_buf) == 256, "probe_buf sits 256 bytes into the block");
 #define MCQ_CTR_ZEROED offsetof(CountersDev, probe_buf)

@@ -97,7 +97,7 @@ struct mcq_ws {
     CountersDev* ctr;         // device
     CountersDev* ctr_host;    // pinned
     u32* ovf_list;            // [ovf_capacity(max_queries)]
-    unsigned long long* probe_buf;   // [(max_queries + MCQ_OVF_TAIL) x 64], see CountersDev
+    unsigned long long* probe_buf;   // [2 x (max_queries + MCQ_OVF_TAIL) x 64]: rows of the back queue, then of the front queue; see CountersDev
     ScratchDev sc;
     int n_block_wgs;
     u32 cap_wave, cap_wave16, cap_reduce16, cap_wave32, cap_wave_many;   // resident workgroups of the wave-per-query kernels on this device
@@ -880,6 +880,15 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
                 if constexpr (!SH) st_feat += nfeat;
                 st_hit += (u32)__builtin_popcountll(__ballot(len > 0));     // counted here, not in the second stage
             }
+#ifndef MCQ_NO_FRONT_HANDOVER                          // tuning knob (A/B)
+            else if constexpr (sizeof(KeyT) == 4 && !SH) {
+                if (!g.ovf && opt.tc_limit != 0) {     // a front-queue entry the third wave stage will look at: the same, by front slot
+                    wave_sync();
+                    const u32 slot = s_ovf[wave][0] - 1;
+                    ctr->probe_front[(u64)slot * 64 + lane] = lane < nfeat ? ((off << 16) | len) : 0xFFFFull;
+                }
+            }
+#endif
 #endif
             continue;
         }
@@ -1092,6 +1101,11 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
                         fq_next = bcast(base, 0); fq_left = MCQ_OVF_CHUNK;
                     }
                     if (lane == 0) ovf_list[fq_next] = q32;
+#ifndef MCQ_NO_FRONT_HANDOVER
+                    // <= 64 features: the third wave stage reads every such front entry's probe results from the slot's row
+                    // (bit 63: features and hit features are counted already -- the first stage did that at its hand-over)
+                    if constexpr (!SH) { if (!g.wide) ctr->probe_front[(u64)fq_next * 64 + lane] = (1ull << 63) | (off0 << 16) | len0; }
+#endif
                     ++fq_next; --fq_left;
                     wave_sync();
                     continue;
@@ -1130,7 +1144,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
 // wave, two waves per SIMD.  Launched only when the two-class tail is (32-bit words, P x M <= 16).
 template <bool SH = false, bool GW = false, int BSH = -1>
 __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, OptDev opt, OutDev out, CountersDev* ctr, u32* ovf_list,
-                                                         ShardDev sh, GwDev gwd) {
+                                                         int force_block, ShardDev sh, GwDev gwd) {
     constexpr int LSEG = 2048;                         // words per LDS segment
 #ifdef MCQ_WAVE32_ONLY                                 // tuning knob (A/B): without the 64-register form
     constexpr int LCAP = 2048;
@@ -1157,11 +1171,11 @@ __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, O
         const u32 q32 = ovf_list[slot];
         if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
         const u64 q = q32;
-        const ReadGeom g = read_geom(db, b, q, 0);
+        const ReadGeom g = read_geom(db, b, q, force_block);          // (as the first stage saw it)
         const u32 narrow = g.qlen < opt.tc_limit ? 1u : 0u;
         if (g.ovf && !g.wide) { st_narrow += narrow; continue; }      // more than 128 features: a workgroup's
         u32 nfeat = 0;
-        bool two = false;
+        bool two = false, counted = false;
         u64 off0 = 0, off1 = 0; u32 len0 = 0, len1 = 0;
         if constexpr (SH) {
             nfeat = (g.nw1 + g.nw2) * db.s;
@@ -1169,7 +1183,17 @@ __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, O
             const u64 sb = sh.win_off[b.paired ? 2 * q : q] * db.s;
             if (lane < nfeat) shard_fetch(sh, sb + lane, off0, len0);
             if (two && 64 + lane < nfeat) shard_fetch(sh, sb + 64 + lane, off1, len1);
-        } else {
+        }
+#ifndef MCQ_NO_FRONT_HANDOVER
+        else if (!g.ovf) {                             // <= 64 features: the first stage left its probe results in the slot's row
+            const u64 pw = ctr->probe_front[(u64)slot * 64 + lane];
+            const u32 l = (u32)(pw & 0xFFFFu);
+            nfeat = (u32)__builtin_popcountll(__ballot(l != 0xFFFFu));
+            len0 = l == 0xFFFFu ? 0u : l; off0 = (pw << 1) >> 17;
+            counted = __ballot((pw >> 63) != 0) != 0;             // handed on by the second stage: counted by the first one
+        }
+#endif
+        else {
             for (u32 w = 0; w < g.nw1 + g.nw2; ++w) {
                 u64 at; u32 wl;
                 window_span(db, g, w, at, wl);
@@ -1206,8 +1230,10 @@ __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, O
         wave_sync();
         if (n2 >= ~1u) { st_narrow += narrow; continue; }             // not taken / not provable: the entry stays
         if (lane == 0) ovf_list[slot] = MCQ_EMPTY;                    // answered
-        if constexpr (!SH) st_feat += nfeat;
-        st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
+        if (!counted) {
+            if constexpr (!SH) st_feat += nfeat;
+            st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
+        }
         st_loc += T; st_cand += n2; st_two += 1;
     }
     if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
@@ -2379,9 +2405,14 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     WSCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
     WSCHK(hipHostMalloc(&ws->ctr_host, sizeof(CountersDev)));
     WSCHK(hipMalloc(&ws->ovf_list, ovf_capacity(max_queries) * 4));
-    WSCHK(hipMalloc(&ws->probe_buf, (max_queries + (u64)MCQ_OVF_TAIL) * 64 * 8));
+    WSCHK(hipMalloc(&ws->probe_buf, 2 * (max_queries + (u64)MCQ_OVF_TAIL) * 64 * 8));       // back-queue rows, then front-queue rows
     WSCHK(hipMemset(ws->ctr, 0, sizeof(CountersDev)));
     WSCHK(hipMemcpy(&ws->ctr->probe_buf, &ws->probe_buf, sizeof(ws->probe_buf), hipMemcpyHostToDevice));
+    WSCHK(hipMemset(ws->probe_buf, 0, 2 * (max_queries + (u64)MCQ_OVF_TAIL) * 64 * 8));        // (a row never written reads as 64 empty lists)
+    {
+        unsigned long long* front = ws->probe_buf + (max_queries + (u64)MCQ_OVF_TAIL) * 64;       // (first-stage pushes stay below max_queries + MCQ_OVF_TAIL)
+        WSCHK(hipMemcpy(&ws->ctr->probe_front, &front, sizeof(front), hipMemcpyHostToDevice));
+    }
     WSCHK(hipMalloc(&ws->sc.feat, nb * ws->sc.fmax * 4));
     WSCHK(hipMalloc(&ws->sc.fpos, nb * ((u64)ws->sc.fmax + 1) * 4));
     WSCHK(hipMalloc(&ws->sc.foff, nb * ws->sc.fmax * 8));
@@ -2574,7 +2605,7 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
     }
     if (with_tc) {          // third wave stage: front-queue entries of up to 2048 locations (see k_query_wave32); counts the narrow ones it leaves
         const dim3 g32(grid_for(ws->cap_wave32, want));
-#define MCQ_LAUNCH_WAVE32(SHV, GWV, BSHV) hipLaunchKernelGGL((k_query_wave32<SHV, GWV, BSHV>), g32, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, sh, db->g)
+#define MCQ_LAUNCH_WAVE32(SHV, GWV, BSHV) hipLaunchKernelGGL((k_query_wave32<SHV, GWV, BSHV>), g32, dim3(256), 0, st, D, b, od, o, ws->ctr, ws->ovf_list, force_block, sh, db->g)
         if (shp)     { if (gw) MCQ_LAUNCH_WAVE32(true, true, -1); else MCQ_LAUNCH_WAVE32(true, false, -1); }
         else if (gw) { if (b64) MCQ_LAUNCH_WAVE32(false, true, 2); else MCQ_LAUNCH_WAVE32(false, true, 0); }
         else         { if (b64) MCQ_LAUNCH_WAVE32(false, false, 2); else MCQ_LAUNCH_WAVE32(false, false, 0); }

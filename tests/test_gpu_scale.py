@@ -393,6 +393,7 @@ def test_two_class_tail_on_chance_hits():
     t2t = (np.arange(n_tgt) // 3).astype(np.uint32)
     rb, ro = orc.pack_reads([s.encode() for s in seqs])
     odb = orc.OracleDb(keys, off, locs, t2t)
+    retries = 0
     for dbflags in (0, eng.MCQ_DB_LOCS_GW, eng.MCQ_DB_LOCS_64):
         db = eng.Database(keys, off, locs, t2t, flags=dbflags)
         for paired in (False, True):
@@ -404,6 +405,7 @@ def test_two_class_tail_on_chance_hits():
                     cands, ncand = ws.query_host(rb, ro, paired, max_cand=M, emulate_ranks=P, flags=qf)
                     _compare(cands, ncand, oc, on, "two-class dbflags=%x paired=%d P=%d M=%d qf=%x" % (dbflags, paired, P, M, qf))
                     st = ws.sync()
+                    retries += st["n_two_class_retry"]
                     if dbflags != eng.MCQ_DB_LOCS_64 and not qf and not paired:      # (one list for all ranks: tried up to P = 8)
                         assert st["n_two_class"] > nq // 2, st
                     if qf or dbflags == eng.MCQ_DB_LOCS_64:
@@ -414,3 +416,6 @@ def test_two_class_tail_on_chance_hits():
                 st = ws.sync()
                 if dbflags == eng.MCQ_DB_LOCS_64 or P * M > 16:
                     assert st["n_two_class"] == 0, st
+    # lists the second wave stage could not prove go on to the front queue with their probe results (the third stage reads
+    # them from the slot's row): that hand-over must have happened here
+    assert retries > 0
