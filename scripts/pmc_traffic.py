@@ -11,7 +11,12 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 tag, workload, kprefix, reads = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-rows = [r for r in csv.DictReader(l for l in open(os.path.join(ROOT, "profiles", tag + "_pmc.csv")) if not l.startswith("#"))]
+rows = []                  # (kernel names hold commas and are not quoted: the three value columns are split off from the right)
+for l in open(os.path.join(ROOT, "profiles", tag + "_pmc.csv")):
+    if l.startswith("#") or l.startswith("Kernel,"):
+        continue
+    k_, c_, d_, m_ = l.rstrip("\n").rsplit(",", 3)
+    rows.append({"Kernel": k_.strip('"'), "Counter": c_, "Dispatches": d_, "MeanPerDispatch": m_})
 kernels = sorted({r["Kernel"] for r in rows if r["Kernel"].startswith(kprefix)})
 if not kernels:
     sys.exit("no kernel starting with %r in profiles/%s_pmc.csv" % (kprefix, tag))
