@@ -315,7 +315,7 @@ template <class KeyT, class LF> __device__ __forceinline__ u64 key_expand(KeyT k
 // in `mark` (64 * E words of the wave's LDS), an inclusive prefix maximum over the slots spreads the marks
 // to the right (6 DPP steps per register instead of a 6-step shuffle search per element).
 template <class KeyT, int E>
-__device__ __forceinline__ void gather_regs(const DbDev& db, KeyT (&r)[E], u32 T, u32 pos, u32 len, u64 off, u32 lane, u32* mark) {
+__device__ __forceinline__ void gather_regs_marks(const DbDev& db, KeyT (&r)[E], u32 T, u32 pos, u32 len, u64 off, u32 lane, u32* mark) {
     const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
 #pragma unroll
     for (int e = 0; e < E; ++e) mark[e * 64 + lane] = 0;
@@ -341,7 +341,7 @@ __device__ __forceinline__ void gather_regs(const DbDev& db, KeyT (&r)[E], u32 T
 // the marks run to 128, and the list's start comes out of the first or the second register set.
 // E > 32 (the 64-register form of the third wave stage): the marks are bytes, so that 4096 of them fit the 2048 words
 template <int E>
-__device__ __forceinline__ void gather_regs2(const DbDev& db, u32 (&r)[E], u32 T, u32 pos0, u32 len0, u64 off0,
+__device__ __forceinline__ void gather_regs2_marks(const DbDev& db, u32 (&r)[E], u32 T, u32 pos0, u32 len0, u64 off0,
                                              u32 pos1, u32 len1, u64 off1, bool two, u32 lane, u32* mark) {
     const u32* __restrict__ locs = static_cast<const u32*>(db.locs);
     unsigned char* mark8 = reinterpret_cast<unsigned char*>(mark);
@@ -380,6 +380,83 @@ __device__ __forceinline__ void gather_regs2(const DbDev& db, u32 (&r)[E], u32 T
     }
     wave_sync();                                         // mark[] is the caller's again
 }
+// r03: the list starts as a BITMAP instead (bit t = a list starts at element t; one ds_or per non-empty list), and the
+// non-empty lists' (offset - start) compacted into a small table: row e takes its 64 bits from a lane of the register that
+// holds the bitmap (v_readlane with a constant lane), the list of element t is the number of starts at or before t -- two
+// v_mbcnt on the row's bits plus the starts of the rows before (a scalar popcount) -- and one ds_read_b64 fetches that list's
+// offset.  ~16 instructions per register row instead of ~40 (12 of them a DPP chain with wait states, three shuffles),
+// and the rows no longer depend on one another.  mark: 64 + 128 words (2E <= 64 bitmap words, then the table, 8-B aligned).
+#ifdef MCQ_GATHER_MARKS          // tuning knob (A/B): the prefix-maximum form
+#define gather_regs gather_regs_marks
+#define gather_regs2 gather_regs2_marks
+#else
+template <class KeyT, int E>
+__device__ __forceinline__ void gather_regs(const DbDev& db, KeyT (&r)[E], u32 T, u32 pos, u32 len, u64 off, u32 lane, u32* mark) {
+    static_assert(E <= 32, "the bitmap of one register");
+    const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
+    u32* bm = mark;
+    unsigned long long* fb = reinterpret_cast<unsigned long long*>(mark + 64);
+    bm[lane] = 0;
+    wave_sync();
+    const bool has = len > 0;
+    const u64 hm = __ballot(has);
+    if (has) { atomicOr(&bm[pos >> 5], 1u << (pos & 31)); fb[lane_rank(hm)] = off - pos; }
+    wave_sync();
+    const u32 bw = bm[lane];                             // word l of the bitmap in lane l
+    u32 before = 0;                                      // starts in the rows before (wave-uniform)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 t = e * 64 + lane;
+        r[e] = key_pad<KeyT>();
+        if (e > 0 && (u32)(e * 64) >= T) continue;       // wave-uniform: nothing up here
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)bw, 2 * e), hi = (u32)__builtin_amdgcn_readlane((int)bw, 2 * e + 1);
+        const u32 cnt = before + __builtin_amdgcn_mbcnt_hi(hi >> 1, __builtin_amdgcn_mbcnt_lo((lo >> 1) | (hi << 31), 0u)) + (lo & 1u);
+        before += (u32)__builtin_popcount(lo) + (u32)__builtin_popcount(hi);
+        const unsigned long long base = fb[(cnt - 1u) & 63u];          // cnt >= 1: the first list starts at element 0
+        if (t < T) r[e] = locs[base + t];
+    }
+    wave_sync();                                         // mark[] is the caller's again
+}
+// The same for up to 128 lists, two per lane (list l of the lane's first feature, list 64 + l of its second); E <= 64:
+// 128 bitmap words in two registers, the table behind them (mark: 128 + 256 words)
+template <int E>
+__device__ __forceinline__ void gather_regs2(const DbDev& db, u32 (&r)[E], u32 T, u32 pos0, u32 len0, u64 off0,
+                                             u32 pos1, u32 len1, u64 off1, bool two, u32 lane, u32* mark) {
+#ifndef MCQ_GATHER_SB            // tuning knob (A/B): the bitmap form for 32 and 64 registers too, with scheduling barriers every 8 rows
+    // (32 / 64 registers per lane: with independent rows the compiler hoists their table reads and loads and spills 100
+    // VGPRs in k_query_wave32 -- RefSeq-scale pairs 13.3 -> 13.9 ms; the prefix-maximum form's carry keeps them in order)
+    if constexpr (E >= 32) { gather_regs2_marks<E>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, mark); return; }
+#endif
+    const u32* __restrict__ locs = static_cast<const u32*>(db.locs);
+    u32* bm = mark;
+    unsigned long long* fb = reinterpret_cast<unsigned long long*>(mark + 128);
+    bm[lane] = 0; bm[64 + lane] = 0;
+    wave_sync();
+    const u64 m0 = __ballot(len0 > 0), m1 = __ballot(len1 > 0);
+    const u32 n0 = (u32)__builtin_popcountll(m0);
+    if (len0 > 0) { atomicOr(&bm[pos0 >> 5], 1u << (pos0 & 31)); fb[lane_rank(m0)] = off0 - pos0; }
+    if (len1 > 0) { atomicOr(&bm[pos1 >> 5], 1u << (pos1 & 31)); fb[n0 + lane_rank(m1)] = off1 - pos1; }
+    wave_sync();
+    const u32 bw0 = bm[lane], bw1 = E > 32 ? bm[64 + lane] : 0u;
+    u32 before = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 t = e * 64 + lane;
+        r[e] = MCQ_EMPTY;
+        if (e > 0 && (u32)(e * 64) >= T) continue;       // wave-uniform: nothing up here
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)(e < 32 ? bw0 : bw1), (2 * e) & 63);
+        const u32 hi = (u32)__builtin_amdgcn_readlane((int)(e < 32 ? bw0 : bw1), (2 * e + 1) & 63);
+        const u32 cnt = before + __builtin_amdgcn_mbcnt_hi(hi >> 1, __builtin_amdgcn_mbcnt_lo((lo >> 1) | (hi << 31), 0u)) + (lo & 1u);
+        before += (u32)__builtin_popcount(lo) + (u32)__builtin_popcount(hi);
+        const unsigned long long base = fb[(cnt - 1u) & 127u];
+        if (t < T) r[e] = locs[base + t];
+#ifdef MCQ_GATHER_SB
+        if constexpr (E >= 32) { if ((e & 7) == 7) __builtin_amdgcn_sched_barrier(0); }
+#endif
+    }
+    wave_sync();                                         // mark[] is the caller's again
+}
+#endif
 // ... sort them there and leave the sorted keys in the wave's LDS segment for the sweep.
 template <class KeyT, int E>
 __device__ __forceinline__ void gather_sort_store(const DbDev& db, KeyT* buf, u32* hits, u32 T, u32 pos, u32 len, u64 off, u32 lane, int stop) {
@@ -668,12 +745,12 @@ __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt
         if constexpr (E > 32) { if (valid && heavy) { const u32 i = nH + lane_rank(bh); if (i < 2048u) hits[i] = r[e]; } }    // (a segment holds 2048)
         else if (valid && heavy) hits[nH + lane_rank(bh)] = r[e];
         nH += (u32)__builtin_popcountll(bh);
-        nL += (u32)__builtin_popcountll(__ballot(valid && !heavy));
         const bool pre = valid && !heavy && r[e] < theta;
         const u64 bp = __ballot(pre);
         if (pre) { const u32 i = nP + lane_rank(bp); if (i < 64) buf[i] = r[e]; }
         nP += (u32)__builtin_popcountll(bp);
     }
+    nL = T - nH;                                             // (every word is one or the other)
     wave_sync();
     if (nP > 64) return ~0u;                                 // theta too generous for this read (words far from uniform)
     const u32 safe = bcast(r[0], 0);                         // any real word (T >= 1)
