@@ -148,12 +148,15 @@ typedef struct {
                                    src/query_options.cpp:176-178, is not offered: past 16 entries its std::sort
                                    is an unstable introsort, so results stop being defined by the inputs.)   */
     uint32_t emulate_ranks;     /* P of the reference run to match (fold order of src/querying.h:867-1073),
-                                   1..64; 1 = single list, no fold.  While pow2ceil(P) x max_cand <= 64 the P lists
-                                   live in the lanes of one wave; beyond that (the reference's scripted -n 32 / -n 64
-                                   with -maxcand 4, script/ft/QueryGeneric_FT.sh:115) they live in the LDS of the
-                                   workgroup kernel, which then takes every query: same results, ~5x slower    */
+                                   1..64; 1 = single list, no fold.  The P lists and their fold are computed as ONE
+                                   bounded selection in the order (hits, rank, position) -- the same list,
+                                   at the same cost for every P and max_cand (the reference's scripted -n 32 / -n 64 with
+                                   -maxcand 4, script/ft/QueryGeneric_FT.sh:115, included).  Only MCQ_QUIRK_SEQ_DROP on a
+                                   table with sequence-level taxa carries the lists out: in the lanes of a wave while
+                                   pow2ceil(P) x max_cand <= 64, in four registers per lane up to 256 list slots, beyond
+                                   that in the LDS of the workgroup kernel (every query, several times slower)          */
     uint64_t insert_size_max;   /* insertSizeMax                                         */
-    uint32_t flags;             /* MCQ_QUIRK_SEQ_DROP and the MCQ_FORCE_* / MCQ_NO_WAVE16 / MCQ_NO_TWO_CLASS test hooks; any other
+    uint32_t flags;             /* MCQ_QUIRK_SEQ_DROP and the MCQ_FORCE_* / MCQ_NO_WAVE16 / MCQ_NO_TWO_CLASS / MCQ_FOLD_BY_LISTS test hooks; any other
                                    bit is rejected with MCQ_E_ARG                         */
 } mcq_query_opts;
 
