@@ -1509,9 +1509,16 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     const bool tc_worth = ctr->n_narrow >= MCQ_TC_MIN_QUEUED;
     if (TC && !tc_worth) return;
 
-    for (u32 it = blockIdx.x; it < n_ovf; it += gridDim.x) {
-        const u32 q32 = ovf_list[ovf_visit(it, n_ovf)];
-        if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation (uniform over the workgroup)
+    // The queue entries of this workgroup's next 64 visits are fetched at once: most entries are empty when the wave stages
+    // have answered them (a RefSeq-scale batch of pairs: 99 %), and one dependent load per visit was 0.5 ms per kernel there.
+    __shared__ u32 s_q[64];
+    for (u32 it0 = blockIdx.x; it0 < n_ovf; it0 += gridDim.x * 64u) {
+    __syncthreads();                                   // (the entries of the visits before are consumed)
+    if (tid < 64) { const u64 it = (u64)it0 + (u64)tid * gridDim.x; s_q[tid] = it < n_ovf ? ovf_list[ovf_visit((u32)it, n_ovf)] : MCQ_EMPTY; }
+    __syncthreads();
+    for (u32 k = 0; k < 64; ++k) {
+        const u32 q32 = s_q[k];
+        if (q32 == MCQ_EMPTY) continue;                // answered, or the unused tail of a wave's reservation (uniform over the workgroup)
         const u64 q = q32;
         const u64 a = b.paired ? 2 * q : q;
         u64 o0, e0, o1, e1;
@@ -1642,6 +1649,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             if (tc != TC_DONE) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill, tc == TC_HEAVY);
         }
         else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
+    }
     }
 }
 
