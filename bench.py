@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1 << 20, help="reads per step per GPU")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--species", type=int, default=50, help="species of the database (x strains genomes); at N > 1 per GPU unless --db-fixed")
+    ap.add_argument("--species", type=int, default=None, help="species of the database (x strains genomes; default 50, with --refseq-scale 2600); at N > 1 per GPU unless --db-fixed")
     ap.add_argument("--strains", type=int, default=10)
     ap.add_argument("--genome-min", type=int, default=2_000_000)
     ap.add_argument("--genome-max", type=int, default=6_000_000)
@@ -78,16 +78,24 @@ def parse():
                     help="location words of the table: auto = what mcq_db_create picks (32-bit bit fields if they fit, else the 32-bit "
                          "global window index, else 64 bit); gw / fields64 force a form (fields32 = auto, fails the run if it does not fit)")
     ap.add_argument("--bucket-bytes", type=int, default=0, choices=[0, 16, 64], help="table layout: 0 = per table (mean list length), 16 / 64 force it")
-    ap.add_argument("--contigs", type=int, default=1, help="split every genome into this many targets (RefSeq assemblies: many sequences per genome)")
+    ap.add_argument("--contigs", type=int, default=None, help="split every genome into this many targets (RefSeq assemblies: many sequences per genome; default 1, with --refseq-scale 2)")
     ap.add_argument("--refseq-scale", action="store_true",
                     help="BASELINE configs[2] shape on ONE GPU: --species 2600 x 10 strains (104 Gbp), --contigs 2 (52 001 targets), one 16 Mbp "
                          "chromosome, -remove-overpopulated-features, table built in parts; any of these can still be given explicitly")
     ap.add_argument("--remove-overpopulated", action="store_true", help="build option -remove-overpopulated-features (src/mode_build.cpp:847-1074)")
     ap.add_argument("--build-parts", action="store_true", help="build the table in feature-hash parts (mcq_build_parts) whatever its size")
-    ap.add_argument("--long-genome-mbp", type=float, default=0.0,
+    ap.add_argument("--long-genome-mbp", type=float, default=None,
                     help="add one genome of this many Mbp (>= 14.9 Mbp = 2^17 windows: with >= 2^15 targets the (target, window) "
                          "fields no longer fit 32 bits, as on RefSeq)")
-    return ap.parse_args()
+    ap.add_argument("--no-refseq-block", action="store_true",
+                    help="default N = 1 line: skip the `refseq_scale` side block (the RefSeq-scale table built and timed in the same run, ~80 s)")
+    a = ap.parse_args()
+    # defaults that depend on --refseq-scale (explicit values win, however they were abbreviated)
+    if a.species is None: a.species = 2600 if a.refseq_scale else 50
+    if a.contigs is None: a.contigs = 2 if a.refseq_scale else 1
+    if a.long_genome_mbp is None: a.long_genome_mbp = 16.0 if a.refseq_scale else 0.0
+    if a.refseq_scale: a.remove_overpopulated = True
+    return a
 
 
 def arm_watchdog(seconds, last_words, exit_code):
@@ -133,12 +141,6 @@ def algorithmic_bytes(n_bases, st):
 
 def main():
     a = parse()
-    if a.refseq_scale:          # defaults of the RefSeq-scale shape (explicit arguments win)
-        argv = " ".join(sys.argv[1:])
-        if "--species" not in argv: a.species = 2600
-        if "--contigs" not in argv: a.contigs = 2
-        if "--long-genome-mbp" not in argv: a.long_genome_mbp = 16.0
-        a.remove_overpopulated = True
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(spawn_ranks(a))
     import torch
@@ -195,89 +197,111 @@ def main():
     with_fused = mode != "sharded" or not a.no_replicas_leg
     n_species = a.species * (world if (world > 1 and not a.db_fixed) else 1)
 
-    # ---- database: same seeded genomes on every rank; each rank keeps its hash-range shard
-    t_setup = time.time()
-    if a.refseq_scale:
-        # BASELINE configs[2] shape on one GPU: >= 100 Gbp, >= 2^15 sequences, one chromosome of > 2^17 windows
-        gen_bases, gen_off, species = synth.make_genomes_big(n_species, a.strains, a.genome_min, a.genome_max, a.divergence, seed=3,
-                                                             device=dev, extra_genome=int(a.long_genome_mbp * 1e6))
-    else:
-        gen_bases, gen_off, species = synth.make_genomes(n_species, a.strains, a.genome_min, a.genome_max,
-                                                         a.divergence, seed=3, device=dev)
-        if a.long_genome_mbp > 0:
-            gen_bases, gen_off, species = synth.add_genome(gen_bases, gen_off, species, int(a.long_genome_mbp * 1e6), seed=4)
-    if a.contigs > 1:
-        gen_off, species = synth.split_targets(gen_off, species, a.contigs, keep_last_whole=a.long_genome_mbp > 0)
-    n_targets = species.numel()
-    db_bp = int(gen_off[-1].item())
-    tgt_windows = synth.window_counts(gen_off)
-    t_genomes = time.time() - t_setup
-
-    # ---- reads (distinct batches, resident in HBM before the clock starts; sampled before the table is built, because the
-    # sequences of a table built in parts are released before the table itself is allocated)
-    L, B = a.read_len, a.batch
-    paired = a.workload == "paired"
-    if a.workload == "long":
-        B = min(B, a.long_batch)
-    nb = a.distinct_batches or a.steps
-    free = torch.cuda.mem_get_info(dev)[0]
-    per_batch = (B * a.long_mean * 12) if a.workload == "long" else (B * L * 3)
-    nb = max(1, min(nb, int(free * (0.1 if a.refseq_scale else 0.5)) // per_batch))
-    batches, offsets = [], []
-    for i in range(nb):
-        sd = 1000 + 7919 * rank + i
-        if a.workload == "c2":
-            r, off, _ = synth.sample_reads(gen_bases, gen_off, B, L, 0.005, 0.001, seed=sd)
-        elif paired:
-            r, off, _ = synth.sample_pairs(gen_bases, gen_off, B // 2, L, 300, 500, 0.005, 0.001, seed=sd)
+    def setup_data():
+        """genomes -> read batches -> table (this rank's shard and / or the whole table); returns everything the legs need"""
+        # ---- database: same seeded genomes on every rank; each rank keeps its hash-range shard
+        t_setup = time.time()
+        if a.refseq_scale:
+            # BASELINE configs[2] shape on one GPU (SURVEY.md 8d C3): >= 100 Gbp, >= 2^15 sequences, one chromosome of > 2^17 windows
+            gen_bases, gen_off, species = synth.make_genomes_big(n_species, a.strains, a.genome_min, a.genome_max, a.divergence, seed=3,
+                                                                 device=dev, extra_genome=int(a.long_genome_mbp * 1e6))
         else:
-            r, off, _ = synth.sample_long_reads(gen_bases, gen_off, B, a.long_mean, 0.08, seed=sd)
-        batches.append(r); offsets.append(off)
+            gen_bases, gen_off, species = synth.make_genomes(n_species, a.strains, a.genome_min, a.genome_max,
+                                                             a.divergence, seed=3, device=dev)
+            if a.long_genome_mbp > 0:
+                gen_bases, gen_off, species = synth.add_genome(gen_bases, gen_off, species, int(a.long_genome_mbp * 1e6), seed=4)
+        if a.contigs > 1:
+            gen_off, species = synth.split_targets(gen_off, species, a.contigs, keep_last_whole=a.long_genome_mbp > 0)
+        n_targets = species.numel()
+        db_bp = int(gen_off[-1].item())
+        tgt_windows = synth.window_counts(gen_off)
+        t_genomes = time.time() - t_setup
 
-    # ---- table built on the GPU through the C ABI (csrc/mcq_build.hip): in one piece (mcq_build_table), or in feature-hash
-    # parts (mcq_build_parts) when the one-piece temporaries would not fit -- the RefSeq-scale table
-    torch.cuda.empty_cache()            # the builder allocates with hipMalloc, outside torch's cache
-    sp32 = species.to(torch.int32).contiguous()
-    bflags = eng.MCQ_BUILD_REMOVE_OVERPOPULATED if a.remove_overpopulated else 0
-    dbflags = {"auto": 0, "fields32": 0, "fields64": eng.MCQ_DB_LOCS_64, "gw": eng.MCQ_DB_LOCS_GW}[a.loc_format] | \
-              {0: 0, 16: eng.MCQ_DB_SLOTS_16, 64: eng.MCQ_DB_BUCKETS_64}[a.bucket_bytes]
-    in_parts = a.refseq_scale or a.build_parts
-    keys, list_off, locs = (None, None, None)
-    t_build = time.time()
-    if in_parts:
-        parts = eng.Parts(gen_bases.data_ptr(), gen_off.data_ptr(), n_targets, emulate_ranks=a.emulate_ranks, flags=bflags, device=dev.index or 0)
-        torch.cuda.synchronize(dev)
-        t_build = time.time() - t_build
-        n_keys, n_locs, n_parts = parts.n_keys, parts.n_locs, parts.n_parts
-        del gen_bases                   # the sequences go before the table comes
-        torch.cuda.empty_cache()
-        lflags = dbflags & (eng.MCQ_DB_SLOTS_16 | eng.MCQ_DB_BUCKETS_64)
-        db = parts.database(sp32.data_ptr(), flags=lflags) if with_fused else None
-        db_shard = parts.database(sp32.data_ptr(), n_shards=world, shard_id=rank, flags=lflags) if with_sharded else None
-        parts.close()
-        # the CPU leg (the checker) works on the part of the table a batch can touch, read back through the staged entry points
-        want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and with_fused
-        host_table = None
-    else:
-        table = eng.Table(gen_bases.data_ptr(), gen_off.data_ptr(), n_targets, emulate_ranks=a.emulate_ranks, flags=bflags,
-                          device=dev.index or 0)
-        torch.cuda.synchronize(dev)
-        t_build = time.time() - t_build
-        n_parts = 1
+        # ---- reads (distinct batches, resident in HBM before the clock starts; sampled before the table is built, because the
+        # sequences of a table built in parts are released before the table itself is allocated)
+        L, B = a.read_len, a.batch
+        paired = a.workload == "paired"
+        if a.workload == "long":
+            B = min(B, a.long_batch)
+        nb = a.distinct_batches or a.steps
+        free = torch.cuda.mem_get_info(dev)[0]
+        per_batch = (B * a.long_mean * 12) if a.workload == "long" else (B * L * 3)
+        nb = max(1, min(nb, int(free * (0.1 if a.refseq_scale else 0.5)) // per_batch))
+        batches, offsets = [], []
+        for i in range(nb):
+            sd = 1000 + 7919 * rank + i
+            if a.workload == "c2":
+                r, off, _ = synth.sample_reads(gen_bases, gen_off, B, L, 0.005, 0.001, seed=sd)
+            elif paired:
+                r, off, _ = synth.sample_pairs(gen_bases, gen_off, B // 2, L, 300, 500, 0.005, 0.001, seed=sd)
+            else:
+                r, off, _ = synth.sample_long_reads(gen_bases, gen_off, B, a.long_mean, 0.08, seed=sd)
+            batches.append(r); offsets.append(off)
 
-        def make_db(n_shards=1, shard_id=0):
-            return eng.Database(None, None, None, None, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0, flags=dbflags,
-                                device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr,
-                                                 tgt2tax=sp32.data_ptr(), n_keys=table.n_keys, n_locs=table.n_locs,
-                                                 n_targets=sp32.numel()))
-        # full table (fused single-GPU path / replicas) and/or this rank's hash-range shard
-        db = make_db() if with_fused else None
-        db_shard = make_db(world, rank) if with_sharded else None
-        n_keys, n_locs = table.n_keys, table.n_locs
-        want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and (world == 1 or n_locs <= 600_000_000)
-        host_table = table.to_host()[:3] if want_cpu else None      # only the CPU baseline (the checker) reads these
-        table.close()
-        del gen_bases
+        # ---- table built on the GPU through the C ABI (csrc/mcq_build.hip): in one piece (mcq_build_table), or in feature-hash
+        # parts (mcq_build_parts) when the one-piece temporaries would not fit -- the RefSeq-scale table
+        torch.cuda.empty_cache()            # the builder allocates with hipMalloc, outside torch's cache
+        sp32 = species.to(torch.int32).contiguous()
+        bflags = eng.MCQ_BUILD_REMOVE_OVERPOPULATED if a.remove_overpopulated else 0
+        dbflags = {"auto": 0, "fields32": 0, "fields64": eng.MCQ_DB_LOCS_64, "gw": eng.MCQ_DB_LOCS_GW}[a.loc_format] | \
+                  {0: 0, 16: eng.MCQ_DB_SLOTS_16, 64: eng.MCQ_DB_BUCKETS_64}[a.bucket_bytes]
+        in_parts = a.refseq_scale or a.build_parts
+        keys, list_off, locs = (None, None, None)
+        t_build = time.time()
+        if in_parts:
+            # (only this rank's hash range of the features when nothing else is wanted: half the passes over the sequences at N = 2)
+            own_only = with_sharded and not with_fused
+            parts = eng.Parts(gen_bases.data_ptr(), gen_off.data_ptr(), n_targets, emulate_ranks=a.emulate_ranks, flags=bflags, device=dev.index or 0,
+                              n_shards=world if own_only else 1, shard_id=rank if own_only else 0)
+            torch.cuda.synchronize(dev)
+            t_build = time.time() - t_build
+            n_keys, n_locs, n_parts = parts.n_keys, parts.n_locs, parts.n_parts
+            del gen_bases                   # the sequences go before the table comes
+            torch.cuda.empty_cache()
+            lflags = dbflags & (eng.MCQ_DB_SLOTS_16 | eng.MCQ_DB_BUCKETS_64)
+            db = parts.database(sp32.data_ptr(), flags=lflags) if with_fused else None
+            db_shard = parts.database(sp32.data_ptr(), n_shards=world, shard_id=rank, flags=lflags) if with_sharded else None
+            parts.close()
+            # the CPU leg (the checker) works on the part of the table a batch can touch, read back through the staged entry points
+            want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and with_fused
+            host_table = None
+        else:
+            table = eng.Table(gen_bases.data_ptr(), gen_off.data_ptr(), n_targets, emulate_ranks=a.emulate_ranks, flags=bflags,
+                              device=dev.index or 0)
+            torch.cuda.synchronize(dev)
+            t_build = time.time() - t_build
+            n_parts = 1
+
+            def make_db(n_shards=1, shard_id=0):
+                return eng.Database(None, None, None, None, n_shards=n_shards, shard_id=shard_id, device=dev.index or 0, flags=dbflags,
+                                    device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr,
+                                                     tgt2tax=sp32.data_ptr(), n_keys=table.n_keys, n_locs=table.n_locs,
+                                                     n_targets=sp32.numel()))
+            # full table (fused single-GPU path / replicas) and/or this rank's hash-range shard
+            db = make_db() if with_fused else None
+            db_shard = make_db(world, rank) if with_sharded else None
+            n_keys, n_locs = table.n_keys, table.n_locs
+            want_cpu = rank == 0 and not a.no_cpu_baseline and not a.stop_stage and (world == 1 or n_locs <= 600_000_000)
+            host_table = table.to_host()[:3] if want_cpu else None      # only the CPU baseline (the checker) reads these
+            table.close()
+            del gen_bases
+        return dict(species=species, n_targets=n_targets, db_bp=db_bp, tgt_windows=tgt_windows, t_genomes=t_genomes, L=L, B=B, paired=paired,
+                    nb=nb, batches=batches, offsets=offsets, sp32=sp32, t_build=t_build, n_parts=n_parts, db=db, db_shard=db_shard,
+                    n_keys=n_keys, n_locs=n_locs, want_cpu=want_cpu, host_table=host_table, t_setup=t_setup)
+
+    # ranks that share a device (the gloo rehearsal of N > 1 on a one-GPU box) take turns: a RefSeq-scale table needs its 100 Gbp of
+    # sequences on the GPU while it is built, once at a time
+    share = world > 1 and torch.cuda.device_count() < world
+    D = None
+    for turn in range(world if share else 1):
+        if not share or turn == rank:
+            D = setup_data()
+            torch.cuda.synchronize(dev)
+        if share:
+            dist.barrier()
+    species, n_targets, db_bp, tgt_windows, t_genomes, L, B, paired = (D[k] for k in ("species", "n_targets", "db_bp", "tgt_windows", "t_genomes", "L", "B", "paired"))
+    nb, batches, offsets, sp32, t_build, n_parts, db, db_shard = (D[k] for k in ("nb", "batches", "offsets", "sp32", "t_build", "n_parts", "db", "db_shard"))
+    n_keys, n_locs, want_cpu, host_table, t_setup = (D[k] for k in ("n_keys", "n_locs", "want_cpu", "host_table", "t_setup"))
     db_layout = (db or db_shard).layout()
     db_layout.pop("gw_offsets", None)
     db_layout["loc_format"] = {eng.MCQ_LOC_FIELDS64: "fields64", eng.MCQ_LOC_FIELDS32: "fields32", eng.MCQ_LOC_GLOBAL_WINDOW: "global_window"}[db_layout["loc_format"]]
@@ -619,18 +643,24 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a, odb_of, batches, offsets, (a.warmup + a.steps - 1) % nb,
                                            gc, gn, B, paired, bounded=world > 1 or host_table is None, note=note)
         parity_ok = out["cpu_baseline"]["gpu_matches_cpu_on_first_batch"] is not False
-        ref_file = os.path.join(ROOT, "profiles", "r02_reference_at_scale.json")
-        if os.path.exists(ref_file) and world == 1 and n_species == 50 and not a.small:
-            # recorded, not measured in this run: the reference's own binary on this table (scripts/reference_at_scale.py)
-            with open(ref_file) as f:
-                rj = json.load(f)
-            out["cpu_baseline"]["reference_itself_recorded"] = {
-                "value": rj.get("reference_reads_per_s"), "unit": "reads/s", "cores": rj["reference_ranks"] * rj["threads_per_rank"],
-                "sample": "%d pairs of 2x150 bp on this table, mpiexec -n %d x %d threads, its own summary line" %
-                          (rj["pairs"], rj["reference_ranks"], rj["threads_per_rank"]),
-                "same_mapping_lines_as_the_engine": bool(rj.get("identical_mapping_lines") or rj.get("identical_after_sorting")),
-                "source": "profiles/r02_reference_at_scale.json (scripts/reference_at_scale.py on the GPU box; the reference's MPI "
-                          "query segfaults on single-end files, so pairs)"}
+    out["timed_region_ms"] = 1e3 * (sharded_elapsed if (mode == "sharded" and sharded_elapsed is not None) else fused_elapsed)
+    if (world == 1 and mode == "single" and a.workload == "c2" and not a.small and not a.refseq_scale and a.species == 50 and not a.stop_stage
+            and not a.no_cpu_baseline and not a.no_pcie_leg and not a.no_refseq_block and not a.packed_input and a.contigs == 1):
+        # the regime north_star targets, in the same driver-timed run (a side block like pcie_inclusive: never `value`): everything of
+        # the configs[1] measurement is released first
+        try:
+            if ws is not None:
+                ws.close()
+            db.close()
+            del batches, offsets, cands, ncand, cands_s, ncand_s
+            host_table = None
+            torch.cuda.empty_cache()
+            out["refseq_scale"] = refseq_side_block(a, eng, synth, torch, dev, stream)
+            for k in ("single_end", "paired"):
+                if isinstance(out["refseq_scale"].get(k), dict) and out["refseq_scale"][k].get("gpu_matches_cpu") is False:
+                    parity_ok = False
+        except Exception as e:
+            out["refseq_scale"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
     if rank == 0:
         emit(out)
     rc = 0
@@ -644,6 +674,155 @@ def main():
             os._exit(rc)
         dist.destroy_process_group()
     sys.exit(rc)
+
+
+def refseq_side_block(a, eng, synth, torch, dev, stream):
+    """The regime north_star targets, timed in the driver's own default run (never `value`): BASELINE configs[2]'s table --
+    2 600 species x 10 strains (>= 100 Gbp), every genome two sequences (52 001 targets), one 16 Mbp chromosome, built with
+    -remove-overpopulated-features in feature-hash parts -- on this ONE GPU; 8 timed steps of 1 M x 150 bp reads and of 524 288
+    pairs of 2 x 150 bp through the fused path, the same through mcq_shard_* at one rank (the N > 1 product path; a rank's own
+    blocks never travel), and the first 2^18 reads of a batch of each against the CPU oracle on the sub-table they can touch."""
+    from oracle import mc_oracle as orc
+    from oracle import subtable
+    t0 = time.time()
+    torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info(dev)[0]
+    if free < 250e9:
+        return {"skipped": "needs 250 GB of free HBM, %.0f GB are free" % (free / 1e9)}
+    P, M, B, K, W, NB, NC = a.emulate_ranks, a.max_cand, 1 << 20, 8, 2, 4, 1 << 18
+    gb, goff, species = synth.make_genomes_big(2600, 10, 2_000_000, 6_000_000, 0.02, seed=3, device=dev, extra_genome=16_000_000)
+    goff, species = synth.split_targets(goff, species, 2, keep_last_whole=True)
+    n_targets, db_bp = species.numel(), int(goff[-1].item())
+    tw = synth.window_counts(goff)
+    sets = {"single_end": [synth.sample_reads(gb, goff, B, 150, 0.005, 0.001, seed=1000 + i)[:2] for i in range(NB)],
+            "paired": [synth.sample_pairs(gb, goff, B // 2, 150, 300, 500, 0.005, 0.001, seed=2000 + i)[:2] for i in range(NB)]}
+    torch.cuda.empty_cache()
+    t_b = time.time()
+    parts = eng.Parts(gb.data_ptr(), goff.data_ptr(), n_targets, emulate_ranks=P, flags=eng.MCQ_BUILD_REMOVE_OVERPOPULATED, device=dev.index or 0)
+    torch.cuda.synchronize(dev)
+    t_b = time.time() - t_b
+    n_keys, n_locs, n_parts = parts.n_keys, parts.n_locs, parts.n_parts
+    del gb
+    torch.cuda.empty_cache()
+    sp32 = species.to(torch.int32).contiguous()
+    db = parts.database(sp32.data_ptr())
+    parts.close()
+    lay = db.layout(); lay.pop("gw_offsets", None)
+    sp = species.cpu().numpy().astype(np.uint32)
+    out = {"workload": "BASELINE configs[2] shape (RefSeq scale) on ONE GPU: %d synthetic targets (2600 species x 10 strains x 2 sequences + one 16 Mbp chromosome, "
+                       "%.1f Gbp), -remove-overpopulated-features, %d x 150 bp reads / %d pairs of 2x150 bp per step" % (n_targets, db_bp / 1e9, B, B // 2),
+           "db_keys": n_keys, "db_locations": n_locs, "db_hbm_bytes": db.bytes(), "db_build_s": round(t_b, 1), "db_build_parts": n_parts,
+           "db_layout": {k: lay[k] for k in ("loc_bytes", "loc_format", "bucket_bytes", "slots_per_key", "n_windows")},
+           "steps": K, "warmup": W, "emulate_ranks": P, "max_cand": M}
+    for name, paired in (("single_end", False), ("paired", True)):
+        bt = sets[name]
+        nq = B // 2 if paired else B
+        max_bases = max(int(o[-1].item()) for _, o in bt)
+        cands = torch.zeros((nq, M, 4), dtype=torch.int32, device=dev); ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
+        ws = eng.Workspace(db, nq, max_bases)
+
+        def step(i):
+            r, o = bt[i % NB]
+            ws.query_device(r.data_ptr(), o.data_ptr(), B, paired, cands.data_ptr(), ncand.data_ptr(), max_cand=M, emulate_ranks=P, stream=stream)
+        for i in range(W):
+            step(i)
+        torch.cuda.synchronize(dev)
+        ws.timing(True)
+        t1 = time.perf_counter()
+        for i in range(K):
+            step(W + i)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t1
+        st = ws.sync()
+        kms, kn = ws.kernel_times()
+        ws.timing(False)
+        algo = algorithmic_bytes(max_bases, st)
+        ksum = sum(kms) / max(1, kn)
+        blk = {"ms_per_step": 1e3 * el / K, "reads_per_s": K * B / el,
+               "roofline": {"bound": "hbm", "achieved": algo / (ksum * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": algo / (ksum * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                            "kernel_ms": {KERNELS["fused"][i]: kms[i] / max(1, kn) for i in range(3)}, "kernel_ms_sum": ksum,
+                            "algorithmic_bytes_per_launch": algo, "bytes_per_read": algo / B,
+                            "per_launch": {k: st[k] for k in ("n_features", "n_hit_features", "n_locations", "n_cands", "n_overflow", "n_two_class", "n_two_class_retry")}}}
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_refseq%s.json" % ("p" if paired else ""))))
+            pkg = importlib.import_module("metacache-mpi_amd")
+            if tj.get("csrc_digest") == pkg.source_digest():
+                blk["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                blk["roofline"]["traffic_source"] = tj.get("source", "")
+            else:
+                blk["roofline"]["traffic_source"] = "STALE, not quoted: collected from csrc digest %s, this run is %s" % (tj.get("csrc_digest"), pkg.source_digest())
+        except Exception:
+            pass
+        # the oracle on the first NC sequences of the last timed batch (the result buffers still hold it)
+        r, o = bt[(W + K - 1) % NB]
+        nqc = NC // 2 if paired else NC
+        k_, o_, l_ = subtable.batch_subtable(eng, db, r.data_ptr(), o.data_ptr(), NC, dev, tw)
+        odb = orc.OracleDb(k_, o_, l_, sp)
+        nbytes = int(o[NC].item())
+        aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = max(1, min(aff, a.cpu_threads))
+        tc = time.perf_counter()
+        oc, on = odb.query(r[:nbytes].cpu().numpy().tobytes(), o[:NC + 1].cpu().numpy().astype(np.uint64), paired, max_cand=M, emulate_ranks=P, threads=cores)
+        tc = time.perf_counter() - tc
+        gc = cands[:nqc].cpu().numpy().view(np.uint32); gn = ncand[:nqc].cpu().numpy().view(np.uint32)
+        ok = bool(np.array_equal(gn, on))
+        if ok:
+            mask = np.arange(M)[None, :] < on[:, None]
+            ok = bool(np.array_equal(gc[mask], oc[mask]))
+        blk["gpu_matches_cpu"] = ok
+        blk["cpu_baseline"] = {"value": NC / tc, "unit": "reads/s", "cores": cores, "kind": "port",
+                               "sample": "%d reads of the last timed batch, oracle on the sub-table of their features read back from the GPU table (oracle/subtable.py)" % NC}
+        del odb, k_, o_, l_
+        ws.close()
+        # the same batches through mcq_shard_* at one rank: S1 sketch + route, S2 owner-side lookup into the location block, S3 the SH
+        # instantiations of the reduce kernels; block sizes learned from the first (exact) batch
+        try:
+            sh = eng.Shard(db, 1, 0, max_queries=nq, max_bases=max_bases, max_seqs=B)
+            c2 = torch.zeros_like(cands); n2 = torch.zeros_like(ncand)
+
+            def sstep(i, last=False):
+                r_, o_2 = bt[i % NB]
+                nx = None if last else (bt[(i + 1) % NB][0].data_ptr(), bt[(i + 1) % NB][1].data_ptr(), B)
+                sh.query(r_.data_ptr(), o_2.data_ptr(), B, paired, c2.data_ptr(), n2.data_ptr(), max_cand=M, emulate_ranks=P, stream=stream, next_batch=nx)
+            for i in range(NB):          # every distinct batch once in the exact mode: the padded sizes cover all of them
+                r_, o_2 = bt[i]
+                sh.query(r_.data_ptr(), o_2.data_ptr(), B, paired, c2.data_ptr(), n2.data_ptr(), max_cand=M, emulate_ranks=P, stream=stream, exact=True)
+                sh.sync(stream)
+            for i in range(W):
+                sstep(i)
+            torch.cuda.synchronize(dev)
+            xb0 = sh.exchange_bytes()
+            sh.timing(True)
+            t1 = time.perf_counter()
+            for i in range(K):
+                sstep(W + i, last=(i == K - 1))
+            torch.cuda.synchronize(dev)
+            el_s = time.perf_counter() - t1
+            sst = sh.sync(stream)
+            skms, skn = sh.kernel_times()
+            stage_ms, stage_n = sh.stage_times()
+            sh.timing(False)
+            xb1 = sh.exchange_bytes()
+            same = bool(torch.equal(ncand, n2))
+            if same:
+                m = torch.arange(M, device=dev)[None, :] < ncand[:, None]
+                same = bool(torch.equal(cands[m], c2[m]))
+            nbt = max(1, xb1["batches"] - xb0["batches"])
+            blk["sharded_one_rank"] = {"ms_per_step": 1e3 * el_s / K, "matches_fused_kernel": same,
+                                       "stage_ms_per_step": dict({k: v / max(1, stage_n) for k, v in stage_ms.items()}, S3=sum(skms) / max(1, skn)),
+                                       "block_bytes_per_step": {"all_blocks": (xb1["own_blocks"] - xb0["own_blocks"]) / nbt,
+                                                                "note": "X1 features + X2 list ends + X2 locations of this rank's own blocks (padded sizes; never travel at one rank); "
+                                                                        "at N ranks (N - 1) / N of the same total do"},
+                                       "block_features_locations": list(sh.caps()), "n_two_class": sst["n_two_class"], "n_locations": sst["n_locations"]}
+            sh.close()
+        except Exception as e:          # the fused figures stand
+            blk["sharded_one_rank"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        out[name] = blk
+        del cands, ncand
+    db.close()
+    out["seconds"] = round(time.time() - t0, 1)
+    return out
 
 
 def cpu_baseline(a, odb_of, batches, offsets, first, cands, ncand, B, paired, bounded=False, note=""):

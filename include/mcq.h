@@ -331,10 +331,13 @@ typedef struct {
     uint64_t max_bases;                /* per batch and rank: bounds the number of windows */
     uint64_t max_locs_per_query;       /* as in mcq_ws_create; 0 = default */
     uint64_t max_features_per_peer;    /* capacity of one peer's feature block; 0 = twice the even share of the batch */
-    uint64_t max_locations_per_peer;   /* capacity of one peer's location block; 0 = 16 per feature slot the batch can have
-                                          (max_bases / stride x sketch size), shared out over the ranks, + 2^20.
-                                          Identical on every rank.  A block that overflows is reported by mcq_shard_sync
-                                          as MCQ_E_CAPACITY (never answered wrongly in silence)                       */
+    uint64_t max_locations_per_peer;   /* capacity of one peer's location block to start with; 0 = sized by the table: the first
+                                          batch of a context runs in the exact mode, its owner-side lookup first counts, and
+                                          every rank allocates blocks for the largest count any rank served + 1/8.  An exact
+                                          batch that outgrows the blocks allocates larger ones the same way (collectively);
+                                          a padded batch that does is reported by mcq_shard_sync as MCQ_E_CAPACITY (never
+                                          answered wrongly in silence) and its repeat with MCQ_SHARD_EXACT grows them.
+                                          Identical on every rank.                                                          */
 } mcq_shard_cfg;
 
 /* moves send_bytes[p] bytes at send_base + send_off[p] to rank p and receives recv_bytes[p] bytes from rank p at
@@ -352,7 +355,7 @@ int mcq_shard_unique_id(void* out /* MCQ_SHARD_UNIQUE_ID_BYTES */);
 int mcq_shard_comm_rccl(mcq_shard* ctx, const void* unique_id);
 int mcq_shard_set_exchange(mcq_shard* ctx, mcq_exchange_fn fn, void* user);
 /* One batch (device pointers).  Default (padded mode): every block travels at a fixed size learned from the last exact
- * batch (largest count any rank saw, plus a quarter), its count inside it: the call only enqueues work, no host
+ * batch (largest count any rank saw, plus a sixteenth), its count inside it: the call only enqueues work, no host
  * round trip.  The first batch of a context, and any batch with MCQ_SHARD_EXACT, exchanges exact sizes after two
  * count exchanges through the host.  `next` (may be NULL): the batch of the following call, resident in device
  * memory and unchanged until that call -- its sketching is enqueued on a second stream now.  The exchanges and the

@@ -577,17 +577,25 @@ extern "C" int mcq_db_from_parts(const mcq_parts* p, const uint32_t* tgt2tax, ui
 extern "C" int mcq_db_build(const mcq_build_desc* d, mcq_db** out) {
     if (!d || !out) return bfail(MCQ_E_ARG, "null argument");
     // in parts when the one-piece temporaries (~60 B per feature slot of the sequences) would not leave room for the table --
-    // or when asked to (MCQ_BUILD_PARTS: test hook); needs the sequences in device memory
+    // or when asked to (MCQ_BUILD_PARTS: test hook); needs the sequences in device memory.
+    // The two routes must not give different location WORDS for the same data when the words travel (a sharded table: the home
+    // rank decodes what the owners send with its own tables): with n_shards > 1 the route is chosen by the size of the data alone
+    // (not by what this rank happens to have free), and both routes give the global-window form over the true window counts of
+    // the targets.  (A one-rank table keeps the faster bit fields where they fit, and the memory-driven choice.)
+    const bool sharded = d->n_shards > 1;
     if ((d->flags & MCQ_DEVICE_PTRS) && !(d->flags & MCQ_DB_LOCS_64) && d->seq_off && d->n_targets) {
         bool in_parts = getenv("MCQ_BUILD_PARTS") != nullptr;
         if (!in_parts) {
             u64 ends[1] = {0};
             BCHK(hipSetDevice(d->device));
             BCHK(hipMemcpy(ends, d->seq_off + d->n_targets, 8, hipMemcpyDeviceToHost));
-            size_t mem_free = 0, mem_total = 0;
-            BCHK(hipMemGetInfo(&mem_free, &mem_total));
             const u64 slots = ends[0] / (d->winstride ? d->winstride : 1) * d->sketch_size;
-            in_parts = slots * 60 > mem_free / 2;
+            if (sharded) in_parts = slots * 60 > (96ull << 30);
+            else {
+                size_t mem_free = 0, mem_total = 0;
+                BCHK(hipMemGetInfo(&mem_free, &mem_total));
+                in_parts = slots * 60 > mem_free / 2;
+            }
         }
         if (in_parts) {
             mcq_parts* parts = nullptr;
@@ -607,7 +615,14 @@ extern "C" int mcq_db_build(const mcq_build_desc* d, mcq_db** out) {
     c.n_targets = d->n_targets; c.n_keys = T->n_keys; c.n_locs = T->n_locs;
     c.keys = T->keys; c.list_off = T->list_off; c.locs = T->locs; c.tgt2tax = t2t;
     c.n_shards = d->n_shards ? d->n_shards : 1; c.shard_id = d->shard_id; c.flags = MCQ_DEVICE_PTRS | (d->flags & (MCQ_DB_LOCS_64 | MCQ_DB_LOCS_GW | MCQ_DB_SLOTS_16 | MCQ_DB_BUCKETS_64)); c.device = d->device;
+    // the true window counts of the targets (what the parts route defines its words by), and for a sharded table that form
+    u32* tw = nullptr;
+    BCHK(hipMalloc(&tw, (u64)d->n_targets * 4));
+    hipLaunchKernelGGL(k_windows_of, dim3((d->n_targets + TB - 1) / TB), dim3(TB), 0, 0, (const u64*)T->win_off, d->n_targets, tw);
+    c.tgt_windows = tw;
+    if (sharded && !(d->flags & MCQ_DB_LOCS_64)) c.flags |= MCQ_DB_LOCS_GW;
     int rc = mcq_db_create(&c, out);
+    (void)hipFree(tw);
     if (rc != MCQ_OK) g_berr = mcq_last_error();
     (void)hipFree(t2t);
     mcq_table_free(T);

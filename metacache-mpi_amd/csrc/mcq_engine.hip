@@ -75,6 +75,8 @@ struct mcq_db {
     u64 n_ext, n_windows;
     u64 bytes;
     bool seq_taxa;            // tgt2tax holds sequence-level taxa (bit 31; see make_opt)
+    u64 fmt_sig;              // what the location words of this handle mean (format, field widths, window offsets of the targets, sketch
+                              // parameters), hashed: the ranks of a sharded run compare it before the first words travel (mcq_shard.hpp)
 };
 
 struct ScratchDev {
@@ -97,7 +99,7 @@ struct mcq_ws {
     CountersDev* ctr;         // device
     CountersDev* ctr_host;    // pinned
     u32* ovf_list;            // [ovf_capacity(max_queries)]
-    unsigned long long* probe_buf;   // [2 x (max_queries + MCQ_OVF_TAIL) x 64]: rows of the back queue, then of the front queue; see CountersDev
+    unsigned long long* probe_buf;   // [(2 x max_queries + 3 x MCQ_OVF_TAIL) x 64]: rows of the back queue, then of the front queue; see CountersDev
     ScratchDev sc;
     int n_block_wgs;
     u32 cap_wave, cap_wave16, cap_reduce16, cap_wave32, cap_wave_many;   // resident workgroups of the wave-per-query kernels on this device
@@ -2355,6 +2357,18 @@ static int create_table(const mcq_db_desc* desc, const std::vector<PartView>& pa
     db->d.magic_stride = (u32)std::min<u64>((1ull << 32) / db->d.winstride, 0xFFFFFFFFull);
     db->d.magic_tgt_stride = (u32)std::min<u64>((1ull << 32) / db->d.tgt_winstride, 0xFFFFFFFFull);
     db->bytes = table_bytes + (u64)desc->n_targets * 4 + (gw ? ((u64)desc->n_targets + 1) * 4 + ((n_windows >> gw_shift) + 2) * 4 : 0);
+    {   // FNV-1a over everything a peer must agree on to read this handle's location words
+        u64 h = 1469598103934665603ull;
+        auto mix = [&h](u64 v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xFF; h *= 1099511628211ull; } };
+        mix(compact); mix(gw); mix(wb); mix(gw ? n_windows : 0); mix(desc->n_targets); mix(db->d.k); mix(db->d.s); mix(db->d.winlen); mix(db->d.winstride);
+        mix(db->d.tgt_winstride); mix(n_shards);
+        if (gw && desc->n_targets) {
+            std::vector<u32> go((u64)desc->n_targets + 1);
+            if (hipMemcpy(go.data(), d_gwoff, go.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { (void)mcq_db_destroy(db); return fail(MCQ_E_HIP, "reading back the window offsets failed"); }
+            for (u32 v : go) { h ^= v; h *= 1099511628211ull; }
+        }
+        db->fmt_sig = h;
+    }
     *out = db;
     return MCQ_OK;
 }
@@ -2490,12 +2504,15 @@ extern "C" int mcq_ws_create(const mcq_db* db, uint64_t max_queries, uint64_t ma
     WSCHK(hipMalloc(&ws->ctr, sizeof(CountersDev)));
     WSCHK(hipHostMalloc(&ws->ctr_host, sizeof(CountersDev)));
     WSCHK(hipMalloc(&ws->ovf_list, ovf_capacity(max_queries) * 4));
-    WSCHK(hipMalloc(&ws->probe_buf, 2 * (max_queries + (u64)MCQ_OVF_TAIL) * 64 * 8));       // back-queue rows, then front-queue rows
+    // back-queue rows (first-stage pushes: below max_queries + MCQ_OVF_TAIL), then front-queue rows (first-stage front pushes AND the
+    // second stage's hand-ons, each set of waves with its reservation tails: below max_queries + 2 x MCQ_OVF_TAIL)
+    const u64 probe_rows = 2 * max_queries + 3 * (u64)MCQ_OVF_TAIL;
+    WSCHK(hipMalloc(&ws->probe_buf, probe_rows * 64 * 8));
     WSCHK(hipMemset(ws->ctr, 0, sizeof(CountersDev)));
     WSCHK(hipMemcpy(&ws->ctr->probe_buf, &ws->probe_buf, sizeof(ws->probe_buf), hipMemcpyHostToDevice));
-    WSCHK(hipMemset(ws->probe_buf, 0, 2 * (max_queries + (u64)MCQ_OVF_TAIL) * 64 * 8));        // (a row never written reads as 64 empty lists)
+    WSCHK(hipMemset(ws->probe_buf, 0, probe_rows * 64 * 8));        // (a row never written reads as 64 empty lists)
     {
-        unsigned long long* front = ws->probe_buf + (max_queries + (u64)MCQ_OVF_TAIL) * 64;       // (first-stage pushes stay below max_queries + MCQ_OVF_TAIL)
+        unsigned long long* front = ws->probe_buf + (max_queries + (u64)MCQ_OVF_TAIL) * 64;
         WSCHK(hipMemcpy(&ws->ctr->probe_front, &front, sizeof(front), hipMemcpyHostToDevice));
     }
     WSCHK(hipMalloc(&ws->sc.feat, nb * ws->sc.fmax * 4));

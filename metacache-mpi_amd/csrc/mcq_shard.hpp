@@ -113,7 +113,7 @@ __global__ void k_shard_fold_err(u32* err, const u32* s1_err) { if (*s1_err) ato
 // then capF list ends.  (One wave per 256-feature tile -- no barriers, no LDS -- measured 5 % slower per batch.)
 template <class KeyT>
 __global__ __launch_bounds__(256) void k_shard_lookup(DbDev db, u32 n_ranks, const u32* recvF, u32 capF, u32 capFx, u32 capT,
-                                                      u32* sendR, KeyT* sendL, u64 capL, u32* err) {
+                                                      u32* sendR, KeyT* sendL, u64 capL, u32* err, int count_only) {
     __shared__ u32 s_wt[4][4];
     __shared__ u32 s_tbase;
     const u32 tid = threadIdx.x, lane = tid & 63;
@@ -163,8 +163,9 @@ __global__ __launch_bounds__(256) void k_shard_lookup(DbDev db, u32 n_ranks, con
         const u32 tb = total ? atomicAdd(&R[0], total) : 0u;
         s_tbase = tb;
         R[MCQ_SHARD_HDR + t] = tb;
-        if ((u64)tb + total > capL) atomicOr(err, 4u);                            // p's location block is full
+        if (!count_only && (u64)tb + total > capL) atomicOr(err, 4u);             // p's location block is full
     }
+    if (count_only) return;                                   // (sizing pass of the exact mode: only the cursors are wanted)
     __syncthreads();
     const u32 tbase = s_tbase;
     const bool fits = (u64)tbase + total <= capL;
@@ -280,6 +281,7 @@ struct mcq_shard {
     ncclComm_t comm; bool have_comm;
     mcq_exchange_fn xfn; void* xuser;
     u64 last_nq;
+    bool fmt_checked;                     // the ranks have compared what their location words mean (first exact batch)
     u64 seen_features, seen_locations;    // exact mode: the largest per-peer counts of the batch (sizes the padded mode's blocks)
     // accounting of the exchanges (mcq_shard_exchange_bytes): bytes handed to the transport for OTHER ranks, and of the rank's own blocks
     u64 xb_batches, xb_x1, xb_x2r, xb_x2l, xb_self;
@@ -351,6 +353,32 @@ extern "C" int mcq_shard_destroy(mcq_shard* c) {
     return MCQ_OK;
 }
 
+// location blocks of every buffer set for `capL` locations per peer (identical on every rank: the offset of peer p's block is
+// p x capL on both sides of the exchange).  The receive side is allocated when a transport needs it: one rank without a
+// transport reads its own send buffers in place.  Frees what was there: callers make sure no kernel still reads it.
+static bool shard_alias(const mcq_shard* c);
+static int shard_alloc_locations(mcq_shard* c, u64 capL) {
+    if (capL >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "more than 2^32 locations per peer and batch: use smaller batches");
+    for (auto& b : c->sb) {
+        if (b.sendL) { (void)hipFree(b.sendL); b.sendL = nullptr; }
+        if (b.recvL) { (void)hipFree(b.recvL); b.recvL = nullptr; }
+    }
+    c->capL = 0;
+    for (auto& b : c->sb) {
+        HIPCHK(hipMalloc(&b.sendL, std::max<u64>(1, (u64)c->n * capL * c->locb)));
+        if (!shard_alias(c)) HIPCHK(hipMalloc(&b.recvL, std::max<u64>(1, (u64)c->n * capL * c->locb)));
+    }
+    c->capL = capL;
+    return MCQ_OK;
+}
+// (a transport was attached after the blocks were allocated)
+static int shard_ensure_recv(mcq_shard* c) {
+    if (shard_alias(c) || !c->capL) return MCQ_OK;
+    for (auto& b : c->sb) if (!b.recvL) HIPCHK(hipMalloc(&b.recvL, std::max<u64>(1, (u64)c->n * c->capL * c->locb)));
+    return MCQ_OK;
+}
+__global__ void k_shard_clear_bits(u32* err, u32 bits) { atomicAnd(err, ~bits); }
+
 extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, mcq_shard** out) {
     if (!shard || !cfg || !out) return fail(MCQ_E_ARG, "null argument");
     if (cfg->n_ranks < 1 || cfg->n_ranks > MCQ_SHARD_MAX_RANKS) return fail(MCQ_E_UNSUPPORTED, "n_ranks must be 1..32");
@@ -368,9 +396,12 @@ extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, m
     u64 capF = cfg->max_features_per_peer ? cfg->max_features_per_peer : std::min<u64>(max_slots, 2 * max_slots / n + 65536);
     capF = (capF + MCQ_SHARD_TILE - 1) / MCQ_SHARD_TILE * MCQ_SHARD_TILE;
     if (capF >= (1ull << MCQ_SHARD_POS_BITS)) return fail(MCQ_E_UNSUPPORTED, "more than 2^27 features per peer and batch");
-    // locations: an average list of 16 entries for every feature slot the batch can have (C2 has 3.4, a 33 Gbp table 11)
-    const u64 capL = cfg->max_locations_per_peer ? cfg->max_locations_per_peer
-                                                 : (std::max<u64>(cfg->max_queries * 512, max_slots * 16) / n + (1u << 20));
+    // locations: the blocks are sized by the table, not by a constant: the first batch of a context runs in the exact mode, whose
+    // owner-side lookup first only counts (k_shard_lookup, count_only), every rank learns the largest count any rank served,
+    // and the blocks are allocated for that plus an eighth (shard_grow_locations).  Later exact batches grow them the same way
+    // when they overflow; a padded batch that overflows is reported (MCQ_E_CAPACITY) and its repeat with MCQ_SHARD_EXACT grows them.
+    // (Until r03 this was 16 locations per feature slot: a RefSeq-scale table delivers 28.)
+    const u64 capL = cfg->max_locations_per_peer;
     if (capL >= (1ull << 32)) return fail(MCQ_E_UNSUPPORTED, "more than 2^32 locations per peer and batch");
     HIPCHK(hipSetDevice(shard->device));
     mcq_shard* c = new mcq_shard();
@@ -390,9 +421,8 @@ extern "C" int mcq_shard_create(const mcq_db* shard, const mcq_shard_cfg* cfg, m
         SCHK(hipMalloc(&b.recvF, n * fblk_words(c) * 4));
         SCHK(hipMalloc(&b.sendR, n * rblk_words(c) * 4));
         SCHK(hipMalloc(&b.recvR, n * rblk_words(c) * 4));
-        SCHK(hipMalloc(&b.sendL, n * capL * c->locb));
-        SCHK(hipMalloc(&b.recvL, n * capL * c->locb));
     }
+    if (capL) { const int rcg = shard_alloc_locations(c, capL); if (rcg) { (void)mcq_shard_destroy(c); return rcg; } }
     SCHK(hipMalloc(&c->err, 4 * (1 + MCQ_SHARD_SETS))); SCHK(hipMemset(c->err, 0, 4 * (1 + MCQ_SHARD_SETS)));
     SCHK(hipHostMalloc(&c->err_host, 4));
     SCHK(hipMalloc(&c->cnt_dev, 4 * n * 8)); SCHK(hipHostMalloc(&c->cnt_host, 4 * n * 8));
@@ -431,7 +461,12 @@ extern "C" int mcq_shard_set_exchange(mcq_shard* c, mcq_exchange_fn fn, void* us
 
 extern "C" int mcq_shard_set_caps(mcq_shard* c, uint64_t features_per_peer, uint64_t locations_per_peer) {
     if (!c) return fail(MCQ_E_ARG, "null argument");
-    if (features_per_peer > c->capF || locations_per_peer > c->capL) return fail(MCQ_E_ARG, "beyond the buffers' capacity");
+    if (features_per_peer > c->capF) return fail(MCQ_E_ARG, "beyond the feature blocks' capacity");
+    if (locations_per_peer > c->capL) {                   // (collective like every call: all ranks pass the same sizes)
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipDeviceSynchronize());
+        int rc = shard_alloc_locations(c, locations_per_peer); if (rc) return rc;
+    }
     c->capFx = (u32)features_per_peer; c->capLx = locations_per_peer;
     return MCQ_OK;
 }
@@ -505,13 +540,24 @@ static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
     const bool alias = shard_alias(c);
     u32* const recvF = alias ? b.sendF : b.recvF;
     u32* const recvR = alias ? b.sendR : b.recvR;
-    void* const recvL = alias ? b.sendL : b.recvL;
     std::vector<u64> sbytes(n), rbytes(n), cnt_mine(n), cnt_theirs(n);
     int rc;
     // ---- X1: feature blocks to their owners
     if (c->ws->timing) HIPCHK(hipEventRecord(c->tv[k][2], st));
     c->xb_batches += 1;
     u32 capFx = c->capFx; u64 capLx = c->capLx;
+    if (exact && !c->fmt_checked) {
+        // before the first location word travels: every rank must read the words the way their owner wrote them (same format, field
+        // widths, window offsets of the targets, sketch parameters, rank count) -- shards built from different data or by different
+        // routes would otherwise answer with wrong candidates in silence
+        std::vector<u64> sig(n, c->db->fmt_sig), theirs(n);
+        rc = shard_exchange_counts(c, sig.data(), theirs.data(), st); if (rc) return rc;
+        for (u32 p = 0; p < n; ++p)
+            if (theirs[p] != c->db->fmt_sig)
+                return fail(MCQ_E_ARG, "rank " + std::to_string(p) + " holds its shard with other location words than rank " + std::to_string(c->rank) +
+                            " (format, window counts of the targets or sketch parameters differ): build every shard from the same description");
+        c->fmt_checked = true;
+    }
     if (exact) {
         HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, b.sendF, fblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -529,28 +575,56 @@ static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
     if (c->ws->timing) HIPCHK(hipEventRecord(c->tv[k][3], st));
 
     // ---- S2: owner side
-    hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendR, rblk_words(c), n);
-    {
+    if (!exact && (!c->capL || capLx > c->capL)) return fail(MCQ_E_ARG, "padded mode before any exact batch has sized the location blocks");
+    { rc = shard_ensure_recv(c); if (rc) return rc; }
+    auto lookup = [&](int count_only) {
+        hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendR, rblk_words(c), n);
         const dim3 grid(n * c->capT);
         if (c->db->d.compact) hipLaunchKernelGGL(k_shard_lookup<u32>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
-                                                 b.sendR, (u32*)b.sendL, c->capL, err);
+                                                 b.sendR, (u32*)b.sendL, c->capL, err, count_only);
         else                  hipLaunchKernelGGL(k_shard_lookup<u64>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
-                                                 b.sendR, (u64*)b.sendL, c->capL, err);
-    }
+                                                 b.sendR, (u64*)b.sendL, c->capL, err, count_only);
+    };
+    lookup(exact && c->capL == 0);
     HIPCHK(hipGetLastError());
+    std::vector<u64> served(n), coming(n);
+    if (exact) {
+        // locations served to each peer (cursor word of its R block), and the largest such count on ANY rank: when that is more
+        // than a block holds -- always on a context's first batch, whose lookup only counted -- every rank allocates the same
+        // larger blocks and the lookup runs again
+        auto cursors = [&](u64& mx) -> int {
+            HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, b.sendR, rblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            mx = 0;
+            for (u32 p = 0; p < n; ++p) { served[p] = c->cnt_host[p]; mx = std::max(mx, served[p]); }
+            return MCQ_OK;
+        };
+        u64 lmax = 0;
+        rc = cursors(lmax); if (rc) return rc;
+        std::vector<u64> mine1(n, lmax), all1(n);
+        rc = shard_exchange_counts(c, mine1.data(), all1.data(), st); if (rc) return rc;
+        u64 gmax = 0;
+        for (u32 p = 0; p < n; ++p) gmax = std::max(gmax, all1[p]);
+        if (gmax > c->capL || c->capL == 0) {
+            HIPCHK(hipDeviceSynchronize());                   // (other buffer sets may still be read by an earlier batch's reduce kernels)
+            rc = shard_alloc_locations(c, gmax + gmax / 8 + (1u << 17)); if (rc) return rc;
+            hipLaunchKernelGGL(k_shard_clear_bits, dim3(1), dim3(1), 0, st, err, 4u);
+            lookup(0);
+            HIPCHK(hipGetLastError());
+            rc = cursors(lmax); if (rc) return rc;
+        }
+    }
     if (c->ws->timing) HIPCHK(hipEventRecord(c->tv[k][4], st));
 
     // ---- X2: list ends + tile starts, and the location blocks, back to the requesters
+    void* const recvL = alias ? b.sendL : b.recvL;            // (after the lookup: the exact mode may have allocated larger blocks)
     if (exact) {
         // ends of the features each peer sent (counts known from X1), locations served to each peer (cursor word of its R block)
         for (u32 p = 0; p < n; ++p) { sbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_theirs[p]) * 4; rbytes[p] = ((u64)MCQ_SHARD_HDR + c->capT + cnt_mine[p]) * 4; }
         if (alias) c->xb_self += sbytes[0];
         else { rc = shard_exchange(c, b.sendR, rblk_words(c) * 4, sbytes.data(), recvR, rblk_words(c) * 4, rbytes.data(), st, &c->xb_x2r); if (rc) return rc; }
-        HIPCHK(hipMemcpy2DAsync(c->cnt_host, 4, b.sendR, rblk_words(c) * 4, 4, n, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
         u64 mx = 0;
-        std::vector<u64> served(n), coming(n);
-        for (u32 p = 0; p < n; ++p) { served[p] = std::min<u64>(c->cnt_host[p], c->capL); mx = std::max(mx, served[p]); }
+        for (u32 p = 0; p < n; ++p) { served[p] = std::min<u64>(served[p], c->capL); mx = std::max(mx, served[p]); }
         rc = shard_exchange_counts(c, served.data(), coming.data(), st); if (rc) return rc;
         for (u32 p = 0; p < n; ++p) { sbytes[p] = served[p] * c->locb; rbytes[p] = coming[p] * c->locb; mx = std::max(mx, coming[p]); }
         if (alias) c->xb_self += sbytes[0];

@@ -64,3 +64,23 @@ def batch_subtable(eng, db, bases_ptr, seq_off_ptr, n_seqs, device, tgt_windows=
     off[1:] = np.cumsum(lens_s)
     idx = np.repeat(starts[order] - off[:-1].astype(np.int64), lens_s) + np.arange(int(off[-1]), dtype=np.int64)
     return np.ascontiguousarray(keys_s), off, np.ascontiguousarray(locs_h[idx])
+
+
+def merge_subtables(tables):
+    """Sub-tables of the same read set read back from the hash-range shards of one table (keys disjoint by construction) ->
+    one (keys, list_off, locs) for the oracle."""
+    keys = np.concatenate([t[0] for t in tables])
+    lens = np.concatenate([np.diff(t[1].astype(np.int64)) for t in tables])
+    base, starts = 0, []
+    for t in tables:
+        starts.append(t[1][:-1].astype(np.int64) + base)
+        base += int(t[1][-1])
+    starts = np.concatenate(starts)
+    locs = np.concatenate([t[2] for t in tables])
+    assert len(np.unique(keys)) == len(keys), "a feature came back from two shards"
+    order = np.argsort(keys, kind="stable")
+    keys_s, lens_s = keys[order], lens[order]
+    off = np.zeros(len(keys) + 1, np.uint64)
+    off[1:] = np.cumsum(lens_s)
+    idx = np.repeat(starts[order] - off[:-1].astype(np.int64), lens_s) + np.arange(int(off[-1]), dtype=np.int64)
+    return np.ascontiguousarray(keys_s.astype(np.uint32)), off, np.ascontiguousarray(locs[idx].astype(np.uint64))

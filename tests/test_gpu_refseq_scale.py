@@ -1,6 +1,11 @@
 """BASELINE.json configs[2] at its stated scale, on ONE GPU: the RefSeq-scale table (a file of its own: the other modules'
 fixtures -- tens of GB of tables -- are gone when it runs)."""
+import glob
 import importlib
+import os
+import subprocess
+import sys
+import tempfile
 
 import numpy as np
 import pytest
@@ -9,6 +14,7 @@ import torch
 from oracle import mc_oracle as orc
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _compare(cands, ncand, oc, on, what):
@@ -64,4 +70,41 @@ def test_config2_refseq_scale_table_on_one_gpu():
         _compare(cands.cpu().numpy().view(np.uint32), ncand.cpu().numpy().view(np.uint32), oc, on, "configs[2] shape on one GPU, paired=%d" % paired)
         assert stats["n_locations"] > 500 * nq and stats["n_two_class"] > nq // 2, stats        # ~900 locations per read: the two-class tails
         ws.close()
+        # ... and through the path that runs this configuration on more than one GPU: mcq_shard_* (one rank: a rank's own blocks
+        # never travel), whose home side runs the SH instantiations of the two-class kernels on the lists the owner side served.
+        # No capacity is given: the exact mode sizes the location blocks by what this table delivers (~900 per read).
+        sh = eng.Shard(db, 1, 0, max_queries=nq, max_bases=rd.numel(), max_seqs=n_seqs)
+        for rep in range(2):            # exact (first batch of the context), then padded at the learned block sizes
+            cands.zero_(); ncand.zero_()
+            sh.query(rd.data_ptr(), ro_t.data_ptr(), n_seqs, paired, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+            sst = sh.sync(st)
+            _compare(cands.cpu().numpy().view(np.uint32), ncand.cpu().numpy().view(np.uint32), oc, on, "configs[2] through mcq_shard_*, paired=%d rep=%d" % (paired, rep))
+            assert sst["n_locations"] == stats["n_locations"] and sst["n_two_class"] > nq // 2, (sst, stats)
+        assert sh.caps()[1] > 500 * nq
+        sh.close()
     db.close()
+
+
+def test_config2_through_the_sharded_path_two_ranks():
+    """configs[2] as north_star runs it, rehearsed at world 2 on the one GPU of the box: the same RefSeq-scale table, one
+    feature-hash-range shard per rank (~38 GB each), mcq_shard_* with its blocks exchanged through gloo, every rank its own
+    150 bp reads and 2 x 150 bp pairs against the oracle on the sub-table read back from both shards (tests/shard_refseq_worker.py)."""
+    dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info(dev)[0] < 250e9:
+        pytest.skip("needs 250 GB of free HBM")
+    with tempfile.TemporaryDirectory() as d:
+        outp = os.path.join(d, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29981", os.path.join(ROOT, "tests", "shard_refseq_worker.py"), outp]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+        assert r.returncode == 0, r.stdout[-3000:]
+        files = sorted(glob.glob(outp + ".[0-9].npz"))
+        assert len(files) == 2
+        for f in files:
+            z = np.load(f)
+            assert bool(z["ok"][0]), f
+            for nq, n_locs, n_two, n_ovf in z["res"]:
+                assert n_locs > 500 * nq and n_two > nq // 2, (f, z["res"])
+            assert z["xb"][3] > 0            # locations travelled to the other rank

@@ -419,3 +419,27 @@ def test_two_class_tail_on_chance_hits():
     # lists the second wave stage could not prove go on to the front queue with their probe results (the third stage reads
     # them from the slot's row): that hand-over must have happened here
     assert retries > 0
+    # The same reads through the sharded path's home side (mcq_shard_* at one rank: the SH instantiations of the second and third
+    # wave stage and of the two-class workgroup kernel, which get their probe results from the exchange instead of the
+    # hand-over rows): same answers, and most reads through the tail there too.
+    import torch
+    dev = torch.device("cuda", 0)
+    st_ = torch.cuda.current_stream(dev).cuda_stream
+    d_rb = torch.frombuffer(bytearray(rb), dtype=torch.uint8).to(dev)
+    d_ro = torch.from_numpy(ro.astype(np.int64)).to(dev)
+    for dbflags in (0, eng.MCQ_DB_LOCS_GW):
+        db = eng.Database(keys, off, locs, t2t, flags=dbflags)
+        for paired in (False, True):
+            nq = n // 2 if paired else n
+            sh = eng.Shard(db, 1, 0, max_queries=nq, max_bases=n * L, max_seqs=n)
+            for P, M in ((2, 2), (4, 4)):
+                oc, on = odb.query(rb, ro, paired, max_cand=M, emulate_ranks=P, threads=8)
+                for rep in range(2):            # exact mode (first batch of the context), then padded
+                    cands = torch.zeros((nq, M, 4), dtype=torch.int32, device=dev); ncand = torch.zeros(nq, dtype=torch.int32, device=dev)
+                    sh.query(d_rb.data_ptr(), d_ro.data_ptr(), n, paired, cands.data_ptr(), ncand.data_ptr(), max_cand=M, emulate_ranks=P, stream=st_)
+                    st = sh.sync(st_)
+                    _compare(cands.cpu().numpy().view(np.uint32), ncand.cpu().numpy().view(np.uint32), oc, on,
+                             "two-class under Shard dbflags=%x paired=%d P=%d M=%d rep=%d" % (dbflags, paired, P, M, rep))
+                    assert st["n_two_class"] > nq // 2, st
+            sh.close()
+        db.close()

@@ -89,12 +89,34 @@ def test_capacity_errors_are_reported(world1):
     n, L = 20000, 150
     r, ro, _ = synth.sample_reads(gb, goff, n, L, 0.01, 0.002, seed=77)
     cands = torch.zeros((n, 2, 4), dtype=torch.int32, device=dev); ncand = torch.zeros(n, dtype=torch.int32, device=dev)
-    # location blocks far too small for the batch
+    oc, on = odb.query(r.cpu().numpy().tobytes(), ro.cpu().numpy().astype(np.uint64), False, max_cand=2, emulate_ranks=2, threads=8)
+    # location blocks given far too small: the first batch of a context is exact, and the exact mode sizes the blocks by what the
+    # table serves (r04; until then: MCQ_E_CAPACITY)
     sh = eng.Shard(db, 1, 0, max_queries=n, max_bases=n * L, max_locations_per_peer=4096)
-    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), stream=st)
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+    sh.sync(st)
+    _same(cands, ncand, oc, on, "blocks grown by the exact mode")
+    assert sh.caps()[1] > 4096
+    sh.close()
+    # blocks learned from a small batch, then a batch ten times as large in the padded mode: reported; its exact repeat grows them
+    sh = eng.Shard(db, 1, 0, max_queries=n, max_bases=n * L)
+    small = n // 10
+    c2 = torch.zeros((small, 2, 4), dtype=torch.int32, device=dev); n2 = torch.zeros(small, dtype=torch.int32, device=dev)
+    sh.query(r.data_ptr(), ro.data_ptr(), small, False, c2.data_ptr(), n2.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
+    sh.sync(st)
+    _same(c2, n2, oc[:small], on[:small], "small first batch")
+    learned = sh.caps()
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)
     with pytest.raises(eng.McqError) as e:
         sh.sync(st)
     assert e.value.code == eng.MCQ_E_CAPACITY
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st, exact=True)
+    sh.sync(st)
+    _same(cands, ncand, oc, on, "exact repeat after a padded overflow")
+    assert sh.caps()[0] > learned[0] and sh.caps()[1] > learned[1]
+    sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st)     # padded again, at the new sizes
+    sh.sync(st)
+    _same(cands, ncand, oc, on, "padded mode at the grown sizes")
     sh.close()
     # padded blocks smaller than the batch needs: reported, and the exact mode then answers correctly
     sh = eng.Shard(db, 1, 0, max_queries=n, max_bases=n * L)
@@ -105,7 +127,6 @@ def test_capacity_errors_are_reported(world1):
     assert e.value.code == eng.MCQ_E_CAPACITY
     sh.query(r.data_ptr(), ro.data_ptr(), n, False, cands.data_ptr(), ncand.data_ptr(), max_cand=2, emulate_ranks=2, stream=st, exact=True)
     sh.sync(st)
-    oc, on = odb.query(r.cpu().numpy().tobytes(), ro.cpu().numpy().astype(np.uint64), False, max_cand=2, emulate_ranks=2, threads=8)
     _same(cands, ncand, oc, on, "exact mode after a capacity error")
     sh.close()
     # a batch with more windows than max_bases was given for: reported, nothing written or read out of bounds
