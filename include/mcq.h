@@ -63,7 +63,8 @@ enum {
     MCQ_NO_WAVE16 = 0x800u,        /* test hook: queries of 513..1024 locations take the workgroup path
                                       instead of the second wave stage                     */
     MCQ_NO_TWO_CLASS = 0x4000u,    /* test hook: long match lists are sorted whole instead of taking the two-class tail
-                                      (light / heavy locations: DESIGN.md section 4); same results either way            */
+                                      (light / heavy locations: DESIGN.md section 4) or, in the workgroup kernel, the counting
+                                      tail (window histograms: DESIGN.md section 11); same results either way              */
     MCQ_FOLD_BY_LISTS = 0x8000u,   /* test hook: emulate_ranks > 1 builds the P bounded lists and folds them level by level (the form
                                       MCQ_QUIRK_SEQ_DROP needs on a table with sequence-level taxa) instead of the one selection
                                       in the order (hits, rank, position) that gives the same list        */
@@ -190,6 +191,8 @@ typedef struct {
     uint64_t n_narrow_queued;   /* queries with narrow window ranges (short reads, pairs) counted in the workgroup kernels' queue:
                                    from 4096 on they get the workgroup kernel with the two-class tail (an upper bound: an
                                    entry may be counted twice)                                            */
+    uint64_t n_counted;         /* queries the workgroup kernel answered by counting (window histograms of the cells a long
+                                   read's locations cluster in) instead of sorting its match list  */
 } mcq_stats;
 
 /* replaces sketch_database::read -> hash_multimap::deserialize (the table build) */

@@ -57,42 +57,38 @@ static bool read_records(const std::string& path, std::vector<Rec>& out) {
     return true;
 }
 
-// taxon_print_mode (src/query_options.h:68-71)
-enum class Mode { rank_id, rank_name, rank_name_id, id, name, name_id };
+// How a taxon is written (the reference's taxon_print_mode, src/query_options.h:68-71; output of src/printing.cpp:117-176,
+// :243-300) as two independent choices: an optional "<rank>:" prefix, and one of three bodies -- name, id, name(id).
+struct Mode {
+    bool rank_prefix; int body;                          // body: 0 = name, 1 = id, 2 = name(id)
+    static constexpr Mode make(bool show_ranks, bool taxids, bool taxids_only) { return Mode{show_ranks, taxids_only ? 1 : (taxids ? 2 : 0)}; }
+    bool ids_only() const { return body == 1; }
+};
 
 struct Out {
     mcq_refdb* db;
-    Mode mode = Mode::rank_name;
+    Mode mode = Mode{true, 0};
     uint32_t lowest = MCQ_RANK_SEQUENCE, highest = MCQ_RANK_DOMAIN;
     bool lineage = false, tophits = false;
     const char* comment = "# "; const char* none = "--"; const char* col = "\t|\t";
 
-    void taxon(std::ostream& os, uint32_t key) const {                       // show_taxon, src/printing.cpp:117-146
-        switch (mode) {
-            default:
-            case Mode::rank_name: os << mcq_rank_name(mcq_refdb_taxon_rank(db, key)) << ':';     // fall through
-            case Mode::name: os << mcq_refdb_taxon_name(db, key); break;
-            case Mode::rank_id: os << mcq_rank_name(mcq_refdb_taxon_rank(db, key)) << ':';       // fall through
-            case Mode::id: os << mcq_refdb_taxon_id(db, key); break;
-            case Mode::rank_name_id: os << mcq_rank_name(mcq_refdb_taxon_rank(db, key)) << ':';  // fall through
-            case Mode::name_id: os << mcq_refdb_taxon_name(db, key) << '(' << mcq_refdb_taxon_id(db, key) << ')'; break;
-        }
+    // one taxon column entry: [prefix ':'] body, the body built from a name text and an id text
+    template <class Name, class Id>
+    void entry(std::ostream& os, const char* prefix, const Name& name, const Id& id) const {
+        if (mode.rank_prefix) os << prefix << ':';
+        if (mode.body != 1) os << name;
+        if (mode.body == 2) os << '(';
+        if (mode.body != 0) os << id;
+        if (mode.body == 2) os << ')';
     }
-    void no_taxon(std::ostream& os, uint32_t rank) const {                   // show_no_taxon, src/printing.cpp:151-176
-        switch (mode) {
-            default:
-            case Mode::rank_name: os << mcq_rank_name(rank) << ':';          // fall through
-            case Mode::name: os << none; break;
-            case Mode::rank_id: os << mcq_rank_name(rank) << ':';            // fall through
-            case Mode::id: os << 0; break;
-            case Mode::rank_name_id: os << mcq_rank_name(rank) << ':';       // fall through
-            case Mode::name_id: os << none << '(' << 0 << ')'; break;
-        }
+    void taxon(std::ostream& os, uint32_t key) const {
+        entry(os, mcq_rank_name(mcq_refdb_taxon_rank(db, key)), mcq_refdb_taxon_name(db, key), mcq_refdb_taxon_id(db, key));
     }
+    void no_taxon(std::ostream& os, uint32_t rank) const { entry(os, mcq_rank_name(rank), none, 0); }
     // classification column: show_taxon(os, db, opt, tax), src/printing.cpp:305-330 (collapseUnclassified is on)
     void best(std::ostream& os, uint32_t key) const {
         if (key == MCQ_NO_TAXON || mcq_refdb_taxon_rank(db, key) > highest) {
-            if (mode == Mode::id) os << 0; else os << none;
+            if (mode.ids_only() && !mode.rank_prefix) os << 0; else os << none;
             return;
         }
         const uint32_t tr = mcq_refdb_taxon_rank(db, key);
@@ -103,19 +99,10 @@ struct Out {
             if (r < rmax) os << ',';
         }
     }
-    void header_taxon(std::ostream& os) const {                              // show_taxon_header, src/printing.cpp:243-300
+    void header_taxon(std::ostream& os) const {          // the TABLE_LAYOUT line's taxon column: one entry per rank shown
         const uint32_t rmax = lineage ? highest : lowest;
         for (uint32_t r = lowest; r <= rmax; ++r) {
-            const bool one = lowest == rmax;
-            switch (mode) {
-                default:
-                case Mode::rank_name: os << (one ? "rank" : mcq_rank_name(r)) << ':';       // fall through
-                case Mode::name: os << "taxname"; break;
-                case Mode::rank_id: os << (one ? "rank" : mcq_rank_name(r)) << ':';         // fall through
-                case Mode::id: os << "taxid"; break;
-                case Mode::rank_name_id: os << (one ? "rank" : mcq_rank_name(r)) << ':';    // fall through
-                case Mode::name_id: os << "taxname(taxid)"; break;
-            }
+            entry(os, lowest == rmax ? "rank" : mcq_rank_name(r), "taxname", "taxid");
             if (r < rmax) os << ',';
         }
     }
@@ -166,9 +153,7 @@ static bool parse_options(int argc, char** argv, Options& o) {
 
 static Out make_out(mcq_refdb* rdb, const Options& p) {
     Out o; o.db = rdb; o.lowest = p.lowest; o.highest = p.highest; o.lineage = p.lineage; o.tophits = p.tophits;
-    if (p.taxids_only) o.mode = p.show_ranks ? Mode::rank_id : Mode::id;     // src/query_options.cpp:262-274
-    else if (p.taxids) o.mode = p.show_ranks ? Mode::rank_name_id : Mode::name_id;
-    else o.mode = p.show_ranks ? Mode::rank_name : Mode::name;
+    o.mode = Mode::make(p.show_ranks, p.taxids, p.taxids_only);          // -taxids-only wins over -taxids (src/query_options.cpp:262-274)
     return o;
 }
 

@@ -75,7 +75,7 @@ class Result(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("n_features", C.c_uint64), ("n_hit_features", C.c_uint64),
-                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64), ("n_two_class", C.c_uint64), ("n_two_class_retry", C.c_uint64), ("n_narrow_queued", C.c_uint64)]
+                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64), ("n_two_class", C.c_uint64), ("n_two_class_retry", C.c_uint64), ("n_narrow_queued", C.c_uint64), ("n_counted", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
