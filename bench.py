@@ -372,11 +372,13 @@ def main():
 
     # ---- leg 1: fused kernel on the full table: THE path at N=1; "replicas only" (reads split, no collective) at N>1
     fused_elapsed, st, kms, kn = None, None, None, 0
+    phase_clocks = None
     if with_fused:
         fused_elapsed = timed(step_fused, lambda: ws.timing(True))
         st = ws.sync()
         kms, kn = ws.kernel_times()
         ws.timing(False)
+        phase_clocks = ws.phase_clocks()
 
     # (state of the sharded leg; roofline() / make_line() are defined BEFORE that leg so that its watchdog can print a line)
     sharded_elapsed, sharded_error, sh_stats, sh_kms, sh_kn, sharded_ok = None, None, None, None, 0, None
@@ -576,6 +578,8 @@ def main():
         dog.cancel()
 
     out = make_line(mode, sharded_elapsed, sharded_error)
+    if phase_clocks and any(phase_clocks):
+        out["DIAGNOSTIC_phase_clocks_of_the_workgroup_kernel"] = phase_clocks
     if a.stop_stage:
         out["INVALID_profiling_stop_stage"] = a.stop_stage
     if world == 1 and mode == "single" and a.workload == "c2" and not a.stop_stage and not a.small and not a.no_pcie_leg:

@@ -455,6 +455,9 @@ const char* mcq_build_last_error(void);
 int mcq_debug_matches(const mcq_db* db, mcq_ws* ws, const mcq_batch* in, uint32_t path_flags,
                       uint64_t* match_off /* host [n_queries+1] */, uint64_t* matches /* host */, uint64_t cap);
 
+/* diagnostic builds only (-DMCQ_PHASE_CLOCK): shader clocks per phase of the workgroup kernel of the last synchronised call */
+int mcq_debug_phase_clocks(mcq_ws* ws, uint64_t* out /* [22] */);
+
 const char* mcq_last_error(void);
 const char* mcq_version(void);
 

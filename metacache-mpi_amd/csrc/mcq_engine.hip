@@ -1326,6 +1326,13 @@ __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, O
 }
 
 // ------------------------------------------------------------------ kernel: workgroup per query
+// -DMCQ_PHASE_CLOCK (diagnostic builds only): thread 0 of every workgroup adds the shader clocks between the phase marks of the
+// workgroup kernel into 24 words of LDS, folded into CountersDev::pad_ when the kernel ends (mcq_debug_phase_clocks).
+#ifdef MCQ_PHASE_CLOCK
+#define PHCLK(ph, i) do { if (threadIdx.x == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); (ph)[i] += t_ - (ph)[23]; (ph)[23] = t_; } } while (0)
+#else
+#define PHCLK(ph, i) do { } while (0)
+#endif
 // exclusive scan of a[0..n) in place by the whole workgroup; returns the total
 __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w /* >= 18 words */) {
     const u32 NTB = blockDim.x;
@@ -1501,7 +1508,7 @@ __device__ __forceinline__ int block_two_class(const DbDev& db, const OptDev& op
 #define MCQ_CT_ENT 2048u                // entries at most
 template <int LCAPB, class LF, class Fill>
 __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr, u32* Bw, u32* HW, u32 T,
-                                                 u32 numWindows, const LF& lf, u64 q, u32 tid, u32* s_x /* 12 words */, Fill fill, bool& filled) {
+                                                 u32 numWindows, const LF& lf, u64 q, u32 tid, u32* s_x /* 12 words */, Fill fill, bool& filled, u64* ph) {
     static_assert(LCAPB == 8192, "segments of 8192 words");
     const u32 NTB = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = NTB >> 6;
     const u32 cs = cell_shift(numWindows);
@@ -1516,6 +1523,7 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
     if (tid < 12) s_x[tid] = 0;
     if (tid == 0) s_gm = 0;
     __syncthreads();
+    PHCLK(ph, 3);
     // ---- 1. cells of the words
     u32 myslot[2] = {0, 0};                                     // slots of this thread's (at most four) words, 16 bits each
     bool crowded = false;
@@ -1542,6 +1550,7 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
     if (lane == 63 && claimed) atomicAdd(&s_x[8], claimed);
     if (__ballot(crowded) && lane == 0) s_x[2] = 1;
     __syncthreads();
+    PHCLK(ph, 4);
     if (s_x[2] || s_x[8] > MCQ_CT_SLOTS * 3 / 4) return false;  // too many distinct cells (uniform; the searches below need empty slots)
     // ---- 2. active cells, their bin blocks; words outside them are entries of their own
     auto find = [&](u32 cell) -> u32 {                          // slot of a cell, MCQ_EMPTY when absent
@@ -1553,6 +1562,7 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
             h = (h + 1) & (MCQ_CT_SLOTS - 1);
         }
     };
+    u32* RS = HW + MCQ_CT_BINS; u32* RC = RS + MCQ_CT_RES;      // per active cell: its cell (from here on), its best range (step 4)
     u32 act[2] = {0, 0};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1569,7 +1579,8 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
         if (lane == 0) { if (ba) base = atomicAdd(&s_x[0], (u32)__builtin_popcountll(ba)); if (bl) atomicAdd(&s_x[1], (u32)__builtin_popcountll(bl)); }
         base = bcast(base, 0);
         act[i] = active ? (0x80000000u | (base + lane_rank(ba))) : 0u;
-    }
+        if (active && base + lane_rank(ba) < MCQ_CT_RES) RC[base + lane_rank(ba)] = c;      // the list of active cells (the match list is in place: the
+    }                                                                                        // feature arrays that lived here are no longer needed)
     __syncthreads();                                            // (every count has been read)
 #pragma unroll
     for (int i = 0; i < 2; ++i) { const u32 sidx = tid + (u32)i * 1024u; if (CK[sidx] != MCQ_EMPTY) CV[sidx] = act[i]; }
@@ -1581,6 +1592,7 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
         for (u32 i = tid; i < nA * WPC; i += NTB) HW[i] = zero;
     }
     __syncthreads();
+    PHCLK(ph, 5);
     // ---- 3. histograms of the active cells
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1591,17 +1603,15 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
         }
     }
     __syncthreads();
-    // ---- 4. per active cell the best range that ends in it: waves over the table's slots
-    u32* RS = HW + MCQ_CT_BINS; u32* RC = RS + MCQ_CT_RES;      // results: hits << 16 | window inside the cell; the cell
+    PHCLK(ph, 6);
+    // ---- 4. per active cell the best range that ends in it: one wave per cell
     {
         const u32 BL = BPC >= 32 ? BPC >> 5 : 1u;               // consecutive bins per lane over [cell before | cell]
         const u32 nws = (2048u / BPC) < nwv ? (2048u / BPC) : nwv;            // waves with a scratch segment of 2 x BPC u16
         unsigned short* S = reinterpret_cast<unsigned short*>(HW + MCQ_CT_BINS + 2 * MCQ_CT_RES) + (size_t)wv * 2 * BPC;
         const unsigned short* bins16 = reinterpret_cast<const unsigned short*>(HW);
-        if (wv < nws) for (u32 sidx = wv; sidx < MCQ_CT_SLOTS; sidx += nws) {
-            const u32 v = CV[sidx];
-            if (!(v & 0x80000000u)) continue;                   // (wave-uniform)
-            const u32 id = v & 0x7FFFFFFFu, c = CK[sidx];
+        if (wv < nws) for (u32 id = wv; id < nA; id += nws) {
+            const u32 c = RC[id];
             u32 idp = MCQ_EMPTY;
             if ((c & ((1u << tshift) - 1)) != 0) { const u32 sp = find(c - 1); if (sp != MCQ_EMPTY) idp = CV[sp] & 0x7FFFFFFFu; }
             const u32 x0 = lane * BL;                           // this lane's first index in [0, 2 BPC)
@@ -1630,11 +1640,12 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
                     best = pk > best ? pk : best;
                 }
             best = wave_max_u32(best);
-            if (lane == 0) { RS[id] = (best & 0xFFFF0000u) | (0xFFFFu - (best & 0xFFFFu)); RC[id] = c; }
+            if (lane == 0) RS[id] = (best & 0xFFFF0000u) | (0xFFFFu - (best & 0xFFFFu));      // hits << 16 | window inside the cell
             wave_sync();
         }
     }
     __syncthreads();
+    PHCLK(ph, 7);
     // ---- 5. entries: (hits << 6 | 63 - rank) << 32 | ~word and the taxon
     const u32 M = opt.max_cand;
     unsigned long long* EW = reinterpret_cast<unsigned long long*>(HW);           // [MCQ_CT_ENT] over the dead bins
@@ -1660,6 +1671,7 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
         if (lone) put(nA + base + lane_rank(bl), Bw[t], 1u);
     }
     __syncthreads();
+    PHCLK(ph, 8);
     const u32 NE = nA + nL;
     // ---- 6. rows 10-11: M rounds of "largest entry, record it, retire its taxon"
     unsigned long long* gm = &s_gm;
@@ -1685,6 +1697,7 @@ __device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& 
     if (tid < n) reinterpret_cast<uint4*>(out.cands)[q * M + tid] = make_uint4(res[tid], res[16 + tid], 0u, 0u);     // no window ranges after a fold
     if (tid == 0) { out.ncand[q] = n; atomicAdd(&ctr->n_cands, (unsigned long long)n); atomicAdd(&ctr->n_counted, 1ull); }
     __syncthreads();
+    PHCLK(ph, 9);
     return true;
 }
 
@@ -1726,6 +1739,15 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     // The queue entries of this workgroup's next 64 visits are fetched at once: most entries are empty when the wave stages
     // have answered them (a RefSeq-scale batch of pairs: 99 %), and one dependent load per visit was 0.5 ms per kernel there.
     __shared__ u32 s_q[64];
+#ifdef MCQ_PHASE_CLOCK
+    __shared__ u64 s_ph[24];
+    if (tid < 24) s_ph[tid] = 0;
+    __syncthreads();
+    if (tid == 0) s_ph[23] = __builtin_amdgcn_s_memtime();
+    u64* const ph = s_ph;
+#else
+    u64* const ph = nullptr;
+#endif
     for (u32 it0 = blockIdx.x; it0 < n_ovf; it0 += gridDim.x * 64u) {
     __syncthreads();                                   // (the entries of the visits before are consumed)
     if (tid < 64) { const u64 it = (u64)it0 + (u64)tid * gridDim.x; s_q[tid] = it < n_ovf ? ovf_list[ovf_visit((u32)it, n_ovf)] : MCQ_EMPTY; }
@@ -1756,6 +1778,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         u64* foff = f_lds ? reinterpret_cast<u64*>(s_hits + 4096) : g_foff;
         if (tid == 0) { s_w[18] = 0; s_w[19] = 0; }
         __syncthreads();
+        PHCLK(ph, 0);
         if constexpr (!SH) {
         for (u32 w = wave; w < (u32)NW; w += NW16) {
             const bool m2 = w >= nw1;
@@ -1772,6 +1795,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         }
         __syncthreads();
         }
+        PHCLK(ph, 1);
         const u32 F = SH ? (u32)(NW * db.s) : s_w[18];     // sharded: every feature slot of the query (unused ones have no list)
         u32 nhit = 0;
         for (u32 i = tid; i < F; i += NT) {
@@ -1784,6 +1808,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         if (lane == 63 && nhit) atomicAdd(&s_w[19], nhit);
         __syncthreads();
         const u32 T = block_excl_scan(fpos, F, tid, s_w);
+        PHCLK(ph, 2);
         if (tid == 0) {
             if (!SH) atomicAdd(&ctr->n_features, (unsigned long long)F);
             atomicAdd(&ctr->n_locations, (unsigned long long)T);
@@ -1865,14 +1890,18 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             // rows 8-11 by counting (block_count_tail): one selection, bit-field words, the plain kernel (long reads live here)
             if constexpr (!TC && BIG == 2 && !GW && sizeof(KeyT) == 4) {
                 if (dbg.mode == 0 && !(opt.hooks & 8u))
-                    done = block_count_tail<LCAPB>(db, opt, out, ctr, reinterpret_cast<u32*>(s_buf), s_hits, T, numWindows, lf, q, tid, s_w, fill, filled);
+                    done = block_count_tail<LCAPB>(db, opt, out, ctr, reinterpret_cast<u32*>(s_buf), s_hits, T, numWindows, lf, q, tid, s_w, fill, filled, ph);
             }
 #endif
-            if (!done) block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill, filled);
+            if (!done) { block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill, filled); PHCLK(ph, 10); }
         }
         else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
     }
     }
+#ifdef MCQ_PHASE_CLOCK
+    __syncthreads();
+    if (tid < 22 && s_ph[tid]) atomicAdd(&ctr->pad_[tid], (unsigned long long)s_ph[tid]);
+#endif
 }
 
 // ------------------------------------------------------------------ staged kernels (sharded path, DB build)
@@ -3103,6 +3132,14 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
     }
     if (ws->ctr_host->err_count)
         return fail(MCQ_E_CAPACITY, std::to_string(ws->ctr_host->err_count) + " queries exceeded the workspace's per-query capacity");
+    return MCQ_OK;
+}
+
+// diagnostic builds (-DMCQ_PHASE_CLOCK): shader clocks per phase of the workgroup kernel, summed over its workgroups, of the last call
+// synchronised by mcq_ws_sync (zeros in a normal build)
+extern "C" int mcq_debug_phase_clocks(mcq_ws* ws, uint64_t* out22) {
+    if (!ws || !out22) return fail(MCQ_E_ARG, "null argument");
+    for (int i = 0; i < 22; ++i) out22[i] = ws->ctr_host->pad_[i];
     return MCQ_OK;
 }
 

@@ -344,6 +344,12 @@ class Workspace:
         _chk(lib().mcq_ws_kernel_time(self.h, C.byref(ms), C.byref(n)))
         return ms.value, int(n.value)
 
+    def phase_clocks(self):
+        """diagnostic builds (-DMCQ_PHASE_CLOCK): shader clocks per phase of the workgroup kernel of the last synchronised call"""
+        out = (C.c_uint64 * 22)()
+        _chk(lib().mcq_debug_phase_clocks(self.h, out))
+        return [int(x) for x in out]
+
     def kernel_times(self):
         """(ms of first wave stage, second wave stage, workgroup kernel summed over the timed batches; n batches)"""
         ms, n = (C.c_double * 3)(), C.c_uint64(0)
