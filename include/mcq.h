@@ -63,8 +63,7 @@ enum {
     MCQ_NO_WAVE16 = 0x800u,        /* test hook: queries of 513..1024 locations take the workgroup path
                                       instead of the second wave stage                     */
     MCQ_NO_TWO_CLASS = 0x4000u,    /* test hook: long match lists are sorted whole instead of taking the two-class tail
-                                      (light / heavy locations: DESIGN.md section 4) or, in the workgroup kernel, the counting
-                                      tail (window histograms: DESIGN.md section 11); same results either way              */
+                                      (light / heavy locations: DESIGN.md section 4); same results either way            */
     MCQ_FOLD_BY_LISTS = 0x8000u,   /* test hook: emulate_ranks > 1 builds the P bounded lists and folds them level by level (the form
                                       MCQ_QUIRK_SEQ_DROP needs on a table with sequence-level taxa) instead of the one selection
                                       in the order (hits, rank, position) that gives the same list        */
@@ -191,8 +190,6 @@ typedef struct {
     uint64_t n_narrow_queued;   /* queries with narrow window ranges (short reads, pairs) counted in the workgroup kernels' queue:
                                    from 4096 on they get the workgroup kernel with the two-class tail (an upper bound: an
                                    entry may be counted twice)                                            */
-    uint64_t n_counted;         /* queries the workgroup kernel answered by counting (window histograms of the cells a long
-                                   read's locations cluster in) instead of sorting its match list  */
 } mcq_stats;
 
 /* replaces sketch_database::read -> hash_multimap::deserialize (the table build) */
@@ -443,6 +440,32 @@ int mcq_parts_info(const mcq_parts* parts, uint64_t* n_keys, uint64_t* n_locs, u
 /* tgt2tax: [n_targets] host, or device with MCQ_DEVICE_PTRS in flags; flags also takes MCQ_DB_SLOTS_16 / MCQ_DB_BUCKETS_64 */
 int mcq_db_from_parts(const mcq_parts* parts, const uint32_t* tgt2tax, uint32_t n_shards, uint32_t shard_id, uint32_t flags, mcq_db** out);
 int mcq_parts_free(mcq_parts* parts);
+
+/* ---- parts from streamed (feature, target, window) triples: a table of any size from the REFERENCE'S OWN shard files --------
+ * (row f1 at scale: sketch_database::read + hash_multimap::deserialize, src/sketch_database.h:858-952, src/hash_multimap.h:923-964,
+ * without the host-side union of mcq_refdb_open -- 16 B per location and a sort on the host: 240 GB for a RefSeq build.)
+ * The host library streams every shard file as chunks of triples (include/mcq_host.h: mcq_refdb_open_meta, mcq_shard_stream_*);
+ * mcq_parts_builder_add takes a chunk (host pointers, or device with MCQ_DEVICE_PTRS), turns (target, window) into the global
+ * window index of tgt_windows' prefix sums on the GPU and appends the (feature, word) pairs of this shard's features to the buffer
+ * of their feature-hash range; mcq_parts_builder_finish sorts every range -- the merge of the reference's P per-rank lists of a
+ * feature into (target, window) order -- and leaves the parts mcq_db_from_parts takes (the builder is released).  Chunks may
+ * come in any order, from any number of files.  Device memory at the peak: 8 B per location of this shard + ~30 B per location
+ * of one range.                                                                                                          */
+typedef struct {
+    uint32_t k, sketch_size, winlen, winstride;   /* what QUERIES are sketched with (the q_* fields of mcq_refdb_info)      */
+    uint32_t tgt_winstride;                       /* window stride of the targets (0 = winstride)                           */
+    uint32_t n_targets;
+    const uint32_t* tgt_windows;                  /* host [n_targets]: mcq_refdb_tgt_windows                                */
+    uint64_t expected_locations;                  /* of the WHOLE table (sum of the shard files' location counts): sizes the ranges */
+    uint32_t n_ranges;                            /* 0 = from expected_locations and the free memory                        */
+    uint32_t n_shards, shard_id;                  /* as in mcq_db_desc: only this shard's features are kept                 */
+    int32_t device;
+} mcq_parts_builder_desc;
+typedef struct mcq_parts_builder mcq_parts_builder;
+int mcq_parts_builder_create(const mcq_parts_builder_desc* desc, mcq_parts_builder** out);
+int mcq_parts_builder_add(mcq_parts_builder* b, const uint32_t* feat, const uint32_t* tgt, const uint32_t* win, uint64_t n, uint32_t flags);
+int mcq_parts_builder_finish(mcq_parts_builder* b, mcq_parts** out);
+int mcq_parts_builder_free(mcq_parts_builder* b);
 const char* mcq_build_last_error(void);
 
 /* ---- debug / parity taps ------------------------------------------------------------

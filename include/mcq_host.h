@@ -13,6 +13,7 @@
  *                       ranked_lca()                      src/taxonomy.h:531-537
  *   mcq_rank_from_name  taxonomy::rank_from_name          src/taxonomy.h:173-213
  *   mcq_refdb_write_shard  sketch_database::write         src/sketch_database.h:959-998
+ *   mcq_refdb_open_meta + mcq_shard_stream_*   the same reader, streaming (no host-side table)
  *
  * A taxon *key* is the index of the taxon in the database's taxon list; bit 31 marks a
  * sequence-level taxon (rank Sequence), 0xFFFFFFFF is "no taxon".  These are the keys
@@ -70,6 +71,24 @@ int mcq_refdb_write_shard(const char* path, const mcq_shard_params* params, cons
 int mcq_refdb_open(const char* prefix, uint32_t n_ranks, mcq_refdb** out);
 int mcq_refdb_close(mcq_refdb* db);
 int mcq_refdb_get_info(const mcq_refdb* db, mcq_refdb_info* out);
+
+/* ---- the streaming route: shard files of any size (RefSeq scale: >= 1.5e10 locations) without a host-side union ----------
+ * mcq_refdb_open_meta reads only the head of every shard file -- parameters, taxa, target count (sketch_database::read up to
+ * the feature store, src/sketch_database.h:858-930) -- so that the taxon functions and classify work; info.n_keys stays 0,
+ * the table accessors return nothing.  mcq_shard_stream_* hands the key records of one file out in file order as chunks of
+ * (feature, target, window) triples (hash_multimap::deserialize, src/hash_multimap.h:923-964: per key {u32 key, u8 n, u64 n,
+ * u32 tgt[n], u64 n, u32 win[n]}), whole key records per chunk; mcq_refdb_tgt_windows gives the windows of every target (the
+ * taxon `windows` field of its owning rank) -- what turns (target, window) into a global window index.  The consumer is
+ * mcq_parts_builder_* of include/mcq.h: the ranks are merged per feature-hash range ON THE GPU.  Host memory: one 16 MB read
+ * buffer per open stream + the caller's chunk.                                                                            */
+int mcq_refdb_open_meta(const char* prefix, uint32_t n_ranks, mcq_refdb** out);
+int mcq_refdb_tgt_windows(const mcq_refdb* db, uint32_t* out /* [n_targets] */);
+int mcq_refdb_file_stats(const mcq_refdb* db, uint32_t rank, uint64_t* bytes, uint64_t* n_keys, uint64_t* n_locs);
+typedef struct mcq_shard_stream mcq_shard_stream;
+int mcq_shard_stream_open(const mcq_refdb* db /* from mcq_refdb_open_meta */, uint32_t rank, mcq_shard_stream** out);
+/* up to `cap` (>= 255) locations into feat / tgt / win; *n = 0 when the file is exhausted */
+int mcq_shard_stream_next(mcq_shard_stream* s, uint32_t* feat, uint32_t* tgt, uint32_t* win, uint64_t cap, uint64_t* n);
+int mcq_shard_stream_close(mcq_shard_stream* s);
 
 /* union table in the layout mcq_db_desc wants; valid until mcq_refdb_close */
 const uint32_t* mcq_refdb_keys(const mcq_refdb* db);

@@ -1,6 +1,7 @@
 /* mcq_reference_binding.cpp -- see mcq_reference_binding.h.  Compiled against the reference's headers by
  * integration/Makefile in the build container; not part of libmcq_hip.so. */
 #include "mcq_reference_binding.h"
+#include "mcq_open.hpp"
 
 #include <algorithm>
 #include <map>
@@ -74,18 +75,17 @@ gpu_engine::gpu_engine(const mc::database& db, const std::string& shard_prefix, 
                        const mc::classification_options& opt, int device, std::uint64_t max_block_reads, std::uint64_t max_block_bases)
 : db_(db), opt_(opt), keys_(make_taxon_keys(db, opt.lowestRank))
 {
-    /* the shard files hold the tables in the reference's own serialisation; libmcq_host reads and unions them */
+    /* the shard files hold the tables in the reference's own serialisation: libmcq_host reads them -- unioned on the host when
+     * they are small, streamed to the GPU and merged there from 1 GB on (include/mcq_open.hpp) -- with the taxon keys of the
+     * reference's own database object */
     mcq_refdb* rdb = nullptr;
-    if (mcq_refdb_open(shard_prefix.c_str(), n_ranks, &rdb) != 0)
-        throw std::runtime_error(std::string("mcq_refdb_open: ") + mcq_host_last_error());
-    mcq_refdb_info info;
-    mcq_refdb_get_info(rdb, &info);
-    flat_table t;
-    t.keys.assign(mcq_refdb_keys(rdb), mcq_refdb_keys(rdb) + info.n_keys);
-    t.list_off.assign(mcq_refdb_list_off(rdb), mcq_refdb_list_off(rdb) + info.n_keys + 1);
-    t.locs.assign(mcq_refdb_locs(rdb), mcq_refdb_locs(rdb) + info.n_locs);
+    std::string err; bool streamed = false;
+    if (mcq_open_refdb(shard_prefix, n_ranks, mcq_stream_load_min_bytes(), &rdb, &streamed, err) != 0)
+        throw std::runtime_error("opening the shard files: " + err);
+    const int rc = mcq_make_db(rdb, streamed, keys_.tgt2tax.data(), 1, 0, device, &gdb_, err);
     mcq_refdb_close(rdb);
-    create(t, device, max_block_reads, max_block_bases);
+    if (rc != 0) throw std::runtime_error("making the GPU table: " + err);
+    check(mcq_ws_create(gdb_, max_block_reads, max_block_bases, 0, &ws_), "mcq_ws_create");
 }
 
 gpu_engine::gpu_engine(const mc::database& db, const flat_table& table, const mc::classification_options& opt,

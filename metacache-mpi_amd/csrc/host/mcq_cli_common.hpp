@@ -32,6 +32,7 @@
 
 #include "../../../include/mcq.h"
 #include "../../../include/mcq_host.h"
+#include "../../../include/mcq_open.hpp"
 
 struct Rec { std::string header, seq; };
 
@@ -234,20 +235,17 @@ static void write_summary(std::ostream& os, const Out& o, const Options& p, cons
     } else std::cerr << cm << "No valid query sequences found.\n";
 }
 
-// the reference's shard files -> table description for mcq_db_create (shard `shard_id` of `n_shards`)
-static bool open_database(const Options& p, mcq_refdb** rdb, std::vector<uint32_t>& t2t, mcq_db_desc& d, uint32_t& hitmin,
+// The reference's shard files -> the queryable handle of shard `shard_id` of `n_shards` (include/mcq_open.hpp: the host-side union
+// for small databases, the streaming route -- heads on the host, tables merged on the GPU -- from MCQ_STREAM_LOAD_MIN_MB, default
+// 1024, MB of shard files on)
+static bool open_database(const Options& p, mcq_refdb** rdb, std::vector<uint32_t>& t2t, mcq_db** edb, uint32_t& hitmin,
                           uint32_t n_shards, uint32_t shard_id, int device) {
-    if (mcq_refdb_open(p.prefix.c_str(), p.P, rdb)) { std::fprintf(stderr, "ABORT: %s\n", mcq_host_last_error()); return false; }
+    std::string err; bool streamed = false;
+    if (mcq_open_refdb(p.prefix, p.P, mcq_stream_load_min_bytes(), rdb, &streamed, err)) { std::fprintf(stderr, "ABORT: %s\n", err.c_str()); return false; }
     mcq_refdb_info info; mcq_refdb_get_info(*rdb, &info);
     hitmin = p.hitmin < 1 ? mcq_default_hits_min(info.sketch_size) : p.hitmin;
     t2t.resize(info.n_targets);
     if (mcq_refdb_tgt2tax(*rdb, p.lowest, t2t.data())) { std::fprintf(stderr, "ABORT: %s\n", mcq_host_last_error()); return false; }
-    std::memset(&d, 0, sizeof(d));
-    d.k = info.k; d.sketch_size = info.q_sketch_size; d.winlen = info.q_winlen; d.winstride = info.q_winstride;
-    d.tgt_winstride = info.winstride; d.n_targets = info.n_targets; d.n_keys = info.n_keys; d.n_locs = info.n_locs;
-    d.keys = mcq_refdb_keys(*rdb); d.list_off = mcq_refdb_list_off(*rdb); d.locs = mcq_refdb_locs(*rdb); d.tgt2tax = t2t.data();
-    d.n_shards = n_shards; d.shard_id = shard_id; d.flags = 0; d.device = device;
-    static const uint64_t zero_off[1] = {0};
-    if (!d.list_off) d.list_off = zero_off;
+    if (mcq_make_db(*rdb, streamed, t2t.data(), n_shards, shard_id, device, edb, err)) { std::fprintf(stderr, "ABORT: %s\n", err.c_str()); return false; }
     return true;
 }

@@ -44,7 +44,66 @@ struct mcq_refdb {
     std::unordered_map<int64_t, uint32_t> by_id;
     std::vector<uint32_t> lineage;          // n_taxa x 21, taxon indices or MCQ_NO_TAXON
     std::vector<uint32_t> keys; std::vector<uint64_t> off, locs;
+    // mcq_refdb_open_meta: no table in host memory; per shard file where its key records begin, how many there are
+    std::string prefix;
+    std::vector<uint64_t> table_pos, table_keys, table_locs, file_bytes;
+    std::vector<uint32_t> tgt_windows;      // windows of every target, from the rank that owns it
 };
+
+namespace {
+// sequential reader of one file through a fixed buffer (the streaming route never holds a shard file in memory)
+struct FileReader {
+    FILE* f = nullptr; std::vector<unsigned char> buf; size_t pos = 0, end = 0; bool ok = true; uint64_t consumed = 0;
+    explicit FileReader(size_t cap = 1u << 22) : buf(cap) {}
+    ~FileReader() { if (f) std::fclose(f); }
+    bool open(const std::string& path) { f = std::fopen(path.c_str(), "rb"); return f != nullptr; }
+    bool seek(uint64_t at) { pos = end = 0; consumed = at; return std::fseek(f, (long)at, SEEK_SET) == 0; }
+    bool fill(size_t need) {                 // makes `need` bytes available at buf[pos..)
+        if (end - pos >= need) return true;
+        if (need > buf.size()) buf.resize(need);
+        std::memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0;
+        while (end < need) {
+            const size_t n = std::fread(buf.data() + end, 1, buf.size() - end, f);
+            if (n == 0) return false;
+            end += n;
+        }
+        return true;
+    }
+    template <class T> T get() {
+        T v{};
+        if (!ok || !fill(sizeof(T))) { ok = false; return v; }
+        std::memcpy(&v, buf.data() + pos, sizeof(T)); pos += sizeof(T); consumed += sizeof(T);
+        return v;
+    }
+    const unsigned char* bytes(size_t n) {   // n bytes in place (valid until the next call)
+        if (!ok || !fill(n)) { ok = false; return nullptr; }
+        const unsigned char* p = buf.data() + pos; pos += n; consumed += n;
+        return p;
+    }
+    std::string str() {
+        const uint64_t n = get<uint64_t>();
+        if (!ok || n > (1u << 24)) { ok = false; return ""; }
+        const unsigned char* p = bytes((size_t)n);
+        return p ? std::string((const char*)p, (size_t)n) : std::string();
+    }
+};
+void build_lineages(mcq_refdb* db) {
+    // ranked lineages: walk the parents, record every ranked ancestor (incl. the taxon itself)
+    // at lineage[rank] (taxonomy::ranks, src/taxonomy.h:576-597)
+    for (uint32_t i = 0; i < db->taxa.size(); ++i) db->by_id[db->taxa[i].id] = i;
+    db->lineage.assign((size_t)db->taxa.size() * kNumRanks, MCQ_NO_TAXON);
+    for (uint32_t i = 0; i < db->taxa.size(); ++i) {
+        int64_t cur = db->taxa[i].id;
+        while (cur != 0) {
+            auto it = db->by_id.find(cur);
+            if (it == db->by_id.end()) break;
+            const Taxon& t = db->taxa[it->second];
+            if (t.rank < kNumRanks) db->lineage[(size_t)i * kNumRanks + t.rank] = it->second;
+            cur = (t.parent != cur) ? t.parent : 0;
+        }
+    }
+}
+}  // namespace
 
 static bool read_file(const std::string& path, std::vector<unsigned char>& out) {
     FILE* f = std::fopen(path.c_str(), "rb");
@@ -115,25 +174,122 @@ extern "C" int mcq_refdb_open(const char* prefix, uint32_t n_ranks, mcq_refdb** 
     }
     if (!all.empty()) db->off.push_back(all.size());
     db->info.n_keys = db->keys.size(); db->info.n_locs = db->locs.size();
-    // ranked lineages: walk the parents, record every ranked ancestor (incl. the taxon itself)
-    // at lineage[rank] (taxonomy::ranks, src/taxonomy.h:576-597)
-    for (uint32_t i = 0; i < db->taxa.size(); ++i) db->by_id[db->taxa[i].id] = i;
-    db->lineage.assign((size_t)db->taxa.size() * kNumRanks, MCQ_NO_TAXON);
-    for (uint32_t i = 0; i < db->taxa.size(); ++i) {
-        int64_t cur = db->taxa[i].id;
-        while (cur != 0) {
-            auto it = db->by_id.find(cur);
-            if (it == db->by_id.end()) break;
-            const Taxon& t = db->taxa[it->second];
-            if (t.rank < kNumRanks) db->lineage[(size_t)i * kNumRanks + t.rank] = it->second;
-            cur = (t.parent != cur) ? t.parent : 0;
-        }
-    }
+    build_lineages(db);
     *out = db;
     return 0;
 }
 
 extern "C" int mcq_refdb_close(mcq_refdb* db) { delete db; return 0; }
+
+// ---- the streaming route (r04): shard files of any size without a host-side union ------------------------------------------
+// mcq_refdb_open (above) materialises every (key, location) of all P shards in one host vector and sorts it: 16 B per location,
+// 240 GB and minutes for a RefSeq-scale database.  The streaming route reads only the head of every file here (parameters,
+// taxa, target count: what classify and the taxon keys need), and hands the key records out in chunks of (feature, target,
+// window) triples in file order; the consumer (mcq_parts_builder_*, include/mcq.h) turns them into global-window words on the
+// GPU, merges the ranks per feature-hash range there and makes the table parts.  Host memory: one read buffer + one chunk.
+extern "C" int mcq_refdb_open_meta(const char* prefix, uint32_t n_ranks, mcq_refdb** out) {
+    if (!prefix || !out || n_ranks < 1) return fail("bad argument");
+    mcq_refdb* db = new mcq_refdb();
+    db->prefix = prefix;
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        const std::string path = std::string(prefix) + ".db_" + std::to_string(r);
+        FileReader rd;
+        if (!rd.open(path)) { delete db; return fail("can't open file " + path); }
+        if (rd.get<uint64_t>() != kDbVersion) { delete db; return fail("Database " + path + " is incompatible (version)"); }
+        uint8_t w[6]; for (auto& x : w) x = rd.get<uint8_t>();
+        if (w[0] != 4 || w[1] != 4 || w[2] != 4 || w[3] != 1 || w[4] != 8 || w[5] != kNumRanks) {
+            delete db; return fail("Database " + path + " is incompatible due to different data type sizes");
+        }
+        uint64_t p[9]; for (auto& x : p) x = rd.get<uint64_t>();
+        const uint64_t ntaxa = rd.get<uint64_t>();
+        std::vector<Taxon> taxa;
+        for (uint64_t i = 0; i < ntaxa && rd.ok; ++i) {
+            Taxon t; t.id = rd.get<int64_t>(); t.parent = rd.get<int64_t>(); t.rank = rd.get<uint8_t>();
+            t.name = rd.str(); rd.str(); rd.get<uint64_t>(); t.windows = rd.get<uint64_t>();
+            taxa.push_back(std::move(t));
+        }
+        const uint32_t ntargets = rd.get<uint32_t>();
+        if (!rd.ok) { delete db; return fail("Database " + path + " is truncated or corrupt"); }
+        if (r == 0) {
+            db->info.k = (uint32_t)p[0]; db->info.sketch_size = (uint32_t)p[1]; db->info.winlen = (uint32_t)p[2];
+            db->info.winstride = (uint32_t)p[3]; db->info.q_sketch_size = (uint32_t)p[5]; db->info.q_winlen = (uint32_t)p[6];
+            db->info.q_winstride = (uint32_t)p[7]; db->info.max_locs_per_feature = (uint32_t)p[8];
+            db->info.n_targets = ntargets; db->info.n_taxa = (uint32_t)ntaxa; db->info.n_ranks = n_ranks;
+            db->tgt_windows.assign(ntargets, 0);
+        } else if (ntargets != db->info.n_targets || ntaxa != db->info.n_taxa) {
+            delete db; return fail("shard " + path + " does not belong to the same database");
+        }
+        // windows of the targets this rank owns (`windows` is non-zero only there, src/taxonomy.h:326-335)
+        for (const Taxon& t : taxa)
+            if (t.id < 0 && (uint64_t)(-t.id - 1) < ntargets && t.windows) {
+                if (t.windows >= (1ull << 32)) { delete db; return fail("a target with 2^32 windows or more"); }
+                db->tgt_windows[(size_t)(-t.id - 1)] = (uint32_t)t.windows;
+            }
+        if (r == 0) db->taxa = std::move(taxa);
+        uint64_t nkeys = 0, nlocs = 0;
+        if (ntargets >= 1) { nkeys = rd.get<uint64_t>(); nlocs = rd.get<uint64_t>(); }
+        if (!rd.ok) { delete db; return fail("Database " + path + " is truncated or corrupt"); }
+        db->table_pos.push_back(rd.consumed); db->table_keys.push_back(nkeys); db->table_locs.push_back(nlocs);
+        std::fseek(rd.f, 0, SEEK_END);
+        db->file_bytes.push_back((uint64_t)std::ftell(rd.f));
+        db->info.n_locs += nlocs;            // (n_keys of the union is not known without reading the tables: left 0)
+    }
+    build_lineages(db);
+    *out = db;
+    return 0;
+}
+extern "C" int mcq_refdb_tgt_windows(const mcq_refdb* db, uint32_t* out) {
+    if (!db || !out) return fail("bad argument");
+    if (db->tgt_windows.size() != db->info.n_targets) return fail("the handle was not opened with mcq_refdb_open_meta");
+    std::memcpy(out, db->tgt_windows.data(), db->tgt_windows.size() * 4);
+    return 0;
+}
+extern "C" int mcq_refdb_file_stats(const mcq_refdb* db, uint32_t rank, uint64_t* bytes, uint64_t* n_keys, uint64_t* n_locs) {
+    if (!db || rank >= db->table_pos.size()) return fail("bad argument");
+    if (bytes) *bytes = db->file_bytes[rank];
+    if (n_keys) *n_keys = db->table_keys[rank];
+    if (n_locs) *n_locs = db->table_locs[rank];
+    return 0;
+}
+
+struct mcq_shard_stream {
+    FileReader rd{1u << 24};
+    uint64_t keys_left = 0;
+};
+extern "C" int mcq_shard_stream_open(const mcq_refdb* db, uint32_t rank, mcq_shard_stream** out) {
+    if (!db || !out || rank >= db->table_pos.size()) return fail("bad argument (the handle must come from mcq_refdb_open_meta)");
+    mcq_shard_stream* s = new mcq_shard_stream();
+    const std::string path = db->prefix + ".db_" + std::to_string(rank);
+    if (!s->rd.open(path) || !s->rd.seek(db->table_pos[rank])) { delete s; return fail("can't open file " + path); }
+    s->keys_left = db->table_keys[rank];
+    *out = s;
+    return 0;
+}
+extern "C" int mcq_shard_stream_next(mcq_shard_stream* s, uint32_t* feat, uint32_t* tgt, uint32_t* win, uint64_t cap, uint64_t* n_out) {
+    if (!s || !feat || !tgt || !win || !n_out || cap < 255) return fail("bad argument (a chunk holds at least 255 locations)");
+    uint64_t n = 0;
+    while (s->keys_left && n + 255 <= cap) {                     // (whole key records only: a list has at most 255 entries)
+        const uint32_t key = s->rd.get<uint32_t>(); const uint8_t cnt = s->rd.get<uint8_t>();
+        --s->keys_left;
+        if (!s->rd.ok) return fail("shard file is truncated or corrupt");
+        if (cnt == 0) continue;                                  // (an empty bucket is written without its columns)
+        const uint64_t n1 = s->rd.get<uint64_t>();
+        if (!s->rd.ok || n1 != cnt) return fail("shard file is truncated or corrupt");
+        const unsigned char* tp = s->rd.bytes(4 * (size_t)cnt);
+        if (!tp) return fail("shard file is truncated or corrupt");
+        std::memcpy(tgt + n, tp, 4 * (size_t)cnt);
+        const uint64_t n2 = s->rd.get<uint64_t>();
+        if (!s->rd.ok || n2 != cnt) return fail("shard file is truncated or corrupt");
+        const unsigned char* wp = s->rd.bytes(4 * (size_t)cnt);
+        if (!wp) return fail("shard file is truncated or corrupt");
+        std::memcpy(win + n, wp, 4 * (size_t)cnt);
+        for (uint32_t j = 0; j < cnt; ++j) feat[n + j] = key;
+        n += cnt;
+    }
+    *n_out = n;
+    return 0;
+}
+extern "C" int mcq_shard_stream_close(mcq_shard_stream* s) { delete s; return 0; }
 
 // ---- shard writer: the exact inverse of the reader above
 namespace {

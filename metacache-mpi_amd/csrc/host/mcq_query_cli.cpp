@@ -5,10 +5,9 @@
 int main(int argc, char** argv) {
     Options p;
     if (!parse_options(argc, argv, p)) return 2;
-    mcq_refdb* rdb = nullptr; std::vector<uint32_t> t2t; mcq_db_desc d; uint32_t hitmin = 0;
-    if (!open_database(p, &rdb, t2t, d, hitmin, 1, 0, 0)) return 1;
+    mcq_refdb* rdb = nullptr; std::vector<uint32_t> t2t; uint32_t hitmin = 0;
     mcq_db* edb = nullptr;
-    if (mcq_db_create(&d, &edb)) { std::fprintf(stderr, "ABORT: %s\n", mcq_last_error()); return 1; }
+    if (!open_database(p, &rdb, t2t, &edb, hitmin, 1, 0, 0)) return 1;
 
     const auto t_start = std::chrono::steady_clock::now();                  // the reference times map_queries_to_targets, readers included (src/mode_query.cpp:130-132)
     std::vector<Rec> r1, r2;

@@ -65,10 +65,9 @@ int main(int argc, char** argv) {
     HIP_OR_DIE(hipSetDevice(device));
 
     // this rank's hash range of the table
-    mcq_refdb* rdb = nullptr; std::vector<uint32_t> t2t; mcq_db_desc d; uint32_t hitmin = 0;
-    if (!open_database(p, &rdb, t2t, d, hitmin, (uint32_t)N, (uint32_t)rank, device)) MPI_Abort(MPI_COMM_WORLD, 1);
+    mcq_refdb* rdb = nullptr; std::vector<uint32_t> t2t; uint32_t hitmin = 0;
     mcq_db* shard = nullptr;
-    MCQ_OR_DIE(mcq_db_create(&d, &shard));
+    if (!open_database(p, &rdb, t2t, &shard, hitmin, (uint32_t)N, (uint32_t)rank, device)) MPI_Abort(MPI_COMM_WORLD, 1);
 
     // the context for a fixed batch shape and the communicator: set up before the clock starts, like the reference's
     // database load and MPI_Init (identical capacities on every rank)

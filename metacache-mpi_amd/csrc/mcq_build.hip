@@ -364,7 +364,8 @@ extern "C" int mcq_build_table(const mcq_build_desc* d, mcq_table** out) {
 // table in the form the query side stores: keys, list lengths, 32-bit global-window words.
 struct mcq_parts {
     int device; u32 n_targets;
-    u32 k, s, winlen, winstride;
+    u32 k, s, winlen, winstride;      // what the handle sketches QUERIES with
+    u32 tgt_winstride;                // window stride of the targets (range width of the candidates); 0 = winstride
     u64 n_windows;
     u32* tgt_windows;         // device [n_targets]
     std::vector<mcq_db_part> parts;
@@ -460,7 +461,7 @@ extern "C" int mcq_build_parts(const mcq_build_desc* d, mcq_parts** out) {
     struct SkGuard { mcq_db* h; ~SkGuard() { mcq_db_destroy(h); } } skg{sk};
 
     mcq_parts* R = new mcq_parts();
-    R->device = d->device; R->n_targets = nt; R->k = d->k; R->s = s; R->winlen = d->winlen; R->winstride = d->winstride;
+    R->device = d->device; R->n_targets = nt; R->k = d->k; R->s = s; R->winlen = d->winlen; R->winstride = d->winstride; R->tgt_winstride = 0;
     R->n_windows = 0; R->tgt_windows = nullptr; R->n_keys = R->n_locs = R->bytes = 0;
     struct PartsGuard { mcq_parts*& p; ~PartsGuard() { if (p) mcq_parts_free(p); } } guard{R};
 
@@ -555,6 +556,216 @@ extern "C" int mcq_build_parts(const mcq_build_desc* d, mcq_parts** out) {
     return MCQ_OK;
 }
 
+
+// ---- parts from streamed (feature, target, window) triples: the reference's shard files without a host-side union --------------
+// (include/mcq.h, mcq_parts_builder_*; the host side is mcq_refdb_open_meta + mcq_shard_stream_* of include/mcq_host.h.)
+// A chunk of triples becomes (feature << 32 | global window) words on the device and is scattered to the buffer of its feature-hash
+// range -- the ranges of mcq_build_parts, sub-ranges of this shard's range: foreign features are dropped --; finish() sorts
+// every range (that is the merge of the reference's P per-rank lists of a feature into (target, window) order: each is
+// already truncated to 254 per rank, src/sketch_database.h:1090-1092) and cuts it into keys / list lengths / words.
+struct mcq_parts_builder {
+    int device = 0; u32 nt = 0, n_ranges = 1, n_shards = 1, shard_id = 0;
+    u32 k = 0, s = 0, winlen = 0, winstride = 0, tgt_winstride = 0;
+    u32* tgt_windows = nullptr;       // device [nt] (moves into the parts)
+    u32* gw_off = nullptr;            // device [nt + 1]
+    u64 n_windows = 0;
+    std::vector<u64*> buf; std::vector<u64> cnt, cap;
+    u64** d_buf = nullptr;            // device copy of the buffer pointers
+    unsigned long long* d_cur = nullptr;   // device write cursors [n_ranges]
+    u32* d_hist = nullptr;            // device [n_ranges + 1]: chunk histogram, [n_ranges] = bad triples
+    u32 *d_feat = nullptr, *d_tgt = nullptr, *d_win = nullptr; u64 stage_cap = 0;
+    u64 n_added = 0, n_kept = 0;
+};
+namespace {
+__global__ void k_gwoff(const u32* tgt_windows, u32 nt, u32* gw_off) {       // (one thread: nt is at most a few 1e5)
+    if (blockIdx.x || threadIdx.x) return;
+    u64 acc = 0;
+    for (u32 t = 0; t < nt; ++t) { gw_off[t] = (u32)acc; acc += tgt_windows[t]; }
+    gw_off[nt] = (u32)acc;
+}
+// range of every triple of a chunk (0xFFFFFFFF: another shard's feature) and the chunk's histogram
+__global__ void k_triple_range(const u32* feat, const u32* tgt, const u32* win, u64 n, u32 n_ranges, u32 n_shards, u32 shard_id,
+                               const u32* tgt_windows, u32 nt, u32* rng, u32* hist) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u32 f = feat[i];
+        const u32 r = (u32)(((u64)tmh_dev(f) * ((u64)n_ranges * n_shards)) >> 32);
+        u32 mine = (r / n_ranges == shard_id) ? r - shard_id * n_ranges : 0xFFFFFFFFu;
+        if (f == 0xFFFFFFFFu || tgt[i] >= nt || win[i] >= tgt_windows[tgt[i]]) { mine = 0xFFFFFFFFu; atomicAdd(&hist[n_ranges], 1u); }
+        rng[i] = mine;
+        if (mine != 0xFFFFFFFFu) atomicAdd(&hist[mine], 1u);
+    }
+}
+__global__ void k_triple_scatter(const u32* feat, const u32* tgt, const u32* win, const u32* rng, u64 n, const u32* gw_off,
+                                 u64* const* bufs, unsigned long long* cur) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u32 lane = threadIdx.x & 63;
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x - lane; i0 < n; i0 += stride) {       // (whole waves iterate together)
+        const u64 i = i0 + lane;
+        const u32 r = i < n ? rng[i] : 0xFFFFFFFFu;
+        unsigned long long todo = __ballot(r != 0xFFFFFFFFu);
+        while (todo) {                                        // one atomic per distinct range among the wave's triples
+            const u32 rr = __shfl(r, (int)__builtin_ctzll(todo), 64);
+            const unsigned long long mm = __ballot(r == rr);
+            unsigned long long base = 0;
+            if (lane == (u32)__builtin_ctzll(mm)) base = atomicAdd(&cur[rr], (unsigned long long)__builtin_popcountll(mm));
+            base = __shfl(base, (int)__builtin_ctzll(mm), 64);
+            if (r == rr) bufs[rr][base + __builtin_popcountll(mm & ((1ull << lane) - 1))] = ((u64)feat[i] << 32) | (u64)(gw_off[tgt[i]] + win[i]);
+            todo &= ~mm;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int mcq_parts_builder_free(mcq_parts_builder* b) {
+    if (!b) return MCQ_OK;
+    (void)hipSetDevice(b->device);
+    for (u64* p : b->buf) (void)hipFree(p);
+    (void)hipFree(b->tgt_windows); (void)hipFree(b->gw_off); (void)hipFree(b->d_buf); (void)hipFree(b->d_cur); (void)hipFree(b->d_hist);
+    (void)hipFree(b->d_feat); (void)hipFree(b->d_tgt); (void)hipFree(b->d_win);
+    delete b;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_parts_builder_create(const mcq_parts_builder_desc* d, mcq_parts_builder** out) {
+    if (!d || !out || !d->tgt_windows || d->n_targets < 1) return bfail(MCQ_E_ARG, "null argument");
+    const u32 n_shards = d->n_shards ? d->n_shards : 1;
+    if (d->shard_id >= n_shards) return bfail(MCQ_E_ARG, "shard_id >= n_shards");
+    BCHK(hipSetDevice(d->device));
+    mcq_parts_builder* b = new mcq_parts_builder();
+    struct Guard { mcq_parts_builder*& p; ~Guard() { if (p) mcq_parts_builder_free(p); } } guard{b};
+    b->device = d->device; b->nt = d->n_targets; b->n_shards = n_shards; b->shard_id = d->shard_id;
+    b->k = d->k; b->s = d->sketch_size; b->winlen = d->winlen; b->winstride = d->winstride; b->tgt_winstride = d->tgt_winstride;
+    u64 total = 0;
+    for (u32 t = 0; t < d->n_targets; ++t) total += d->tgt_windows[t];
+    if (total >= 0xFFFFFFFFull) return bfail(MCQ_E_UNSUPPORTED, "2^32 - 1 windows or more");
+    b->n_windows = total;
+    BCHK(hipMalloc(&b->tgt_windows, (u64)d->n_targets * 4));
+    BCHK(hipMemcpy(b->tgt_windows, d->tgt_windows, (u64)d->n_targets * 4, hipMemcpyHostToDevice));
+    BCHK(hipMalloc(&b->gw_off, ((u64)d->n_targets + 1) * 4));
+    hipLaunchKernelGGL(k_gwoff, dim3(1), dim3(1), 0, 0, (const u32*)b->tgt_windows, d->n_targets, b->gw_off);
+    // ranges: what the sort of one range needs at its peak (~30 B per location: the words twice, heads, key ids) against a
+    // quarter of the free memory, from the caller's estimate of the locations this shard will receive
+    size_t mem_free = 0, mem_total = 0;
+    BCHK(hipMemGetInfo(&mem_free, &mem_total));
+    const u64 expect = d->expected_locations / n_shards + 1;
+    u32 n_ranges = (u32)std::max<u64>(1, (expect * 30 + mem_free / 4 - 1) / (mem_free / 4 ? mem_free / 4 : 1));
+    if (d->n_ranges) n_ranges = d->n_ranges;
+    if (const char* e = getenv("MCQ_BUILD_PARTS")) n_ranges = (u32)std::max<u64>(1, strtoull(e, nullptr, 10));      // (test hook, as mcq_build_parts)
+    if ((u64)n_ranges * n_shards > (1u << 20)) return bfail(MCQ_E_UNSUPPORTED, "too many ranges");
+    b->n_ranges = n_ranges;
+    b->buf.assign(n_ranges, nullptr); b->cnt.assign(n_ranges, 0); b->cap.assign(n_ranges, 0);
+    BCHK(hipMalloc(&b->d_buf, (u64)n_ranges * 8));
+    BCHK(hipMalloc(&b->d_cur, (u64)n_ranges * 8));
+    BCHK(hipMalloc(&b->d_hist, ((u64)n_ranges + 1) * 4));
+    BCHK(hipDeviceSynchronize());
+    *out = b;
+    b = nullptr;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_parts_builder_add(mcq_parts_builder* b, const uint32_t* feat, const uint32_t* tgt, const uint32_t* win, uint64_t n, uint32_t flags) {
+    if (!b || (n && (!feat || !tgt || !win))) return bfail(MCQ_E_ARG, "null argument");
+    if (!n) return MCQ_OK;
+    if (n >= (1ull << 31)) return bfail(MCQ_E_ARG, "a chunk holds fewer than 2^31 triples");
+    BCHK(hipSetDevice(b->device));
+    const u32 *df = feat, *dt = tgt, *dw = win;
+    if (!(flags & MCQ_DEVICE_PTRS)) {
+        if (n > b->stage_cap) {
+            (void)hipFree(b->d_feat); (void)hipFree(b->d_tgt); (void)hipFree(b->d_win); b->d_feat = b->d_tgt = b->d_win = nullptr; b->stage_cap = 0;
+            BCHK(hipMalloc(&b->d_feat, n * 4)); BCHK(hipMalloc(&b->d_tgt, n * 4)); BCHK(hipMalloc(&b->d_win, n * 4));
+            b->stage_cap = n;
+        }
+        BCHK(hipMemcpyAsync(b->d_feat, feat, n * 4, hipMemcpyHostToDevice, 0));
+        BCHK(hipMemcpyAsync(b->d_tgt, tgt, n * 4, hipMemcpyHostToDevice, 0));
+        BCHK(hipMemcpyAsync(b->d_win, win, n * 4, hipMemcpyHostToDevice, 0));
+        df = b->d_feat; dt = b->d_tgt; dw = b->d_win;
+    }
+    u32* rng = nullptr;
+    BCHK(hipMalloc(&rng, n * 4));
+    struct Free { void* p; ~Free() { (void)hipFree(p); } } fr{rng};
+    BCHK(hipMemsetAsync(b->d_hist, 0, ((u64)b->n_ranges + 1) * 4, 0));
+    hipLaunchKernelGGL(k_triple_range, grid_for(n), dim3(TB), 0, 0, df, dt, dw, n, b->n_ranges, b->n_shards, b->shard_id,
+                       (const u32*)b->tgt_windows, b->nt, rng, b->d_hist);
+    std::vector<u32> hist(b->n_ranges + 1);
+    BCHK(hipMemcpy(hist.data(), b->d_hist, hist.size() * 4, hipMemcpyDeviceToHost));
+    if (hist[b->n_ranges]) return bfail(MCQ_E_ARG, std::to_string(hist[b->n_ranges]) + " triples name a target or a window the database does not have");
+    // room in every range's buffer (grown by half when it runs out: a copy of what is there)
+    bool moved = false;
+    for (u32 r = 0; r < b->n_ranges; ++r) {
+        const u64 need = b->cnt[r] + hist[r];
+        if (need <= b->cap[r]) continue;
+        const u64 ncap = std::max<u64>(need + need / 2, 1u << 20);
+        u64* nb = nullptr;
+        BCHK(hipMalloc(&nb, ncap * 8));
+        if (b->cnt[r]) BCHK(hipMemcpy(nb, b->buf[r], b->cnt[r] * 8, hipMemcpyDeviceToDevice));
+        (void)hipFree(b->buf[r]);
+        b->buf[r] = nb; b->cap[r] = ncap; moved = true;
+    }
+    if (moved) BCHK(hipMemcpy(b->d_buf, b->buf.data(), (u64)b->n_ranges * 8, hipMemcpyHostToDevice));
+    BCHK(hipMemcpy(b->d_cur, b->cnt.data(), (u64)b->n_ranges * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_triple_scatter, grid_for(n), dim3(TB), 0, 0, df, dt, dw, (const u32*)rng, n, (const u32*)b->gw_off, (u64* const*)b->d_buf, b->d_cur);
+    BCHK(hipDeviceSynchronize());
+    BCHK(hipGetLastError());
+    for (u32 r = 0; r < b->n_ranges; ++r) { b->cnt[r] += hist[r]; b->n_kept += hist[r]; }
+    b->n_added += n;
+    return MCQ_OK;
+}
+
+extern "C" int mcq_parts_builder_finish(mcq_parts_builder* b, mcq_parts** out) {
+    if (!b || !out) return bfail(MCQ_E_ARG, "null argument");
+    BCHK(hipSetDevice(b->device));
+    Scratch tmpbuf;
+    BCHK(tmpbuf.init(b->device));
+    PhaseTrace phase;
+    mcq_parts* R = new mcq_parts();
+    R->device = b->device; R->n_targets = b->nt; R->k = b->k; R->s = b->s; R->winlen = b->winlen; R->winstride = b->winstride;
+    R->tgt_winstride = b->tgt_winstride;
+    R->n_windows = b->n_windows; R->tgt_windows = b->tgt_windows; b->tgt_windows = nullptr;
+    R->n_keys = R->n_locs = R->bytes = 0;
+    struct PartsGuard { mcq_parts*& p; ~PartsGuard() { if (p) mcq_parts_free(p); } } guard{R};
+    (void)hipFree(b->d_feat); (void)hipFree(b->d_tgt); (void)hipFree(b->d_win); b->d_feat = b->d_tgt = b->d_win = nullptr;
+    for (u32 r = 0; r < b->n_ranges; ++r) {
+        const u64 n = b->cnt[r];
+        mcq_db_part q; q.n_keys = 0; q.n_locs = n; q.keys = nullptr; q.list_len = nullptr; q.locs = nullptr;
+        u64* fw = nullptr; u32* head = nullptr; u64 *kid = nullptr, *first = nullptr; u64 n_keys = 0;
+        if (n) {
+            BCHK(tmpbuf.get(&fw, n * 8));
+            size_t tmp = 0;
+            BCHK(rocprim::radix_sort_keys(nullptr, tmp, b->buf[r], fw, n, 0, 64));
+            void* t = nullptr; BCHK(tmpbuf.get(&t, tmp ? tmp : 1));
+            BCHK(rocprim::radix_sort_keys(t, tmp, b->buf[r], fw, n, 0, 64));
+            BCHK(hipDeviceSynchronize());
+            tmpbuf.put(t);
+            (void)hipFree(b->buf[r]); b->buf[r] = nullptr; b->cap[r] = 0;
+            BCHK(tmpbuf.get(&head, n * 4)); BCHK(tmpbuf.get(&kid, n * 8));
+            hipLaunchKernelGGL(k_feat_heads, grid_for(n), dim3(TB), 0, 0, (const u64*)fw, n, head);
+            MCHK(excl_scan(head, kid, n, &n_keys));
+        }
+        q.n_keys = n_keys;
+        u32 *pk = nullptr, *pl = nullptr, *pw = nullptr;
+        BCHK(hipMalloc(&pk, (n_keys ? n_keys : 1) * 4)); q.keys = pk;
+        R->parts.push_back(q);                                   // (owned by R from here)
+        BCHK(hipMalloc(&pl, (n_keys ? n_keys : 1) * 4)); R->parts.back().list_len = pl;
+        BCHK(hipMalloc(&pw, (n ? n : 1) * 4)); R->parts.back().locs = pw;
+        if (n) {
+            BCHK(tmpbuf.get(&first, (n_keys ? n_keys : 1) * 8));
+            hipLaunchKernelGGL(k_part_first, grid_for(n), dim3(TB), 0, 0, (const u32*)head, (const u64*)kid, n, first);
+            hipLaunchKernelGGL(k_part_len, grid_for(n_keys), dim3(TB), 0, 0, (const u64*)first, n_keys, n, pl);
+            hipLaunchKernelGGL(k_emit_part, grid_for(n), dim3(TB), 0, 0, (const u64*)fw, (const u32*)head, (const u64*)kid, n, pk, pw);
+            BCHK(hipDeviceSynchronize());
+            BCHK(hipGetLastError());
+            tmpbuf.put(first); tmpbuf.put(fw); tmpbuf.put(head); tmpbuf.put(kid);
+        }
+        R->n_keys += n_keys; R->n_locs += n; R->bytes += n_keys * 8 + n * 4;
+        phase("  range sorted + emitted");
+    }
+    *out = R;
+    R = nullptr;
+    mcq_parts_builder_free(b);
+    return MCQ_OK;
+}
+
 extern "C" int mcq_db_from_parts(const mcq_parts* p, const uint32_t* tgt2tax, uint32_t n_shards, uint32_t shard_id, uint32_t flags, mcq_db** out) {
     if (!p || !tgt2tax || !out) return bfail(MCQ_E_ARG, "null argument");
     BCHK(hipSetDevice(p->device));
@@ -564,7 +775,7 @@ extern "C" int mcq_db_from_parts(const mcq_parts* p, const uint32_t* tgt2tax, ui
         BCHK(hipMemcpy(t2t, tgt2tax, (u64)p->n_targets * 4, hipMemcpyHostToDevice));
     }
     mcq_db_desc c; std::memset(&c, 0, sizeof(c));
-    c.k = p->k; c.sketch_size = p->s; c.winlen = p->winlen; c.winstride = p->winstride; c.tgt_winstride = p->winstride;
+    c.k = p->k; c.sketch_size = p->s; c.winlen = p->winlen; c.winstride = p->winstride; c.tgt_winstride = p->tgt_winstride ? p->tgt_winstride : p->winstride;
     c.n_targets = p->n_targets; c.tgt2tax = t2t ? t2t : tgt2tax; c.tgt_windows = p->tgt_windows;
     c.n_shards = n_shards ? n_shards : 1; c.shard_id = shard_id; c.device = p->device;
     c.flags = MCQ_DEVICE_PTRS | (flags & (MCQ_DB_SLOTS_16 | MCQ_DB_BUCKETS_64));

@@ -165,8 +165,7 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     // queues by their length here -- 64 words per back-queue slot: list offset << 16 | list length of the
     // lane's feature -- so the second stage neither sketches nor probes them again.  (In a cache line of its own: the
     // counters above are hammered by atomics, and a load from their line queues behind them.)
-    unsigned long long n_counted;     // queries the workgroup kernel answered by counting instead of sorting (block_count_tail)
-    unsigned long long pad_[22];
+    unsigned long long pad_[23];      // (diagnostic builds, -DMCQ_PHASE_CLOCK: phase clocks of the workgroup kernel)
     unsigned long long* probe_buf;
     unsigned long long* probe_front;  // the same for FRONT-queue slots of queries with <= 64 features (third wave stage); a lane without
                                       // a feature holds 0xFFFF

@@ -1356,6 +1356,36 @@ __device__ __forceinline__ u32 block_excl_scan(u32* a, u32 n, u32 tid, u32* s_w 
     return s_w[17];
 }
 
+// The same for n <= 4 x blockDim.x values of which thread tid holds a[tid + c x blockDim.x] (it wrote them itself: no barrier needed
+// in front) in TWO barriers whatever n is: wave scans of every chunk, the (chunk, wave) totals through 64 words of LDS, their
+// prefix by one more wave scan in every wave.  (block_excl_scan takes four barriers per 1024 values: 9 for the 1136 features of
+// an 8 kb read, with the barrier in front -- measured with the phase clocks of r04: probe + scan were 19 % of the kernel.)
+__device__ __forceinline__ u32 block_excl_scan4(u32* a, u32 n, u32 tid) {
+    __shared__ u32 s_tot[64];
+    const u32 NTB = blockDim.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = NTB >> 6;
+    u32 v[4], x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const u32 i = (u32)c * NTB + tid;
+        v[c] = i < n ? a[i] : 0u;
+        x[c] = wave_incl_scan_dpp(v[c]);
+        if (lane == 63) s_tot[c * nwv + wave] = x[c];
+    }
+    __syncthreads();
+    const u32 t = lane < 4 * nwv ? s_tot[lane] : 0u;              // (nwv <= 16)
+    const u32 incl = wave_incl_scan_dpp(t);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const u32 i = (u32)c * NTB + tid;
+        const u32 j = c * nwv + wave;                               // (wave-uniform)
+        const u32 before = bcast(incl - t, j);
+        if (i < n) a[i] = before + x[c] - v[c];
+    }
+    const u32 total = bcast(incl, 63);
+    __syncthreads();
+    return total;
+}
+
 // Tail of the workgroup path: fill B[0..n2p) through `load(t)`, sort, sweep, top lists.
 // HT/JB: packed (hits << JB | index) word of the sweep: u32 with JB = 13 when the list fits the workgroup's LDS
 // (<= 8192 entries, hits <= 8192), u64 with JB = 32 in global scratch
@@ -1483,224 +1513,6 @@ __device__ __forceinline__ int block_two_class(const DbDev& db, const OptDev& op
     return done ? TC_DONE : TC_FAILED;
 }
 
-// ---- rows 8-11 of the workgroup kernel by COUNTING instead of sorting (long reads: heavy clusters) ------------------------
-// A long read's match list is a few thousand words of which most lie in clusters: ~70 windows of each strain of its species,
-// hit by up to s features each (8 kb on the configs[1] table: 2 430 words, 1 400 distinct, ~20 clusters), the rest chance hits
-// alone in their neighbourhood.  Rows 8-9 ask per target for the first strictly-best range of numWindows windows
-// (src/candidates.h:118-180) -- a question about window HISTOGRAMS: cut the word space into cells of 2^cs >= numWindows windows
-// (cell = word >> cs; bit-field words, so a target's first window starts a cell); a range ends in one cell and begins there or in
-// the cell before.  Per query, by the whole workgroup:
-//   1. the cells of all words go into an open-addressing table in LDS (ds_cmpst claims a slot, ds_add counts);
-//   2. a cell is ACTIVE when it holds two or more words or a neighbour cell of the same target is occupied: its words may share
-//      ranges.  Active cells get a dense histogram of u16 bins, one per window (ds_add per word);
-//   3. one wave per active cell E: inclusive prefix sums S over the bins of the cell before it and its own, hits(e) = S[e] -
-//      S[e - numWindows] for the windows e of E, the cell's best = max hits, smallest e -- what the two-pointer sweep reports
-//      for the ranges that END in E (a window without words never beats the last occupied one before it);
-//   4. every active cell's best and every other word (alone in its neighbourhood: one hit, its own range) is an ENTRY
-//      (hits, 63 - virtual rank, ~word); rows 10-11 as ONE selection (OptDev::lin) take the first M distinct
-//      taxa in that order -- the weaker entries of a target retire with its taxon, so the per-target maximum is never formed.
-// No sort, no per-word binary searches; O(words) LDS atomics + O(active cells x 2^cs) scan work.  Exact, no fallback inside: the
-// capacity checks (table load, active cells, entries) come before anything is destroyed, and the caller then sorts as before.
-#define MCQ_CT_SLOTS 2048u              // cell table (power of two); at most 3/4 full
-#define MCQ_CT_MAX_T 4096u              // longest list taken (words in the first half of the key segment, the table in the second)
-#define MCQ_CT_BINS 5632u               // u32 words of bins (two u16 bins each): 88 active cells of 128 windows
-#define MCQ_CT_RES 256u                 // active cells at most (their results: 2 x 256 words behind the bins)
-#define MCQ_CT_ENT 2048u                // entries at most
-template <int LCAPB, class LF, class Fill>
-__device__ __forceinline__ bool block_count_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr, u32* Bw, u32* HW, u32 T,
-                                                 u32 numWindows, const LF& lf, u64 q, u32 tid, u32* s_x /* 12 words */, Fill fill, bool& filled, u64* ph) {
-    static_assert(LCAPB == 8192, "segments of 8192 words");
-    const u32 NTB = blockDim.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), nwv = NTB >> 6;
-    const u32 cs = cell_shift(numWindows);
-    if (T > MCQ_CT_MAX_T || cs < 4 || cs > 10 || lf.wb < cs || NTB != 1024) return false;
-    const u32 BPC = 1u << cs, WPC = BPC >> 1;                   // bins / u32 words of bins per cell
-    const u32 tshift = lf.wb - cs;                              // cell >> tshift = target
-    u32* CK = Bw + MCQ_CT_MAX_T; u32* CV = CK + MCQ_CT_SLOTS;   // cell table: key, then count -> (active: bit 31 | block id)
-    __shared__ unsigned long long s_gm;                         // maximum of a selection round
-    fill(Bw);
-    filled = true;
-    for (u32 i = tid; i < MCQ_CT_SLOTS; i += NTB) { CK[i] = MCQ_EMPTY; CV[i] = 0; }
-    if (tid < 12) s_x[tid] = 0;
-    if (tid == 0) s_gm = 0;
-    __syncthreads();
-    PHCLK(ph, 3);
-    // ---- 1. cells of the words
-    u32 myslot[2] = {0, 0};                                     // slots of this thread's (at most four) words, 16 bits each
-    bool crowded = false;
-    u32 claimed = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const u32 t = tid + (u32)i * 1024u;
-        if (t < T) {
-            const u32 cell = Bw[t] >> cs;
-            u32 h = (cell * 0x9E3779B1u) >> 21;                 // 11 bits
-            u32 steps = 0;
-            for (;;) {
-                const u32 prev = atomicCAS(&CK[h], MCQ_EMPTY, cell);
-                if (prev == MCQ_EMPTY) ++claimed;
-                if (prev == MCQ_EMPTY || prev == cell) break;
-                h = (h + 1) & (MCQ_CT_SLOTS - 1);
-                if (++steps > 96) { crowded = true; break; }
-            }
-            if (!crowded) atomicAdd(&CV[h], 1u);
-            myslot[i >> 1] |= h << (16 * (i & 1));
-        }
-    }
-    claimed = wave_incl_scan_dpp(claimed);
-    if (lane == 63 && claimed) atomicAdd(&s_x[8], claimed);
-    if (__ballot(crowded) && lane == 0) s_x[2] = 1;
-    __syncthreads();
-    PHCLK(ph, 4);
-    if (s_x[2] || s_x[8] > MCQ_CT_SLOTS * 3 / 4) return false;  // too many distinct cells (uniform; the searches below need empty slots)
-    // ---- 2. active cells, their bin blocks; words outside them are entries of their own
-    auto find = [&](u32 cell) -> u32 {                          // slot of a cell, MCQ_EMPTY when absent
-        u32 h = (cell * 0x9E3779B1u) >> 21;
-        for (;;) {
-            const u32 k = CK[h];
-            if (k == cell) return h;
-            if (k == MCQ_EMPTY) return MCQ_EMPTY;
-            h = (h + 1) & (MCQ_CT_SLOTS - 1);
-        }
-    };
-    u32* RS = HW + MCQ_CT_BINS; u32* RC = RS + MCQ_CT_RES;      // per active cell: its cell (from here on), its best range (step 4)
-    u32 act[2] = {0, 0};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const u32 sidx = tid + (u32)i * 1024u;
-        const u32 c = CK[sidx];
-        bool active = false, occupied = c != MCQ_EMPTY;
-        if (occupied) {
-            active = CV[sidx] >= 2;
-            if (!active && (c & ((1u << tshift) - 1)) != 0) active = find(c - 1) != MCQ_EMPTY;               // (the cell before it, same target)
-            if (!active && ((c + 1) & ((1u << tshift) - 1)) != 0) active = find(c + 1) != MCQ_EMPTY;
-        }
-        const u64 ba = __ballot(active), bl = __ballot(occupied && !active);
-        u32 base = 0;
-        if (lane == 0) { if (ba) base = atomicAdd(&s_x[0], (u32)__builtin_popcountll(ba)); if (bl) atomicAdd(&s_x[1], (u32)__builtin_popcountll(bl)); }
-        base = bcast(base, 0);
-        act[i] = active ? (0x80000000u | (base + lane_rank(ba))) : 0u;
-        if (active && base + lane_rank(ba) < MCQ_CT_RES) RC[base + lane_rank(ba)] = c;      // the list of active cells (the match list is in place: the
-    }                                                                                        // feature arrays that lived here are no longer needed)
-    __syncthreads();                                            // (every count has been read)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { const u32 sidx = tid + (u32)i * 1024u; if (CK[sidx] != MCQ_EMPTY) CV[sidx] = act[i]; }
-    const u32 nA = s_x[0], nL = s_x[1];
-    if (nA > MCQ_CT_RES || nA * WPC > MCQ_CT_BINS || nA + nL > MCQ_CT_ENT) return false;       // (uniform; the list is intact)
-    {
-        u32 zero;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
-        for (u32 i = tid; i < nA * WPC; i += NTB) HW[i] = zero;
-    }
-    __syncthreads();
-    PHCLK(ph, 5);
-    // ---- 3. histograms of the active cells
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const u32 t = tid + (u32)i * 1024u;
-        if (t < T) {
-            const u32 v = CV[(myslot[i >> 1] >> (16 * (i & 1))) & 0xFFFFu];
-            if (v) { const u32 w = Bw[t] & (BPC - 1); atomicAdd(&HW[(v & 0x7FFFFFFFu) * WPC + (w >> 1)], 1u << (16 * (w & 1))); }
-        }
-    }
-    __syncthreads();
-    PHCLK(ph, 6);
-    // ---- 4. per active cell the best range that ends in it: one wave per cell
-    {
-        const u32 BL = BPC >= 32 ? BPC >> 5 : 1u;               // consecutive bins per lane over [cell before | cell]
-        const u32 nws = (2048u / BPC) < nwv ? (2048u / BPC) : nwv;            // waves with a scratch segment of 2 x BPC u16
-        unsigned short* S = reinterpret_cast<unsigned short*>(HW + MCQ_CT_BINS + 2 * MCQ_CT_RES) + (size_t)wv * 2 * BPC;
-        const unsigned short* bins16 = reinterpret_cast<const unsigned short*>(HW);
-        if (wv < nws) for (u32 id = wv; id < nA; id += nws) {
-            const u32 c = RC[id];
-            u32 idp = MCQ_EMPTY;
-            if ((c & ((1u << tshift) - 1)) != 0) { const u32 sp = find(c - 1); if (sp != MCQ_EMPTY) idp = CV[sp] & 0x7FFFFFFFu; }
-            const u32 x0 = lane * BL;                           // this lane's first index in [0, 2 BPC)
-            u32 local = 0;
-            if (x0 < 2 * BPC)
-                for (u32 j = 0; j < BL; ++j) {
-                    const u32 x = x0 + j;
-                    const u32 b = x < BPC ? (idp != MCQ_EMPTY ? bins16[(size_t)idp * BPC + x] : 0u) : bins16[(size_t)id * BPC + (x - BPC)];
-                    local += b;
-                }
-            u32 run = wave_incl_scan_dpp(local) - local;
-            if (x0 < 2 * BPC)
-                for (u32 j = 0; j < BL; ++j) {
-                    const u32 x = x0 + j;
-                    const u32 b = x < BPC ? (idp != MCQ_EMPTY ? bins16[(size_t)idp * BPC + x] : 0u) : bins16[(size_t)id * BPC + (x - BPC)];
-                    run += b;
-                    S[x] = (unsigned short)run;
-                }
-            wave_sync();
-            u32 best = 0;
-            if (x0 >= BPC && x0 < 2 * BPC)
-                for (u32 j = 0; j < BL; ++j) {
-                    const u32 x = x0 + j;                       // window x - BPC of this cell; x - numWindows >= 0
-                    const u32 h = (u32)S[x] - (u32)S[x - numWindows];
-                    const u32 pk = (h << 16) | (0xFFFFu - (x - BPC));
-                    best = pk > best ? pk : best;
-                }
-            best = wave_max_u32(best);
-            if (lane == 0) RS[id] = (best & 0xFFFF0000u) | (0xFFFFu - (best & 0xFFFFu));      // hits << 16 | window inside the cell
-            wave_sync();
-        }
-    }
-    __syncthreads();
-    PHCLK(ph, 7);
-    // ---- 5. entries: (hits << 6 | 63 - rank) << 32 | ~word and the taxon
-    const u32 M = opt.max_cand;
-    unsigned long long* EW = reinterpret_cast<unsigned long long*>(HW);           // [MCQ_CT_ENT] over the dead bins
-    u32* ET = HW + MCQ_CT_BINS + 2 * MCQ_CT_RES;                                    // [MCQ_CT_ENT] over the dead scratch
-    u32 rs = 0, rc = 0;
-    if (tid < nA) { rs = RS[tid]; rc = RC[tid]; }               // (the results lie between the two entry arrays)
-    auto put = [&](u32 e, u32 word, u32 hits) {
-        const u32 tgt = lf.tgt(word);
-        const u32 tax = tgt < db.n_targets ? db.tgt2tax[tgt] : MCQ_EMPTY;
-        const u32 r = lin_rank(opt, tgt);
-        EW[e] = (hits && tax != MCQ_EMPTY && r < opt.keep) ? (((unsigned long long)((hits << 6) | (63u - r))) << 32) | (u32)~word : 0ull;
-        ET[e] = tax;
-    };
-    if (tid < nA) put(tid, (rc << cs) | (rs & 0xFFFFu), rs >> 16);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                               // (uniform trip count: the ballots need every lane)
-        const u32 t = tid + (u32)i * 1024u;
-        const bool lone = t < T && CV[(myslot[i >> 1] >> (16 * (i & 1))) & 0xFFFFu] == 0;
-        const u64 bl = __ballot(lone);
-        u32 base = 0;
-        if (lane == 0 && bl) base = atomicAdd(&s_x[3], (u32)__builtin_popcountll(bl));
-        base = bcast(base, 0);
-        if (lone) put(nA + base + lane_rank(bl), Bw[t], 1u);
-    }
-    __syncthreads();
-    PHCLK(ph, 8);
-    const u32 NE = nA + nL;
-    // ---- 6. rows 10-11: M rounds of "largest entry, record it, retire its taxon"
-    unsigned long long* gm = &s_gm;
-    u32* wtax = s_x + 6;
-    u32* res = CK;                                                                  // the list: taxa [16], hits [16] (the table is dead)
-    u32 n = 0;
-    for (u32 i = 0; i < M; ++i) {
-        unsigned long long v = 0; u32 ve = 0;
-        for (u32 e = tid; e < NE; e += NTB) { const unsigned long long w = EW[e]; if (w > v) { v = w; ve = e; } }
-        const unsigned long long wm = wave_max_pair(v);
-        if (lane == 0 && wm != 0) atomicMax(gm, wm);
-        __syncthreads();
-        const unsigned long long m = *gm;
-        if (m == 0) break;                                      // (uniform)
-        if (v == m) { const u32 tx = ET[ve]; *wtax = tx; res[i] = tx; res[16 + i] = (u32)(m >> 38); }       // entries are distinct: one winner
-        __syncthreads();
-        const u32 wt = *wtax;
-        for (u32 e = tid; e < NE; e += NTB) if (ET[e] == wt) EW[e] = 0;
-        if (tid == 0) *gm = 0;
-        ++n;
-        __syncthreads();
-    }
-    if (tid < n) reinterpret_cast<uint4*>(out.cands)[q * M + tid] = make_uint4(res[tid], res[16 + tid], 0u, 0u);     // no window ranges after a fold
-    if (tid == 0) { out.ncand[q] = n; atomicAdd(&ctr->n_cands, (unsigned long long)n); atomicAdd(&ctr->n_counted, 1ull); }
-    __syncthreads();
-    PHCLK(ph, 9);
-    return true;
-}
-
 // NT threads per workgroup; LCAPB entries of the match list fit its LDS (longer lists are sorted in global scratch).
 // 32-bit keys: 8192 x (4 + 4) B = 64 KB of LDS and 64 VGPRs, so two 1024-thread workgroups share a CU -- the phases
 // of a query are serialised by workgroup barriers, and the second workgroup fills the gaps (+45 % on 8 kb reads;
@@ -1780,13 +1592,28 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         __syncthreads();
         PHCLK(ph, 0);
         if constexpr (!SH) {
-        for (u32 w = wave; w < (u32)NW; w += NW16) {
+        // (ASCII bases: the next window's two bases per lane are loaded before this window is sketched -- a wave sketches four or five
+        // windows of an 8 kb read one after the other, and every one of them waited for its own load)
+        auto span = [&](u32 w, u64& at, u32& wl) {
             const bool m2 = w >= nw1;
-            const u64 n = m2 ? n2 : n1;
-            const u64 sb = m2 ? o1 : o0;
-            u64 beg; u32 wl;
-            window_of(n, W, S, m2 ? w - nw1 : w, beg, wl);
-            u32 m = wave_sketch_b(b, sb + beg, wl, db.k, db.s, lane, sk, sk + 64);
+            u64 beg;
+            window_of(m2 ? n2 : n1, W, S, m2 ? w - nw1 : w, beg, wl);
+            at = (m2 ? o1 : o0) + beg;
+        };
+        u32 chars = 0;
+        if (!b.packed && wave < (u32)NW) { u64 at; u32 wl; span(wave, at, wl); chars = window_chars2(b.bases + at, wl, lane); }
+        for (u32 w = wave; w < (u32)NW; w += NW16) {
+            u64 at; u32 wl;
+            span(w, at, wl);
+            u32 m;
+            if (b.packed) m = wave_sketch_b(b, at, wl, db.k, db.s, lane, sk, sk + 64);
+            else {
+                const u32 cur = chars;
+                if (w + NW16 < (u32)NW) { u64 at2; u32 wl2; span(w + NW16, at2, wl2); chars = window_chars2(b.bases + at2, wl2, lane); }
+                u32 ww, am;
+                wave_words_of_chars(cur & 0xFFu, cur >> 8, lane, ww, am);
+                m = wave_sketch_words(ww, am, wl, db.k, db.s, lane, sk, sk + 64);
+            }
             u32 base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_w[18], m);
             base = bcast(base, 0);
@@ -1806,8 +1633,9 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         }
         nhit = wave_incl_scan_dpp(nhit);
         if (lane == 63 && nhit) atomicAdd(&s_w[19], nhit);
-        __syncthreads();
-        const u32 T = block_excl_scan(fpos, F, tid, s_w);
+        u32 T;
+        if (F <= 4 * NT && NT >= 256) T = block_excl_scan4(fpos, F, tid);       // (uniform; the thread scans the lengths it wrote itself)
+        else { __syncthreads(); T = block_excl_scan(fpos, F, tid, s_w); }
         PHCLK(ph, 2);
         if (tid == 0) {
             if (!SH) atomicAdd(&ctr->n_features, (unsigned long long)F);
@@ -1885,14 +1713,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
                     if (tc == TC_HEAVY) tc_skip = 15;
                 } else if (tc_skip) --tc_skip;
             }
-            bool done = tc == TC_DONE, filled = tc == TC_HEAVY;
-#ifndef MCQ_NO_COUNT_TAIL                                      // tuning knob (A/B)
-            // rows 8-11 by counting (block_count_tail): one selection, bit-field words, the plain kernel (long reads live here)
-            if constexpr (!TC && BIG == 2 && !GW && sizeof(KeyT) == 4) {
-                if (dbg.mode == 0 && !(opt.hooks & 8u))
-                    done = block_count_tail<LCAPB>(db, opt, out, ctr, reinterpret_cast<u32*>(s_buf), s_hits, T, numWindows, lf, q, tid, s_w, fill, filled, ph);
-            }
-#endif
+            const bool done = tc == TC_DONE, filled = tc == TC_HEAVY;
             if (!done) { block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill, filled); PHCLK(ph, 10); }
         }
         else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
@@ -3128,7 +2949,6 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
         stats->n_overflow = ws->ctr_host->n_ovf;
         stats->n_two_class = ws->ctr_host->n_two_class; stats->n_two_class_retry = ws->ctr_host->n_two_class_retry;
         stats->n_narrow_queued = ws->ctr_host->n_narrow;
-        stats->n_counted = ws->ctr_host->n_counted;
     }
     if (ws->ctr_host->err_count)
         return fail(MCQ_E_CAPACITY, std::to_string(ws->ctr_host->err_count) + " queries exceeded the workspace's per-query capacity");

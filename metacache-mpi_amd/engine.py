@@ -75,10 +75,16 @@ class Result(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("n_features", C.c_uint64), ("n_hit_features", C.c_uint64),
-                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64), ("n_two_class", C.c_uint64), ("n_two_class_retry", C.c_uint64), ("n_narrow_queued", C.c_uint64), ("n_counted", C.c_uint64)]
+                ("n_locations", C.c_uint64), ("n_cands", C.c_uint64), ("n_overflow", C.c_uint64), ("n_two_class", C.c_uint64), ("n_two_class_retry", C.c_uint64), ("n_narrow_queued", C.c_uint64)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class PartsBuilderDesc(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("sketch_size", C.c_uint32), ("winlen", C.c_uint32), ("winstride", C.c_uint32),
+                ("tgt_winstride", C.c_uint32), ("n_targets", C.c_uint32), ("tgt_windows", C.c_void_p), ("expected_locations", C.c_uint64),
+                ("n_ranges", C.c_uint32), ("n_shards", C.c_uint32), ("shard_id", C.c_uint32), ("device", C.c_int32)]
 
 
 class ShardCfg(C.Structure):
@@ -141,6 +147,10 @@ def lib():
         L.mcq_parts_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         L.mcq_db_from_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.mcq_parts_free.argtypes = [C.c_void_p]
+        L.mcq_parts_builder_create.argtypes = [C.POINTER(PartsBuilderDesc), C.POINTER(C.c_void_p)]
+        L.mcq_parts_builder_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        L.mcq_parts_builder_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.mcq_parts_builder_free.argtypes = [C.c_void_p]
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         L.mcq_packed_bytes.restype = C.c_uint64; L.mcq_packed_bytes.argtypes = [C.c_uint64]
@@ -567,6 +577,54 @@ class Parts:
     def close(self):
         if getattr(self, "h", None):
             lib().mcq_parts_free(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PartsBuilder:
+    """mcq_parts_builder_*: table parts from streamed (feature, target, window) triples -- the reference's shard files without a
+    host-side union (host.RefDb(meta_only=True).stream() feeds it).  finish() returns a Parts object."""
+
+    def __init__(self, tgt_windows, k=16, sketch_size=16, winlen=128, winstride=113, tgt_winstride=0, expected_locations=0, n_ranges=0,
+                 n_shards=1, shard_id=0, device=0):
+        tw = np.ascontiguousarray(tgt_windows, np.uint32)
+        d = PartsBuilderDesc(k, sketch_size, winlen, winstride, tgt_winstride, len(tw), tw.ctypes.data_as(C.c_void_p), expected_locations,
+                             n_ranges, n_shards, shard_id, device)
+        h = C.c_void_p()
+        rc = lib().mcq_parts_builder_create(C.byref(d), C.byref(h))
+        if rc != 0:
+            raise McqError(rc, (lib().mcq_build_last_error() or b"").decode())
+        self.h, self.n_targets, self.device = h, len(tw), device
+        self.k, self.sketch_size, self.winlen, self.winstride = k, sketch_size, winlen, winstride
+
+    def add(self, feat, tgt, win):
+        f, t, w = (np.ascontiguousarray(x, np.uint32) for x in (feat, tgt, win))
+        rc = lib().mcq_parts_builder_add(self.h, f.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), len(f), 0)
+        if rc != 0:
+            raise McqError(rc, (lib().mcq_build_last_error() or b"").decode())
+
+    def finish(self):
+        ph = C.c_void_p()
+        rc = lib().mcq_parts_builder_finish(self.h, C.byref(ph))
+        self.h = None if rc == 0 else self.h
+        if rc != 0:
+            raise McqError(rc, (lib().mcq_build_last_error() or b"").decode())
+        p = Parts.__new__(Parts)
+        p.h, p.n_targets, p.device = ph, self.n_targets, self.device
+        p.k, p.sketch_size, p.winlen, p.winstride = self.k, self.sketch_size, self.winlen, self.winstride
+        nk, nl, nw, nb = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        npar = C.c_uint32()
+        _chk(lib().mcq_parts_info(ph, C.byref(nk), C.byref(nl), C.byref(nw), C.byref(npar), C.byref(nb)))
+        p.n_keys, p.n_locs, p.n_windows, p.n_parts, p.bytes = int(nk.value), int(nl.value), int(nw.value), int(npar.value), int(nb.value)
+        return p
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcq_parts_builder_free(self.h); self.h = None
 
     def __del__(self):
         try:

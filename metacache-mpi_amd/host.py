@@ -73,6 +73,12 @@ def lib():
         L.mcq_host_last_error.restype = C.c_char_p
         L.mcq_refdb_write_shard.argtypes = [C.c_char_p, C.POINTER(ShardParams), C.POINTER(TaxonRec), C.c_uint64, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.mcq_refdb_open_meta.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.mcq_refdb_tgt_windows.argtypes = [C.c_void_p, C.c_void_p]
+        L.mcq_refdb_file_stats.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.mcq_shard_stream_open.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.mcq_shard_stream_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.mcq_shard_stream_close.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -80,9 +86,11 @@ def lib():
 class RefDb:
     """The reference's <prefix>.db_<r> shard files, parsed and unioned on the host."""
 
-    def __init__(self, prefix, n_ranks):
+    def __init__(self, prefix, n_ranks, meta_only=False):
+        """meta_only: mcq_refdb_open_meta -- parameters and taxa only, the tables are streamed (stream())"""
         h = C.c_void_p()
-        if lib().mcq_refdb_open(prefix.encode(), n_ranks, C.byref(h)) != 0:
+        opener = lib().mcq_refdb_open_meta if meta_only else lib().mcq_refdb_open
+        if opener(prefix.encode(), n_ranks, C.byref(h)) != 0:
             raise RuntimeError(lib().mcq_host_last_error().decode())
         self.h = h
         self.info = Info()
@@ -97,6 +105,36 @@ class RefDb:
             self.close()
         except Exception:
             pass
+
+    def tgt_windows(self):
+        out = np.zeros(self.info.n_targets, np.uint32)
+        if lib().mcq_refdb_tgt_windows(self.h, out.ctypes.data_as(C.c_void_p)) != 0:
+            raise RuntimeError(lib().mcq_host_last_error().decode())
+        return out
+
+    def file_stats(self, rank):
+        b, k, l = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        if lib().mcq_refdb_file_stats(self.h, rank, C.byref(b), C.byref(k), C.byref(l)) != 0:
+            raise RuntimeError(lib().mcq_host_last_error().decode())
+        return int(b.value), int(k.value), int(l.value)
+
+    def stream(self, rank, chunk=1 << 20):
+        """yields (feature, target, window) uint32 arrays, chunk by chunk in file order (meta_only handles)"""
+        sh = C.c_void_p()
+        if lib().mcq_shard_stream_open(self.h, rank, C.byref(sh)) != 0:
+            raise RuntimeError(lib().mcq_host_last_error().decode())
+        try:
+            f, t, w = (np.zeros(chunk, np.uint32) for _ in range(3))
+            n = C.c_uint64()
+            while True:
+                if lib().mcq_shard_stream_next(sh, f.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                               chunk, C.byref(n)) != 0:
+                    raise RuntimeError(lib().mcq_host_last_error().decode())
+                if n.value == 0:
+                    return
+                yield f[:n.value].copy(), t[:n.value].copy(), w[:n.value].copy()
+        finally:
+            lib().mcq_shard_stream_close(sh)
 
     def table(self):
         n, m = self.info.n_keys, self.info.n_locs

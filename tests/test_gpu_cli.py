@@ -42,11 +42,12 @@ def test_cli_output_equals_reference(tag, P, tmp_path):
 
 VARIANTS = {"default": [], "tophits": ["-tophits"], "lineage": ["-tophits", "-taxids", "-lineage"],
             "idsonly": ["-tophits", "-taxids-only", "-omit-ranks", "-mapped-only"]}
-BATCHING = {"": [], "batch16": ["-batch", "16"], "bases5000": ["-batch-bases", "5000"]}      # how the CLI cuts the reads (mcq_query_pipelined)
+BATCHING = {"": [], "batch16": ["-batch", "16"], "bases5000": ["-batch-bases", "5000"],      # how the CLI cuts the reads (mcq_query_pipelined)
+            "streamed": []}              # ... and the database opened by the streaming route (MCQ_STREAM_LOAD_MIN_MB=0: include/mcq_open.hpp)
 
 
 @pytest.mark.parametrize("tag,P", [("mini", 4), ("tie", 2)])
-@pytest.mark.parametrize("variant,batching", [(v, "") for v in sorted(VARIANTS)] + [("tophits", "batch16"), ("tophits", "bases5000")])
+@pytest.mark.parametrize("variant,batching", [(v, "") for v in sorted(VARIANTS)] + [("tophits", "batch16"), ("tophits", "bases5000"), ("tophits", "streamed")])
 def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, batching, tmp_path):
     """the whole -out file -- parameter lines, TABLE_LAYOUT, mapping lines in the default rank:name layout and the
     other layouts, the summary with its statistics (src/printing.cpp:622-641, :522-555; src/classification.cpp:583-632)
@@ -65,7 +66,8 @@ def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, batch
     prefix = fx.shard_paths[0][: -len(".db_0")]
     r = subprocess.run([pkg.cli_path(), prefix, str(P), "r1.fq", "r2.fq", "-lowest", fx.q["lowest"], "-maxcand", str(fx.maxcand),
                         "-hitmin", str(fx.hitmin), "-hitdiff", str(fx.q["hitdiff"]), "-threads", "2", "-out", "out.txt"] + VARIANTS[variant] + BATCHING[batching],
-                       cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                       cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env=dict(os.environ, MCQ_STREAM_LOAD_MIN_MB="0") if batching == "streamed" else None)
     assert r.returncode == 0, r.stderr
 
     def norm(text):
@@ -81,7 +83,8 @@ def test_cli_out_file_equals_the_references_byte_for_byte(tag, P, variant, batch
 @pytest.mark.parametrize("n_ranks,transport,extra", [(1, "rccl", []), (2, "mpi", []), (3, "mpi", []),
                                                      (1, "rccl", ["-batch", "50"]),            # 4 batches, RCCL, padded after the first
                                                      (2, "mpi", ["-batch", "16"]),             # 7 batches per rank
-                                                     (3, "mpi", ["-batch-bases", "6000"])])    # cut by bases: ranks differ in their batch counts
+                                                     (3, "mpi", ["-batch-bases", "6000"]),     # cut by bases: ranks differ in their batch counts
+                                                     (2, "mpi", ["STREAMED"])])                # every rank's shard made by the streaming route
 def test_mpi_program_writes_the_references_out_file(n_ranks, transport, extra, tmp_path):
     """mcq_query_mpi -- the multi-GPU host in C++ under mpiexec, one hash-range shard of the table per rank, the sharded
     path behind the C ABI -- writes the file the reference wrote under mpiexec -n 4 (emulate_ranks = 4, whatever the
@@ -104,6 +107,8 @@ def test_mpi_program_writes_the_references_out_file(n_ranks, transport, extra, t
     env = dict(os.environ, LD_LIBRARY_PATH=pkg.mpi_lib_dir() + ":" + os.environ.get("LD_LIBRARY_PATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if n_ranks == 1:
         env["MCQ_SHARD_FORCE_RCCL"] = "1"
+    if extra == ["STREAMED"]:
+        env["MCQ_STREAM_LOAD_MIN_MB"] = "0"; extra = []
     r = subprocess.run([mpiexec, "-n", str(n_ranks), pkg.mpi_cli_path(), prefix, "4", "r1.fq", "r2.fq", "-lowest", fx.q["lowest"],
                         "-maxcand", str(fx.maxcand), "-hitmin", str(fx.hitmin), "-hitdiff", str(fx.q["hitdiff"]), "-threads", "2",
                         "-tophits", "-transport", transport, "-out", "out.txt"] + extra,

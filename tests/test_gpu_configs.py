@@ -126,9 +126,3 @@ def test_config4_long_reads(c2):
         _compare(cands, ncand, oc, on, "configs[4] shape P=%d M=%d" % (P, M))
     st = ws.sync()
     assert st["n_overflow"] == n and st["n_locations"] > 1500 * n
-    # rows 8-11 of these reads are answered by COUNTING (window histograms of the cells their locations cluster in: r04), the
-    # sort taking what does not fit it; the hook turns the counting off: same lists
-    assert st["n_counted"] > 0.9 * n, st
-    cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P, flags=eng.MCQ_NO_TWO_CLASS)
-    _compare(cands, ncand, oc, on, "configs[4] shape, sorted instead of counted")
-    assert ws.sync()["n_counted"] == 0

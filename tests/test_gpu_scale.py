@@ -90,29 +90,20 @@ def test_long_reads_take_the_block_path(world):
 
 
 @pytest.mark.parametrize("L,n,sub", [(1000, 1500, 0.05), (2500, 800, 0.06), (9000, 400, 0.10), (20000, 200, 0.14), (45000, 80, 0.18)])
-def test_long_reads_by_counting(world, L, n, sub):
-    """The workgroup kernel's counting tail (block_count_tail: cells of 2^cs >= numWindows windows, dense window histograms of
-    the cells that hold more than a lone word, prefix sums instead of the sort + sweep) against the oracle: read lengths from
-    1 kb (numWindows 10: cells of 16 windows) to 45 kb (400: cells of 512), P x M from one entry to 16, and the same with the
-    counting switched off.  (Error rates rise with the length so that the lists stay within the 4096 words the tail takes: the
-    fixture's species have 12 strains.)  Most reads must have been counted."""
+def test_long_reads_of_every_length(world, L, n, sub):
+    """The workgroup kernel over read lengths from 1 kb (numWindows 10) to 45 kb (400), lists in LDS and in global scratch, P x M
+    from one entry to 16 and a non-power-of-two P, against the oracle.  (Written in r04 for a counting tail -- window histograms
+    instead of sort + sweep -- that was parity-green on all of it and 8 % slower: DESIGN.md section 11.)"""
     eng, synth, gb, goff, dbs = world
-    db, odb = dbs[2]                                   # bit-field words (the counting tail's form)
+    db, odb = dbs[2]
     reads, off, _ = synth.sample_reads(gb, goff, n, L, sub, 0.001, seed=4242 + L)
     ws = eng.Workspace(db, n, n * L)
     rb = reads.cpu().numpy().tobytes(); ro = off.cpu().numpy().astype(np.uint64)
-    counted = 0
     for P, M in ((2, 1), (2, 2), (4, 4), (8, 2), (16, 16), (3, 4)):
         oc, on = odb.query(rb, ro, False, max_cand=M, emulate_ranks=P, threads=8)
         cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P)
-        _compare(cands, ncand, oc, on, "counted L=%d P=%d M=%d" % (L, P, M))
-        st = ws.sync()
-        assert st["n_overflow"] == n
-        counted += st["n_counted"]
-        cands, ncand = ws.query_host(rb, ro, False, max_cand=M, emulate_ranks=P, flags=eng.MCQ_NO_TWO_CLASS)
-        _compare(cands, ncand, oc, on, "sorted L=%d P=%d M=%d" % (L, P, M))
-        assert ws.sync()["n_counted"] == 0
-    assert counted > 3 * n, counted                    # (of 6 x n)
+        _compare(cands, ncand, oc, on, "L=%d P=%d M=%d" % (L, P, M))
+        assert ws.sync()["n_overflow"] == n
 
 
 def test_db_roundtrip_lookup(world):
