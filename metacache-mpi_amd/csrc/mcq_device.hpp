@@ -25,6 +25,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define MCQ_EMPTY 0xFFFFFFFFu
+#define MCQ_Q_UNPROBED 0x80000000u     // back-queue entry of the direct mode: the second wave stage sketches and probes it itself (queries are < 2^31)
 #define MCQ_MAX_FOLD 64
 #define MCQ_BIGLIST_MAX 1024u        // 64 virtual ranks x 16 candidates
 
@@ -165,10 +166,16 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     // queues by their length here -- 64 words per back-queue slot: list offset << 16 | list length of the
     // lane's feature -- so the second stage neither sketches nor probes them again.  (In a cache line of its own: the
     // counters above are hammered by atomics, and a load from their line queues behind them.)
-    unsigned long long pad_[23];      // (diagnostic builds, -DMCQ_PHASE_CLOCK: phase clocks of the workgroup kernel)
+    unsigned long long n_short;       // direct mode: queued queries whose list the first wave stage would have kept (<= 512 locations)
+    unsigned long long pad_[22];      // (diagnostic builds, -DMCQ_PHASE_CLOCK: phase clocks of the workgroup kernel)
     unsigned long long* probe_buf;
     unsigned long long* probe_front;  // the same for FRONT-queue slots of queries with <= 64 features (third wave stage); a lane without
                                       // a feature holds 0xFFFF
+    // not zeroed per call either: how the NEXT batch on this workspace enters (k_next_mode, after the last kernel of a batch).
+    // 1 = direct: most of this batch's queries left the first wave stage (a table with long lists: RefSeq scale, 99 %), so the next
+    // batch's first stage only looks at the geometry of its queries -- one LANE per query -- and queues all of them; the second
+    // stage sketches and probes what it takes.  Results are the same either way; only the path differs.
+    u32 direct_mode;
 };
 static_assert(offsetof(CountersDev, probe_buf) == 256, "probe_buf sits 256 bytes into the block");
 #define MCQ_CTR_ZEROED offsetof(CountersDev, probe_buf)
@@ -225,7 +232,8 @@ __device__ __forceinline__ void shard_fetch(const ShardDev& sh, u64 slot, u64& o
 #endif
 #define MCQ_OVF_TAIL (MCQ_OVF_CHUNK * 32768u)      // unused reservation tails of one set of waves
 #define MCQ_OVF_PAD (3u * MCQ_OVF_TAIL)
-__device__ __host__ __forceinline__ u64 ovf_capacity(u64 nq) { return 2 * nq + MCQ_OVF_PAD; }
+// (+ nq / 8: the direct mode's first stage reserves whole chunks per 64 queries, ~5 % of its slots stay empty)
+__device__ __host__ __forceinline__ u64 ovf_capacity(u64 nq) { return 2 * nq + nq / 8 + MCQ_OVF_PAD; }
 __device__ __forceinline__ u64 ovf_slot(u64 nq, int back, u32 i) { return back ? ovf_capacity(nq) - 1 - i : (u64)i; }
 // Draining order: slot of the it-th visit.  Reservations are filled from their first slot, so the real entries sit at
 // the low positions of every chunk; a drainer striding through the slots by a multiple of its size (5120 waves, 512

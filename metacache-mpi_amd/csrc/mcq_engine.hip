@@ -914,6 +914,37 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
     wave_sync();
 #endif
 
+#ifndef MCQ_NO_DIRECT_MODE                             // tuning knob (A/B)
+    // Direct mode (CountersDev::direct_mode, set by the batch before): most queries of such a batch leave this stage anyway -- it
+    // would sketch, probe, scan, write 512 B of probe results and push one queue entry per wave and query (2.3 ms per 1 M reads at
+    // RefSeq scale).  Instead one LANE per query looks at its geometry and every query is queued: wide and narrow ones to the back
+    // queue, flagged MCQ_Q_UNPROBED (the second stage sketches and probes two features per lane as it does for wide reads), more
+    // than 128 features to the front queue.  Whole chunks of queue slots per 64 queries, one atomic per queue.
+    if constexpr (sizeof(KeyT) == 4 && !TAP && NL == 1) {
+        if (ctr->direct_mode && !(force_block & 7) && stop == 0) {
+            for (u64 q0 = ((u64)blockIdx.x * 4 + wave) * 64; q0 < b.nq; q0 += nwaves * 64) {
+                const u64 q = q0 + lane;
+                const bool valid = q < b.nq;
+                bool front = false;
+                if (valid) { const ReadGeom g = read_geom(db, b, q, 0); front = g.ovf && !g.wide; }
+#pragma unroll
+                for (int back = 0; back < 2; ++back) {
+                    const u64 m = __ballot(valid && (back ? !front : front));
+                    const u32 cnt = (u32)__builtin_popcountll(m);
+                    if (!cnt) continue;                                 // (wave-uniform)
+                    const u32 padded = (cnt + MCQ_OVF_CHUNK - 1) / MCQ_OVF_CHUNK * MCQ_OVF_CHUNK;
+                    u32 base = 0;
+                    if (lane == 0) base = atomicAdd(back ? &ctr->ovf_mid_count : &ctr->ovf_count, padded);
+                    base = bcast(base, 0);
+                    if (valid && (back ? !front : front)) ovf_list[ovf_slot(b.nq, back, base + lane_rank(m))] = (u32)q | (back ? MCQ_Q_UNPROBED : 0u);
+                    if (lane < padded - cnt) ovf_list[ovf_slot(b.nq, back, base + cnt + lane)] = MCQ_EMPTY;
+                }
+                if (lane == 0) atomicAdd(&ctr->n_ovf, (u32)__builtin_popcountll(__ballot(valid)));
+            }
+            return;
+        }
+    }
+#endif
     for (u64 q = (u64)blockIdx.x * 4 + wave; q < b.nq; q += nwaves) {
         const ReadGeom g = read_geom(db, b, q, force_block);
         bool ovf = g.ovf;
@@ -1079,22 +1110,25 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     u32* feat = hits + 64;
     const u32 nwaves = gridDim.x * 4;
     const u32 n_mid = ctr->ovf_mid_count;
-    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_retry = 0;
+    unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_retry = 0, st_short = 0;
     u32 fq_next = 0, fq_left = 0;                      // this wave's reservation in the front queue (wide reads with > 1024 locations)
     // size of the space the location words live in (for the light-word threshold of the two-class tail)
     float word_space;
     if constexpr (GW) word_space = (float)gwd.off[db.n_targets];
     else word_space = (db.wb < 32 && ((u64)db.n_targets << db.wb) < 0xFFFFFFFFull) ? (float)((u64)db.n_targets << db.wb) : 4294967040.0f;
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
-        const u32 q32 = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
-        if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
+        const u32 qe = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
+        if (qe == MCQ_EMPTY) continue;                 // unused tail of a wave's reservation
+        const u32 q32 = qe & ~MCQ_Q_UNPROBED;
         const u64 q = q32;
         const ReadGeom g = read_geom(db, b, q, 0);
+        // fresh: nothing is known of the query's features yet -- a wide read, or any read the first stage queued unseen (direct mode)
+        const bool fresh = g.wide || (qe & MCQ_Q_UNPROBED) != 0;
         u32 nfeat = 0;                                 // <= 128: the first stage queued nothing wider
         bool two = false;
         u64 off0 = 0, off1 = 0; u32 len0 = 0, len1 = 0;
 #ifndef MCQ_NO_PROBE_HANDOVER
-        if (!g.wide) {                                 // queued by its length: the first stage left its probe results
+        if (!fresh) {                                  // queued by its length: the first stage left its probe results
             const u64 pw = ctr->probe_buf[(u64)ovf_visit(it, n_mid) * 64 + lane];
             off0 = pw >> 16; len0 = (u32)(pw & 0xFFFFu);
         } else
@@ -1124,13 +1158,18 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         const u32 incl1 = wave_incl_scan_dpp(len1) + T0;
         const u32 pos0 = incl0 - len0, pos1 = incl1 - len1;
         const u32 T = bcast(incl1, 63);                // <= 1024 for the queries queued by their length
-        if (T > (u32)LCAP) {                           // a wide read with a longer list: on to the workgroup kernel
+        if (T > (u32)LCAP) {                           // a longer list than this stage takes: on to the front queue
             if (fq_left == 0) {
                 u32 base = 0;
                 if (lane == 0) base = atomicAdd(&ctr->ovf_count, MCQ_OVF_CHUNK);
                 fq_next = bcast(base, 0); fq_left = MCQ_OVF_CHUNK;
             }
             if (lane == 0) ovf_list[fq_next] = q32;
+#ifndef MCQ_NO_FRONT_HANDOVER
+            // (direct mode) <= 64 features: the third wave stage reads such an entry's probe results from the slot's row, as it does
+            // for the entries the first stage queues there itself; it counts the features (no bit 63)
+            if constexpr (!SH) { if (!g.wide) ctr->probe_front[(u64)fq_next * 64 + lane] = lane < nfeat ? ((off0 << 16) | len0) : 0xFFFFull; }
+#endif
             ++fq_next; --fq_left;
             continue;
         }
@@ -1139,7 +1178,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
 #ifdef MCQ_NO_PROBE_HANDOVER
         {
 #else
-        if (g.wide) {                                  // (the first stage counted the features of the others)
+        if (fresh) {                                   // (the first stage counted the features of the others)
 #endif
             if constexpr (!SH) st_feat += nfeat;
             st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
@@ -1147,7 +1186,8 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        if (T <= MCQ_DEDUP_MAX_T) {                    // a wide read with a short list: the distinct-key tail of the first stage
+        if (T <= MCQ_DEDUP_MAX_T && (qe & MCQ_Q_UNPROBED)) st_short += 1;       // (direct mode: the first stage would have kept this one)
+        if (T <= MCQ_DEDUP_MAX_T) {                    // a short list (a wide read, or direct mode): the distinct-key tail of the first stage
             u32 D, k1 = MCQ_EMPTY, incl1 = 0, t1 = 0, tb1 = 0;
             if (T <= 128)      D = gather2_dedup_insert<2>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
             else if (T <= 256) D = gather2_dedup_insert<4>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
@@ -1170,7 +1210,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
                 const u32 n2 = two_class_tail<16>(db, opt, out, r, T, numWindows, word_space, lf, q, lane, buf, hits);
                 if (n2 == ~1u) {                        // given up after the registers were spent: the workgroup kernel takes it
                     st_loc -= T; st_retry += 1;
-                    if (g.wide) {                       // (the workgroup kernel counts them again)
+                    if (fresh) {                        // (the next stage counts them again)
                         if constexpr (!SH) st_feat -= nfeat;
                         st_hit -= (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
                     }
@@ -1183,7 +1223,8 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
 #ifndef MCQ_NO_FRONT_HANDOVER
                     // <= 64 features: the third wave stage reads every such front entry's probe results from the slot's row
                     // (bit 63: features and hit features are counted already -- the first stage did that at its hand-over)
-                    if constexpr (!SH) { if (!g.wide) ctr->probe_front[(u64)fq_next * 64 + lane] = (1ull << 63) | (off0 << 16) | len0; }
+                    if constexpr (!SH) { if (!g.wide) ctr->probe_front[(u64)fq_next * 64 + lane] = fresh ? (lane < nfeat ? ((off0 << 16) | len0) : 0xFFFFull)
+                                                                                                           : ((1ull << 63) | (off0 << 16) | len0); }
 #endif
                     ++fq_next; --fq_left;
                     wave_sync();
@@ -1204,6 +1245,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
     if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
     if (lane == 0 && st_retry) atomicAdd(&ctr->n_two_class_retry, st_retry);
+    if (lane == 0 && st_short) atomicAdd(&ctr->n_short, st_short);
     if (lane == 0 && (st_feat | st_loc | st_hit)) {
         if (st_feat) atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);
@@ -2716,6 +2758,13 @@ struct LaunchTimer {
     }
 };
 
+// how the next batch on this workspace enters (CountersDev::direct_mode): after the last kernel of a batch.  In the direct mode every
+// query counts as queued; those the second stage found short (n_short) would not have been.  Enter at 3/4, leave at 1/2.
+__global__ void k_next_mode(CountersDev* ctr, u64 nq) {
+    const unsigned long long would = (unsigned long long)ctr->n_ovf - ctr->n_short;
+    ctr->direct_mode = ctr->direct_mode ? (would * 2 > nq ? 1u : 0u) : (would * 4 > nq * 3 ? 1u : 0u);
+}
+
 // sh != nullptr: the feature-sharded home side (SH instantiations; dbd = the handle's DbDev with `locs` pointing at the
 // received location buffer); the counters are then zeroed by the caller (the sketch kernel has already counted)
 static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const OptDev& od_in, const OutDev& o,
@@ -2804,6 +2853,10 @@ static int launch_query(const mcq_db* db, mcq_ws* ws, const BatchDev& b, const O
 #undef MCQ_LAUNCH_TC
     }
     rc = tm.end(); if (rc) return rc;
+#ifndef MCQ_NO_DIRECT_MODE
+    if (db->d.compact && !tap && !many && !(force_block & 7) && !getenv("MCQ_NO_DIRECT_MODE")) hipLaunchKernelGGL(k_next_mode, dim3(1), dim3(1), 0, st, ws->ctr, b.nq);
+    else HIPCHK(hipMemsetAsync(&ws->ctr->direct_mode, 0, 4, st));
+#endif
     HIPCHK(hipGetLastError());
     ws->last_nq = b.nq;
     return MCQ_OK;
@@ -2946,7 +2999,7 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
         stats->n_queries = ws->last_nq;
         stats->n_features = ws->ctr_host->n_features; stats->n_hit_features = ws->ctr_host->n_hit_features;
         stats->n_locations = ws->ctr_host->n_locations; stats->n_cands = ws->ctr_host->n_cands;
-        stats->n_overflow = ws->ctr_host->n_ovf;
+        stats->n_overflow = ws->ctr_host->n_ovf - ws->ctr_host->n_short;      // (direct mode: every query is queued; those the first stage would have kept are not counted)
         stats->n_two_class = ws->ctr_host->n_two_class; stats->n_two_class_retry = ws->ctr_host->n_two_class_retry;
         stats->n_narrow_queued = ws->ctr_host->n_narrow;
     }

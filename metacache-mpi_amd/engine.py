@@ -147,10 +147,11 @@ def lib():
         L.mcq_parts_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
         L.mcq_db_from_parts.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
         L.mcq_parts_free.argtypes = [C.c_void_p]
-        L.mcq_parts_builder_create.argtypes = [C.POINTER(PartsBuilderDesc), C.POINTER(C.c_void_p)]
-        L.mcq_parts_builder_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
-        L.mcq_parts_builder_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
-        L.mcq_parts_builder_free.argtypes = [C.c_void_p]
+        if hasattr(L, "mcq_parts_builder_create"):          # (an older build of the library under MCQ_HIP_LIB, for same-box A/B runs, lacks the r04 entry points)
+            L.mcq_parts_builder_create.argtypes = [C.POINTER(PartsBuilderDesc), C.POINTER(C.c_void_p)]
+            L.mcq_parts_builder_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+            L.mcq_parts_builder_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+            L.mcq_parts_builder_free.argtypes = [C.c_void_p]
         L.mcq_reduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.POINTER(QueryOpts), C.POINTER(Result), C.c_void_p]
         L.mcq_packed_bytes.restype = C.c_uint64; L.mcq_packed_bytes.argtypes = [C.c_uint64]
@@ -357,7 +358,8 @@ class Workspace:
     def phase_clocks(self):
         """diagnostic builds (-DMCQ_PHASE_CLOCK): shader clocks per phase of the workgroup kernel of the last synchronised call"""
         out = (C.c_uint64 * 22)()
-        _chk(lib().mcq_debug_phase_clocks(self.h, out))
+        if hasattr(lib(), "mcq_debug_phase_clocks"):
+            _chk(lib().mcq_debug_phase_clocks(self.h, out))
         return [int(x) for x in out]
 
     def kernel_times(self):
