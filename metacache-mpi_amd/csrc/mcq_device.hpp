@@ -167,14 +167,18 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     // lane's feature -- so the second stage neither sketches nor probes them again.  (In a cache line of its own: the
     // counters above are hammered by atomics, and a load from their line queues behind them.)
     unsigned long long n_short;       // direct mode: queued queries whose list the first wave stage would have kept (<= 512 locations)
-    unsigned long long pad_[22];      // (diagnostic builds, -DMCQ_PHASE_CLOCK: phase clocks of the workgroup kernel)
+    unsigned long long n_geom;        // queries with more than 128 features: the workgroup kernels' by their geometry alone
+    unsigned long long pad_[21];      // (diagnostic builds, -DMCQ_PHASE_CLOCK: phase clocks of the workgroup kernel)
     unsigned long long* probe_buf;
     unsigned long long* probe_front;  // the same for FRONT-queue slots of queries with <= 64 features (third wave stage); a lane without
                                       // a feature holds 0xFFFF
     // not zeroed per call either: how the NEXT batch on this workspace enters (k_next_mode, after the last kernel of a batch).
-    // 1 = direct: most of this batch's queries left the first wave stage (a table with long lists: RefSeq scale, 99 %), so the next
-    // batch's first stage only looks at the geometry of its queries -- one LANE per query -- and queues all of them; the second
-    // stage sketches and probes what it takes.  Results are the same either way; only the path differs.
+    // Direct entry: the next batch's first stage only looks at the geometry of its queries -- one LANE per query -- and queues all
+    // of them.  bit 1: most of this batch's queries had more than 128 features (long reads: the first stage did nothing for them
+    // but push one queue entry per wave).  bit 0: most of them left the first stage one way or the other (a table with long
+    // lists: RefSeq scale, 99 %) -- taken by the sharded home side only, whose first stage has no sketch to lose: on the fused
+    // path the second stage (4 waves per SIMD) sketches and probes no faster than the first (8), measured +-2 %.  Results are
+    // the same either way; only the path differs.
     u32 direct_mode;
 };
 static_assert(offsetof(CountersDev, probe_buf) == 256, "probe_buf sits 256 bytes into the block");

@@ -896,6 +896,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
     u32* feat = hits + 64;
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
+    u32 st_geom = 0;
 #ifdef MCQ_PROFILE_HOOKS
     const int stop = force_block >> 4;              // profiling builds: stop after stage 1..5 (results invalid); 0 = run everything
 #else
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
     // queue, flagged MCQ_Q_UNPROBED (the second stage sketches and probes two features per lane as it does for wide reads), more
     // than 128 features to the front queue.  Whole chunks of queue slots per 64 queries, one atomic per queue.
     if constexpr (sizeof(KeyT) == 4 && !TAP && NL == 1) {
-        if (ctr->direct_mode && !(force_block & 7) && stop == 0) {
+        if ((ctr->direct_mode & (SH ? 1u : 2u)) && !(force_block & 7) && stop == 0) {
             for (u64 q0 = ((u64)blockIdx.x * 4 + wave) * 64; q0 < b.nq; q0 += nwaves * 64) {
                 const u64 q = q0 + lane;
                 const bool valid = q < b.nq;
@@ -939,7 +940,8 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
                     if (valid && (back ? !front : front)) ovf_list[ovf_slot(b.nq, back, base + lane_rank(m))] = (u32)q | (back ? MCQ_Q_UNPROBED : 0u);
                     if (lane < padded - cnt) ovf_list[ovf_slot(b.nq, back, base + cnt + lane)] = MCQ_EMPTY;
                 }
-                if (lane == 0) atomicAdd(&ctr->n_ovf, (u32)__builtin_popcountll(__ballot(valid)));
+                const u32 nv = (u32)__builtin_popcountll(__ballot(valid)), nf = (u32)__builtin_popcountll(__ballot(valid && front));      // (by every lane)
+                if (lane == 0) { atomicAdd(&ctr->n_ovf, nv); if (nf) atomicAdd(&ctr->n_geom, (unsigned long long)nf); }
             }
             return;
         }
@@ -971,6 +973,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
             if (T > (u32)LCAP) ovf = true;
         }
         if (ovf) {
+            if (g.ovf && !g.wide) ++st_geom;
             // two queues in one array: 32-bit keys and either 513..1024 locations or 65..128 features from the back
             // (k_query_wave16: still one wave per query), everything else from the front (k_query_block)
             if (lane == 0) {
@@ -1078,6 +1081,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
         wave_sync();
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, b.nq);
+    if (lane == 0 && st_geom) atomicAdd(&ctr->n_geom, (unsigned long long)st_geom);
     if (lane == 0 && (st_feat | st_loc | st_hit)) {
         if (st_feat) atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);
@@ -1186,7 +1190,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         if (T == 0) { if (lane == 0) out.ncand[q] = 0; continue; }
         wave_sync();                                   // feat[] (aliasing hits) has been consumed
         const u32 numWindows = range_width(g.qlen, opt.insert_size_max, db.tgt_winstride, db.magic_tgt_stride);
-        if (T <= MCQ_DEDUP_MAX_T && (qe & MCQ_Q_UNPROBED)) st_short += 1;       // (direct mode: the first stage would have kept this one)
+        if (T <= MCQ_DEDUP_MAX_T && (qe & MCQ_Q_UNPROBED) && !g.wide) st_short += 1;       // (direct mode: the first stage would have kept this one)
         if (T <= MCQ_DEDUP_MAX_T) {                    // a short list (a wide read, or direct mode): the distinct-key tail of the first stage
             u32 D, k1 = MCQ_EMPTY, incl1 = 0, t1 = 0, tb1 = 0;
             if (T <= 128)      D = gather2_dedup_insert<2>(db, buf, hits, T, pos0, len0, off0, pos1, len1, off1, two, lane);
@@ -1634,28 +1638,15 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         __syncthreads();
         PHCLK(ph, 0);
         if constexpr (!SH) {
-        // (ASCII bases: the next window's two bases per lane are loaded before this window is sketched -- a wave sketches four or five
-        // windows of an 8 kb read one after the other, and every one of them waited for its own load)
-        auto span = [&](u32 w, u64& at, u32& wl) {
-            const bool m2 = w >= nw1;
-            u64 beg;
-            window_of(m2 ? n2 : n1, W, S, m2 ? w - nw1 : w, beg, wl);
-            at = (m2 ? o1 : o0) + beg;
-        };
-        u32 chars = 0;
-        if (!b.packed && wave < (u32)NW) { u64 at; u32 wl; span(wave, at, wl); chars = window_chars2(b.bases + at, wl, lane); }
+        // (Loading the next window's bases before this one is sketched -- a wave sketches four or five windows of an 8 kb read one after
+        // the other -- was measured in r04: +4 % kernel time, same box; removed.)
         for (u32 w = wave; w < (u32)NW; w += NW16) {
-            u64 at; u32 wl;
-            span(w, at, wl);
-            u32 m;
-            if (b.packed) m = wave_sketch_b(b, at, wl, db.k, db.s, lane, sk, sk + 64);
-            else {
-                const u32 cur = chars;
-                if (w + NW16 < (u32)NW) { u64 at2; u32 wl2; span(w + NW16, at2, wl2); chars = window_chars2(b.bases + at2, wl2, lane); }
-                u32 ww, am;
-                wave_words_of_chars(cur & 0xFFu, cur >> 8, lane, ww, am);
-                m = wave_sketch_words(ww, am, wl, db.k, db.s, lane, sk, sk + 64);
-            }
+            const bool m2 = w >= nw1;
+            const u64 n = m2 ? n2 : n1;
+            const u64 sb = m2 ? o1 : o0;
+            u64 beg; u32 wl;
+            window_of(n, W, S, m2 ? w - nw1 : w, beg, wl);
+            u32 m = wave_sketch_b(b, sb + beg, wl, db.k, db.s, lane, sk, sk + 64);
             u32 base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_w[18], m);
             base = bcast(base, 0);
@@ -1676,7 +1667,11 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         nhit = wave_incl_scan_dpp(nhit);
         if (lane == 63 && nhit) atomicAdd(&s_w[19], nhit);
         u32 T;
+#ifndef MCQ_NO_SCAN4                                    // tuning knob (A/B)
         if (F <= 4 * NT && NT >= 256) T = block_excl_scan4(fpos, F, tid);       // (uniform; the thread scans the lengths it wrote itself)
+#else
+        if (false) { }
+#endif
         else { __syncthreads(); T = block_excl_scan(fpos, F, tid, s_w); }
         PHCLK(ph, 2);
         if (tid == 0) {
@@ -1763,7 +1758,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     }
 #ifdef MCQ_PHASE_CLOCK
     __syncthreads();
-    if (tid < 22 && s_ph[tid]) atomicAdd(&ctr->pad_[tid], (unsigned long long)s_ph[tid]);
+    if (tid < 21 && s_ph[tid]) atomicAdd(&ctr->pad_[tid], (unsigned long long)s_ph[tid]);
 #endif
 }
 
@@ -2761,8 +2756,11 @@ struct LaunchTimer {
 // how the next batch on this workspace enters (CountersDev::direct_mode): after the last kernel of a batch.  In the direct mode every
 // query counts as queued; those the second stage found short (n_short) would not have been.  Enter at 3/4, leave at 1/2.
 __global__ void k_next_mode(CountersDev* ctr, u64 nq) {
-    const unsigned long long would = (unsigned long long)ctr->n_ovf - ctr->n_short;
-    ctr->direct_mode = ctr->direct_mode ? (would * 2 > nq ? 1u : 0u) : (would * 4 > nq * 3 ? 1u : 0u);
+    const unsigned long long would = (unsigned long long)ctr->n_ovf - ctr->n_short, geom = ctr->n_geom;
+    const u32 was = ctr->direct_mode;
+    const u32 b0 = (was & 1u) ? (would * 2 > nq ? 1u : 0u) : (would * 4 > nq * 3 ? 1u : 0u);
+    const u32 b1 = (was & 2u) ? (geom * 2 > nq ? 2u : 0u) : (geom * 4 > nq * 3 ? 2u : 0u);
+    ctr->direct_mode = b0 | b1;
 }
 
 // sh != nullptr: the feature-sharded home side (SH instantiations; dbd = the handle's DbDev with `locs` pointing at the
@@ -3012,7 +3010,7 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
 // synchronised by mcq_ws_sync (zeros in a normal build)
 extern "C" int mcq_debug_phase_clocks(mcq_ws* ws, uint64_t* out22) {
     if (!ws || !out22) return fail(MCQ_E_ARG, "null argument");
-    for (int i = 0; i < 22; ++i) out22[i] = ws->ctr_host->pad_[i];
+    for (int i = 0; i < 22; ++i) out22[i] = i < 21 ? ws->ctr_host->pad_[i] : 0;
     return MCQ_OK;
 }
 
