@@ -402,18 +402,19 @@ def main():
             rf["whole_step"] = {"achieved": algo / (elapsed / a.steps) / 1e9, "frac": algo / (elapsed / a.steps) / 1e9 / HBM_PEAK_GBS,
                                 "note": "algorithmic bytes / ms_per_step (exchange included): the conservative figure for the sharded path"}
         # HBM traffic per launch from the committed PMC passes of this workload (bench.py cannot run rocprofv3 itself)
-        if kind == "fused" and not a.small and n_species == 50:
+        tname = a.workload if n_species == 50 and not a.refseq_scale else ({"c2": "refseq", "paired": "refseqp"}.get(a.workload) if a.refseq_scale and n_species == 2600 else None)
+        if kind == "fused" and not a.small and tname:
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.workload)))
+                tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % tname)))
                 # counters belong to the kernels they were collected from: another state of csrc/ -> no figure, said so
                 fresh = tj.get("csrc_digest") == pkg.source_digest()
                 rf["traffic_fresh"] = fresh
                 if not fresh:
                     rf["traffic_source"] = "STALE, not quoted: profiles/pmc_traffic_%s.json was collected from csrc digest %s, this run is %s (scripts/profile.sh + scripts/pmc_traffic.py renew it)" % (
-                        a.workload, tj.get("csrc_digest"), pkg.source_digest())
+                        tname, tj.get("csrc_digest"), pkg.source_digest())
                     raise LookupError("stale")
                 rf["traffic"] = tj["hbm_bytes_per_launch"] * B / tj["reads_per_launch"]
-                rf["traffic_source"] = "profiles/pmc_traffic_%s.json: %s" % (a.workload, tj.get("source", ""))
+                rf["traffic_source"] = "profiles/pmc_traffic_%s.json: %s" % (tname, tj.get("source", ""))
                 if tj.get("valu_insts_per_launch"):
                     # second roofline: wave64 VALU instructions (SQ_INSTS_VALU of the committed PMC pass) over the live kernel
                     # time, against 1 instruction / 4 cycles / SIMD x 1024 SIMDs x 2.4 GHz

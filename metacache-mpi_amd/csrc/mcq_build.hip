@@ -501,7 +501,8 @@ extern "C" int mcq_build_parts(const mcq_build_desc* d, mcq_parts** out) {
     if (const char* e = getenv("MCQ_BUILD_PARTS")) n_parts = (u32)std::max<u64>(1, strtoull(e, nullptr, 10));
     if ((u64)n_parts * n_shards > (1u << 20)) return bfail(MCQ_E_UNSUPPORTED, "too many parts");
     const u32 n_ranges = n_parts * n_shards;
-    // a range's share of the slots: the hash spreads them evenly (3 % and 2^20 slack; an overflow is reported, not cut)
+    // a range's share of the slots to start with: the hash spreads distinct features evenly (3 % and 2^20 slack; a range that holds
+    // more -- repeats -- grows, see below)
     const u64 cap = (u64)((double)n_slots_mine / n_parts * 1.03) + (1ull << 20);
 
     u32 *feat = nullptr, *nfeat = nullptr, *flag = nullptr; u64 *pos = nullptr, *woff = nullptr;
@@ -511,7 +512,9 @@ extern "C" int mcq_build_parts(const mcq_build_desc* d, mcq_parts** out) {
     for (u32 p = 0; p < n_parts; ++p) {
         const u32 range = d->shard_id * n_parts + p;
         u64* key = nullptr; u32* val = nullptr;
-        BCHK(tmpbuf.get(&key, cap * 8)); BCHK(tmpbuf.get(&val, cap * 4));
+        u64 cap_p = cap;
+        if (const char* e = getenv("MCQ_BUILD_PART_CAP")) cap_p = std::max<u64>(1, strtoull(e, nullptr, 10));      // test hook: start small, grow
+        BCHK(tmpbuf.get(&key, cap_p * 8)); BCHK(tmpbuf.get(&val, cap_p * 4));
         u64 cursor = 0;
         for (size_t c = 0; c + 1 < cut.size(); ++c) {
             const u32 t0 = cut[c], t1 = cut[c + 1];
@@ -523,10 +526,22 @@ extern "C" int mcq_build_parts(const mcq_build_desc* d, mcq_parts** out) {
             hipLaunchKernelGGL(k_part_flags, grid_for(ns), dim3(TB), 0, 0, (const u32*)feat, ns, n_ranges, range, flag);
             u64 kept = 0;
             MCHK(excl_scan(flag, pos, ns, &kept));
+            if (cursor + kept > cap_p) {
+                // more than the even share + 3 %: real data is not uniform -- features that repeat millions of times (low-complexity
+                // minimisers, rRNA, IS copies) all land in ONE range before the 254-per-feature limit applies.  The pair arrays of
+                // this part grow (half again, at least what is needed) instead of failing (until r04: MCQ_E_CAPACITY and the advice
+                // to ask for more parts, which shrinks the cap as well)
+                const u64 ncap = std::max<u64>(cursor + kept, cap_p + cap_p / 2);
+                u64* key2 = nullptr; u32* val2 = nullptr;
+                BCHK(tmpbuf.get(&key2, ncap * 8)); BCHK(tmpbuf.get(&val2, ncap * 4));
+                if (cursor) { BCHK(hipMemcpyAsync(key2, key, cursor * 8, hipMemcpyDeviceToDevice, 0)); BCHK(hipMemcpyAsync(val2, val, cursor * 4, hipMemcpyDeviceToDevice, 0)); }
+                BCHK(hipStreamSynchronize(0));
+                tmpbuf.put(key); tmpbuf.put(val);
+                key = key2; val = val2; cap_p = ncap;
+            }
             hipLaunchKernelGGL(k_part_scatter, grid_for(ns), dim3(TB), 0, 0, (const u32*)feat, (const u32*)flag, (const u64*)pos, ns, s, w0,
-                               (const u64*)win_off, nt, P, cursor, cap, key, val);
+                               (const u64*)win_off, nt, P, cursor, cap_p, key, val);
             cursor += kept;
-            if (cursor > cap) return bfail(MCQ_E_CAPACITY, "a feature range holds more than its share of the features + 3 %: set MCQ_BUILD_PARTS");
         }
         BCHK(hipDeviceSynchronize());
         phase("  sketch + keep the part's features");

@@ -230,10 +230,12 @@ def _all_lists_of(engine, db, keys, win_off):
     return lens.cpu().numpy().astype(np.int64), out.cpu().numpy().astype(np.uint64)
 
 
-@pytest.mark.parametrize("P,flags", [(1, 0), (2, 0), (3, 0x1000)])
-def test_build_in_parts_equals_the_one_piece_build(P, flags, monkeypatch):
+@pytest.mark.parametrize("P,flags,cap", [(1, 0, 0), (2, 0, 0), (3, 0x1000, 0), (2, 0x1000, 5000)])
+def test_build_in_parts_equals_the_one_piece_build(P, flags, cap, monkeypatch):
     """the same sequences through mcq_build_table (the build that is pinned to the reference's shard files above) and through
-    mcq_build_parts with 3 feature ranges and sketch chunks of a few targets: every key, every list, and any shard of it"""
+    mcq_build_parts with 3 feature ranges and sketch chunks of a few targets: every key, every list, and any shard of it.
+    cap > 0: the pair arrays of a part start that small and must GROW (a range that holds more than its even share of the features:
+    repeats; until r04 that was MCQ_E_CAPACITY)"""
     engine = importlib.import_module("metacache-mpi_amd.engine")
     synth = importlib.import_module("metacache-mpi_amd.synth")
     dev = torch.device("cuda", 0)
@@ -249,6 +251,8 @@ def test_build_in_parts_equals_the_one_piece_build(P, flags, monkeypatch):
     tb.close()
     monkeypatch.setenv("MCQ_BUILD_PARTS", "3")
     monkeypatch.setenv("MCQ_BUILD_CHUNK_WINDOWS", "9000")
+    if cap:
+        monkeypatch.setenv("MCQ_BUILD_PART_CAP", str(cap))
     parts = engine.Parts(gb.data_ptr(), goff.data_ptr(), nt, emulate_ranks=P, flags=flags)
     assert parts.n_parts == 3 and parts.n_keys == len(keys) and parts.n_locs == len(locs) and parts.n_windows == int(win_off[-1])
     sp32 = species.to(torch.int32).contiguous()

@@ -26,6 +26,49 @@ def _compare(cands, ncand, oc, on, what):
     assert len(bad) == 0, (what, "cands differ at", bad[:5], cands[bad[0]], oc[bad[0]])
 
 
+def _spot_check_against_a_one_piece_build(eng, db, spot, n_targets, tw):
+    """Every feature of the 40 picked targets' own one-piece table: the locations the big handle returns for it, filtered to those
+    targets, must be exactly the one-piece build's list (target ids mapped back) -- part boundaries, the long-list area beyond 2^32
+    B, the global-window offsets of targets all over the table.  A feature may be missing from the big table only because
+    -remove-overpopulated-features took it out (more than 254 locations in the whole database): rare, and then missing whole."""
+    from oracle import subtable                                     # (only for its decoding of the handle's words)
+    pick, keys, off, locs = spot
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    step = max(1, len(keys) // 200_000)
+    sel = np.arange(0, len(keys), step)
+    k32 = torch.from_numpy(keys[sel].view(np.int32).copy()).to(dev)
+    n = k32.numel()
+    lens = torch.zeros(n, dtype=torch.int32, device=dev)
+    db.lookup_count(k32.data_ptr(), n, lens.data_ptr(), None, st)
+    ooff = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens.to(torch.int64), 0, out=ooff[1:])
+    native = torch.zeros(int(ooff[-1].item()) + 1, dtype=torch.int32, device=dev)
+    db.lookup_gather(k32.data_ptr(), n, ooff.data_ptr(), native.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    go = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(tw.to(torch.int64), 0)])
+    w = native[:-1].to(torch.int64) & 0xFFFFFFFF
+    t = torch.searchsorted(go, w, right=True) - 1
+    big = ((t << 32) | (w - go[t])).cpu().numpy().view(np.uint64)
+    lens_h = lens.cpu().numpy().astype(np.int64)
+    o = np.zeros(n + 1, np.int64); o[1:] = np.cumsum(lens_h)
+    back = {p: i for i, p in enumerate(pick)}
+    is_pick = np.zeros(n_targets, bool); is_pick[pick] = True
+    remap = np.zeros(n_targets, np.uint64); remap[pick] = np.arange(len(pick), dtype=np.uint64)
+    missing = 0
+    for j, ki in enumerate(sel):
+        want = locs[int(off[ki]):int(off[ki + 1])]
+        got = big[o[j]:o[j + 1]]
+        if len(got) == 0:
+            missing += 1
+            continue
+        gt = (got >> np.uint64(32)).astype(np.int64)
+        m = is_pick[gt]
+        mine = (remap[gt[m]] << np.uint64(32)) | (got[m] & np.uint64(0xFFFFFFFF))
+        assert np.array_equal(np.sort(mine), want), (int(keys[ki]), mine[:8], want[:8])
+    assert missing < 0.01 * len(sel), (missing, len(sel))
+
+
 def test_config2_refseq_scale_table_on_one_gpu():
     """configs[2] shape on ONE GPU: 2 600 species x 10 strains of 2-6 Mbp (>= 100 Gbp), every genome two
     sequences (>= 2^15 targets), one 16 Mbp chromosome (> 2^17 windows), built with -remove-overpopulated-features in
@@ -47,6 +90,21 @@ def test_config2_refseq_scale_table_on_one_gpu():
     n = 1 << 18
     reads, roff, _ = synth.sample_reads(gb, goff, n, 150, 0.005, 0.001, seed=2000)
     pairs, poff, _ = synth.sample_pairs(gb, goff, n // 2, 150, 300, 500, 0.005, 0.001, seed=2001)
+    # an INDEPENDENT derivation of some of the table's lists (the oracle's sub-tables are read back through the handle itself): 40
+    # targets from all over the database -- among them the two halves of a part-boundary genome and the 16 Mbp chromosome --
+    # sketched and merged by the one-piece build (mcq_build_table: pinned to the reference's shard files, tests/test_gpu_dbbuild.py)
+    pick = sorted(set([0, 1, 2, 3, n_targets - 1, n_targets - 2] + [int(x) for x in torch.randint(0, n_targets, (34,), generator=torch.Generator().manual_seed(5)).tolist()]))
+    sub_off = [0]
+    pieces = []
+    for t in pick:
+        a, b_ = int(goff[t].item()), int(goff[t + 1].item())
+        pieces.append(gb[a:b_]); sub_off.append(sub_off[-1] + (b_ - a))
+    sub_bases = torch.cat(pieces).contiguous()
+    sub_goff = torch.tensor(sub_off, dtype=torch.int64, device=dev)
+    tb = eng.Table(sub_bases.data_ptr(), sub_goff.data_ptr(), len(pick), emulate_ranks=1)
+    spot = (pick,) + tb.to_host()[:3]
+    tb.close()
+    del sub_bases, pieces
     parts = eng.Parts(gb.data_ptr(), goff.data_ptr(), n_targets, emulate_ranks=2, flags=eng.MCQ_BUILD_REMOVE_OVERPOPULATED)
     assert parts.n_parts > 1 and parts.n_locs > 1e10
     del gb
@@ -56,6 +114,7 @@ def test_config2_refseq_scale_table_on_one_gpu():
     parts.close()
     lay = db.layout()
     assert lay["loc_format"] == eng.MCQ_LOC_GLOBAL_WINDOW and lay["loc_bytes"] == 4 and lay["bucket_bytes"] == 16, lay
+    _spot_check_against_a_one_piece_build(eng, db, spot, n_targets, tw)
     sp = species.cpu().numpy().astype(np.uint32)
     st = torch.cuda.current_stream(dev).cuda_stream
     for (rd, ro_t, n_seqs, paired) in ((reads, roff, n, False), (pairs, poff, n, True)):
