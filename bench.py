@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--long-genome-mbp", type=float, default=None,
                     help="add one genome of this many Mbp (>= 14.9 Mbp = 2^17 windows: with >= 2^15 targets the (target, window) "
                          "fields no longer fit 32 bits, as on RefSeq)")
+    ap.add_argument("--shard-serial", action="store_true",
+                    help="diagnosis: the sharded leg without overlap -- no `next` batch, a sync after every step -- so that stage_ms_per_step are the stages' times ALONE (results invalid as a throughput)")
     ap.add_argument("--no-refseq-block", action="store_true",
                     help="default N = 1 line: skip the `refseq_scale` side block (the RefSeq-scale table built and timed in the same run, ~80 s)")
     a = ap.parse_args()
@@ -321,9 +323,11 @@ def main():
 
     def step_sharded(i):
         # the next step's batch is announced so that its sketching runs on the second stream under this step's exchange
-        nxt = (batches[(i + 1) % nb].data_ptr(), offsets[(i + 1) % nb].data_ptr(), B) if i + 1 < a.warmup + a.steps else None
+        nxt = (batches[(i + 1) % nb].data_ptr(), offsets[(i + 1) % nb].data_ptr(), B) if (i + 1 < a.warmup + a.steps and not a.shard_serial) else None
         sharded.query(batches[i % nb].data_ptr(), offsets[i % nb].data_ptr(), B, paired, cands_s.data_ptr(), ncand_s.data_ptr(),
                       max_cand=a.max_cand, emulate_ranks=a.emulate_ranks, flags=a.query_flags, stream=stream, next_batch=nxt)
+        if a.shard_serial:
+            sharded.sync(stream)
 
     packed_batches = None
     if a.packed_input and with_fused:
@@ -583,6 +587,8 @@ def main():
         out["DIAGNOSTIC_phase_clocks_of_the_workgroup_kernel"] = phase_clocks
     if a.stop_stage:
         out["INVALID_profiling_stop_stage"] = a.stop_stage
+    if a.shard_serial:
+        out["INVALID_diagnostic_run_without_overlap"] = True
     if world == 1 and mode == "single" and a.workload == "c2" and not a.stop_stage and not a.small and not a.no_pcie_leg:
         # the boundary may hand over HOST buffers (what the reference's readers fill): mcq_query_pipelined keeps two batches
         # in flight -- copy in, compute, copy out on three streams -- from pinned memory; once with ASCII bases (PCIe Gen5 x16
