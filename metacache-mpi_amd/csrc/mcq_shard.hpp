@@ -110,36 +110,33 @@ __global__ void k_shard_fold_err(u32* err, const u32* s1_err) { if (*s1_err) ato
 // four probes in flight per thread, inclusive scan of the list lengths over the tile (feature order), one global
 // atomic per tile for its room in p's location block, then every wave copies the lists of its 64-feature groups.
 // R block of p: [0] = locations served to p so far (the cursor), [1] = features of p seen, then capT tile starts,
-// then capF list ends.  (One wave per 256-feature tile -- no barriers, no LDS -- measured 5 % slower per batch.)
+// then capF list ends.  (One wave per 256-feature tile -- no barriers, no LDS -- measured 5 % slower per batch.  r04: FOUR tiles per
+// 1024-thread workgroup with one cursor atomic for all four -- on the theory that ~33 000 atomics on one address were what this
+// stage waits for -- 1.51 against 1.35 ms alone and 3.36 against 2.74 ms per step overlapped: a 1024-thread workgroup needs 16 free
+// wave slots on ONE CU at once and does not start beside the resident reduce grid.  Removed.)
 template <class KeyT>
-__global__ __launch_bounds__(1024) void k_shard_lookup(DbDev db, u32 n_ranks, const u32* recvF, u32 capF, u32 capFx, u32 capT,
-                                                       u32* sendR, KeyT* sendL, u64 capL, u32* err, int count_only) {
-    // FOUR tiles per workgroup, one per 256-thread quarter, and ONE atomic on the requester's cursor for all four: with one
-    // workgroup (and one atomic) per tile the ~33 000 tiles of a 1 M-read batch queued on a single address, which -- not the
-    // probes, not the copy -- was most of the 1.35 ms this stage took alone on the configs[1] table (r04)
-    __shared__ u32 s_wt[4][4][4];                               // [quarter][group k][wave of the quarter]
+__global__ __launch_bounds__(256) void k_shard_lookup(DbDev db, u32 n_ranks, const u32* recvF, u32 capF, u32 capFx, u32 capT,
+                                                      u32* sendR, KeyT* sendL, u64 capL, u32* err, int count_only) {
+    __shared__ u32 s_wt[4][4];
     __shared__ u32 s_tbase;
     const u32 tid = threadIdx.x, lane = tid & 63;
-    const u32 qt = __builtin_amdgcn_readfirstlane(tid >> 8), tq = tid & 255u;
-    const u32 wave = __builtin_amdgcn_readfirstlane(tq >> 6);    // wave inside the quarter
-    const u32 capT4 = (capT + 3) / 4;
-    const u32 p = blockIdx.x / capT4, t = (blockIdx.x - p * capT4) * 4 + qt;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 p = blockIdx.x / capT, t = blockIdx.x - p * capT;
     const u64 fblk = (u64)capF + MCQ_SHARD_HDR, rblk = (u64)MCQ_SHARD_HDR + capT + capF;
     const u32* F = recvF + (u64)p * fblk;
     u32 cnt = F[0];
-    if (cnt > capFx) { cnt = capFx; if (blockIdx.x == p * capT4 && tid == 0) atomicOr(err, 2u); }      // more than a block carries: the sender's error
+    if (cnt > capFx) { cnt = capFx; if (t == 0 && tid == 0) atomicOr(err, 2u); }      // more than a block carries: the sender's error
     u32* R = sendR + (u64)p * rblk;
-    if (blockIdx.x == p * capT4 && tid == 0) R[1] = cnt;
-    if ((u64)(blockIdx.x - p * capT4) * 4 * MCQ_SHARD_TILE >= cnt) return;            // (the whole workgroup: uniform)
-    const bool live = t < capT && (u64)t * MCQ_SHARD_TILE < cnt;                     // this quarter's tile holds features
+    if (t == 0 && tid == 0) R[1] = cnt;
+    if (t * MCQ_SHARD_TILE >= cnt) return;
     const KeyT* __restrict__ locs = static_cast<const KeyT*>(db.locs);
     u64 off[4]; u32 len[4], incl[4];
     {   // the first slot of all four probes in one round trip; a probe that has to walk on (load 0.25: one in eight) goes alone
         u32 f[4], idx[4]; uint4 sl[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const u32 i = t * MCQ_SHARD_TILE + k * 256 + tq;
-            f[k] = (live && i < cnt) ? F[MCQ_SHARD_HDR + i] : MCQ_EMPTY;
+            const u32 i = t * MCQ_SHARD_TILE + k * 256 + tid;
+            f[k] = i < cnt ? F[MCQ_SHARD_HDR + i] : MCQ_EMPTY;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -157,36 +154,30 @@ __global__ __launch_bounds__(1024) void k_shard_lookup(DbDev db, u32 n_ranks, co
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         incl[k] = wave_incl_scan_dpp(len[k]);
-        if (lane == 63) s_wt[qt][k][wave] = incl[k];
+        if (lane == 63) s_wt[k][wave] = incl[k];
     }
     __syncthreads();
-    u32 before[4], total = 0, qbase = 0, all = 0;              // inside the quarter's tile / the quarters before it / all four
+    u32 before[4], total = 0;
 #pragma unroll
-    for (int q2 = 0; q2 < 4; ++q2) {
-        u32 tq2 = 0;
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { if ((u32)q2 == qt && (u32)w == wave) before[k] = tq2; tq2 += s_wt[q2][k][w]; }
-        if ((u32)q2 == qt) { total = tq2; qbase = all; }
-        all += tq2;
-    }
+        for (int w = 0; w < 4; ++w) { if ((u32)w == wave) before[k] = total; total += s_wt[k][w]; }
     if (tid == 0) {
-        const u32 tb = all ? atomicAdd(&R[0], all) : 0u;
+        const u32 tb = total ? atomicAdd(&R[0], total) : 0u;
         s_tbase = tb;
-        if (!count_only && (u64)tb + all > capL) atomicOr(err, 4u);               // p's location block is full
+        R[MCQ_SHARD_HDR + t] = tb;
+        if (!count_only && (u64)tb + total > capL) atomicOr(err, 4u);             // p's location block is full
     }
     if (count_only) return;                                   // (sizing pass of the exact mode: only the cursors are wanted)
     __syncthreads();
-    const u32 tbase = s_tbase + qbase;
-    if (live && tq == 0) R[MCQ_SHARD_HDR + t] = tbase;
+    const u32 tbase = s_tbase;
     const bool fits = (u64)tbase + total <= capL;
     KeyT* L = sendL + (u64)p * capL + tbase;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const u32 i = t * MCQ_SHARD_TILE + k * 256 + tq;
-        if (live && i < cnt) R[MCQ_SHARD_HDR + capT + i] = before[k] + incl[k];
-        if (!fits || !live) continue;
+        const u32 i = t * MCQ_SHARD_TILE + k * 256 + tid;
+        if (i < cnt) R[MCQ_SHARD_HDR + capT + i] = before[k] + incl[k];
+        if (!fits) continue;
         // the 64 lists of this wave's group k, copied cooperatively (as k_lookup_gather)
         const u32 pos = incl[k] - len[k];
         const u32 Tg = bcast(incl[k], 63);
@@ -591,10 +582,10 @@ static int shard_owner_round(mcq_shard* c, int k, hipStream_t st, bool exact) {
     { rc = shard_ensure_recv(c); if (rc) return rc; }
     auto lookup = [&](int count_only) {
         hipLaunchKernelGGL(k_shard_zero_headers, dim3(1), dim3(64), 0, st, b.sendR, rblk_words(c), n);
-        const dim3 grid(n * ((c->capT + 3) / 4));
-        if (c->db->d.compact) hipLaunchKernelGGL(k_shard_lookup<u32>, grid, dim3(1024), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
+        const dim3 grid(n * c->capT);
+        if (c->db->d.compact) hipLaunchKernelGGL(k_shard_lookup<u32>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
                                                  b.sendR, (u32*)b.sendL, c->capL, err, count_only);
-        else                  hipLaunchKernelGGL(k_shard_lookup<u64>, grid, dim3(1024), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
+        else                  hipLaunchKernelGGL(k_shard_lookup<u64>, grid, dim3(256), 0, st, c->db->d, n, (const u32*)recvF, c->capF, capFx, c->capT,
                                                  b.sendR, (u64*)b.sendL, c->capL, err, count_only);
     };
     lookup(exact && c->capL == 0);

@@ -1,22 +1,11 @@
 #!/bin/bash
-# end-of-round measurements on one GPU box (round 4): kernel traces + PMC passes per workload, bench lines per workload
+# part B: RefSeq-scale pairs profiled, then the bench lines (profiles/pmc_traffic_*.json of part A are in the tree by now)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for w in c2 paired long; do
-  bash scripts/profile.sh r04_$w --workload $w > gpurun_out/r04_${w}_profile.log 2>&1 || echo "profile $w failed"
-  cp profiles/r04_${w}_*.csv gpurun_out/ 2>/dev/null
-  echo "profiled $w"
-done
-bash scripts/profile.sh r04_refseq --refseq-scale > gpurun_out/r04_refseq_profile.log 2>&1 || echo "profile refseq failed"
 bash scripts/profile.sh r04_refseqp --refseq-scale --workload paired > gpurun_out/r04_refseqp_profile.log 2>&1 || echo "profile refseqp failed"
-cp profiles/r04_refseq*_*.csv gpurun_out/ 2>/dev/null
-echo "profiled refseq"
-python3 scripts/pmc_traffic.py r04_c2 c2 "k_query_wave<" 1048576 > /dev/null
-python3 scripts/pmc_traffic.py r04_paired paired "k_query_wave<" 1048576 > /dev/null
-python3 scripts/pmc_traffic.py r04_long long "k_query_block<" 16384 > /dev/null
-python3 scripts/pmc_traffic.py r04_refseq refseq ALL 1048576 > /dev/null
-python3 scripts/pmc_traffic.py r04_refseqp refseqp ALL 1048576 > /dev/null
-cp profiles/pmc_traffic_*.json gpurun_out/
+cp profiles/r04_refseqp_*.csv gpurun_out/ 2>/dev/null
+python3 scripts/pmc_traffic.py r04_refseqp refseqp ALL 1048576 > /dev/null; cp profiles/pmc_traffic_refseqp.json gpurun_out/
+echo "profiled refseqp"
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r04_bench_line_c2_driver_form.json 2> gpurun_out/r04_bench_c2d.err; echo "c2 (driver form) rc $?"
 python3 bench.py --workload paired --steps 24 > gpurun_out/r04_bench_line_paired.json 2> gpurun_out/r04_bench_paired.err; echo "paired rc $?"
 python3 bench.py --workload long --steps 24 > gpurun_out/r04_bench_line_long.json 2> gpurun_out/r04_bench_long.err; echo "long rc $?"
