@@ -71,10 +71,7 @@ def main():
     keys = dev_tensor(table.keys_ptr, nk, torch.int32)
     off = dev_tensor(table.list_off_ptr, nk + 1, torch.int64)
     locs = dev_tensor(table.locs_ptr, nl, torch.int64)
-    sp32 = species.to(torch.int32).contiguous()
-    db_direct = eng.Database(None, None, None, None, device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr,
-                                                                      tgt2tax=sp32.data_ptr(), n_keys=nk, n_locs=nl, n_targets=n_targets))
-    table.close()
+    table_handle = table                                    # (its buffers stay until the direct handle is made, after the files are written)
 
     # ---- the shard files, rank by rank (host memory: one rank's arrays)
     W, S = 128, 113
@@ -85,10 +82,15 @@ def main():
     t0 = time.time()
     total_bytes = 0
     for rk in range(P):
-        sel = ((locs >> 32) % P) == rk
-        l_r = locs[sel]
-        k_r = key_of[sel]
-        del sel
+        lp, kp = [], []
+        CH = 1 << 29                                        # (boolean-mask indexing of more than 2^31 elements is not supported)
+        for c0 in range(0, nl, CH):
+            lc = locs[c0:c0 + CH]
+            sel = ((lc >> 32) % P) == rk
+            lp.append(lc[sel]); kp.append(key_of[c0:c0 + CH][sel])
+            del sel, lc
+        l_r = torch.cat(lp); k_r = torch.cat(kp)
+        del lp, kp
         kk, cnt = torch.unique_consecutive(k_r, return_counts=True)
         del k_r
         keys_r = keys[kk.long()].cpu().numpy().view(np.uint32)
@@ -111,6 +113,12 @@ def main():
     torch.cuda.empty_cache()
     res["shard_bytes"] = int(total_bytes)
     res["shard_files_written_s"] = round(time.time() - t0, 1)
+    # the directly built handle, with the taxon keys of the files just written
+    rdb = host.RefDb(os.path.join(a.workdir, "db"), P, meta_only=True)
+    t2t = torch.from_numpy(rdb.tgt2tax(4).view(np.int32).copy()).to(dev)
+    db_direct = eng.Database(None, None, None, None, device_ptrs=dict(keys=table_handle.keys_ptr, list_off=table_handle.list_off_ptr, locs=table_handle.locs_ptr,
+                                                                      tgt2tax=t2t.data_ptr(), n_keys=nk, n_locs=nl, n_targets=n_targets))
+    table_handle.close()
 
     # ---- the reads as two FASTA files; the direct handle's answer for them
     npairs = a.pairs
@@ -151,7 +159,6 @@ def main():
         print(json.dumps(res, indent=1)); sys.exit(1)
 
     # ---- the same lines from the direct handle's candidates (taxon keys -> ids, classify by the host library)
-    rdb = host.RefDb(os.path.join(a.workdir, "db"), P, meta_only=True)
     hitdiff = float(np.float32(np.float32(80) * np.float32(0.01)))
     want = []
     for q in range(npairs):
