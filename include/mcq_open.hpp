@@ -20,6 +20,14 @@
 
 #define MCQ_STREAM_LOAD_DEFAULT_MIN_BYTES (1ull << 30)
 
+/* MCQ_BUILD_TRACE=1: resident set of the process at the steps of the streaming route, on stderr */
+inline void mcq_trace_rss(const char* what) {
+    if (!std::getenv("MCQ_BUILD_TRACE")) return;
+    long pages = 0, rss = 0;
+    if (FILE* f = std::fopen("/proc/self/statm", "r")) { if (std::fscanf(f, "%ld %ld", &pages, &rss) != 2) rss = 0; std::fclose(f); }
+    std::fprintf(stderr, "[mcq_open] %-34s rss %8.1f MB\n", what, rss * 4096.0 / 1048576.0);
+}
+
 /* threshold in bytes: MCQ_STREAM_LOAD_MIN_MB overrides the default of 1 GB (0 = always stream) */
 inline uint64_t mcq_stream_load_min_bytes() {
     if (const char* e = std::getenv("MCQ_STREAM_LOAD_MIN_MB")) return std::strtoull(e, nullptr, 10) << 20;
@@ -53,6 +61,7 @@ inline int mcq_make_db(mcq_refdb* rdb, bool streamed, const uint32_t* tgt2tax, u
         if (mcq_db_create(&d, out)) { err = mcq_last_error(); return -1; }
         return 0;
     }
+    mcq_trace_rss("heads read");
     std::vector<uint32_t> tw(info.n_targets);
     if (mcq_refdb_tgt_windows(rdb, tw.data())) { err = mcq_host_last_error(); return -1; }
     mcq_parts_builder_desc bd; std::memset(&bd, 0, sizeof(bd));
@@ -61,6 +70,7 @@ inline int mcq_make_db(mcq_refdb* rdb, bool streamed, const uint32_t* tgt2tax, u
     bd.n_shards = n_shards; bd.shard_id = shard_id; bd.device = device;
     mcq_parts_builder* pb = nullptr;
     if (mcq_parts_builder_create(&bd, &pb)) { err = mcq_build_last_error(); return -1; }
+    mcq_trace_rss("builder created (GPU runtime up)");
     const uint64_t chunk = 1u << 22;
     std::vector<uint32_t> cf(chunk), ct(chunk), cw(chunk);
     for (uint32_t r = 0; r < info.n_ranks; ++r) {
@@ -73,12 +83,15 @@ inline int mcq_make_db(mcq_refdb* rdb, bool streamed, const uint32_t* tgt2tax, u
             if (mcq_parts_builder_add(pb, cf.data(), ct.data(), cw.data(), n, 0)) { err = mcq_build_last_error(); mcq_shard_stream_close(st); mcq_parts_builder_free(pb); return -1; }
         }
         mcq_shard_stream_close(st);
+        mcq_trace_rss("a shard file streamed");
     }
     mcq_parts* parts = nullptr;
     if (mcq_parts_builder_finish(pb, &parts)) { err = mcq_build_last_error(); mcq_parts_builder_free(pb); return -1; }
+    mcq_trace_rss("ranges sorted: parts made");
     const int rc = mcq_db_from_parts(parts, tgt2tax, n_shards, shard_id, 0, out);
     mcq_parts_free(parts);
     if (rc) { err = mcq_build_last_error(); return -1; }
+    mcq_trace_rss("table made");
     return 0;
 }
 #endif

@@ -153,7 +153,7 @@ def main():
     res["cli_streamed_wall_s"] = round(wall, 1)
     res["cli_streamed_max_rss_mb"] = round(ruc.ru_maxrss / 1024.0, 1)          # (KB on Linux; the largest child so far = this one)
     res["cli_streamed_gb_per_s"] = round(total_bytes / 1e9 / wall, 2)
-    res["cli_stderr_tail"] = err.decode(errors="replace")[-1200:]
+    res["cli_rss_trace"] = [ln for ln in err.decode(errors="replace").split("\n") if ln.startswith("[mcq_open]")]
     if p.returncode != 0:
         res["error"] = "mcq_query_cli failed"
         print(json.dumps(res, indent=1)); sys.exit(1)
