@@ -5,14 +5,18 @@
  * Replaces sketch_database::read (src/sketch_database.h:858-952) + hash_multimap::deserialize (src/hash_multimap.h:923-964):
  *   small databases: mcq_refdb_open unions the P shard tables on the host (16 B per location) -> mcq_db_create;
  *   from `stream_min_bytes` of shard files on: mcq_refdb_open_meta reads only the heads; the key records are streamed to the GPU in
- *   chunks of 4 M locations (48 MB of host memory), the P ranks merged there per feature-hash range (mcq_parts_builder_*), the
- *   handle made from the parts (32-bit global-window words) -- host memory stays at one chunk whatever the database's size.  */
+ *   chunks of 4 M locations (48 MB of host memory each; up to 8 files are parsed at a time by as many host threads), the P ranks
+ *   merged there per feature-hash range (mcq_parts_builder_*), the handle made from the parts (32-bit global-window words) -- host
+ *   memory stays at a few chunks whatever the database's size.                                                              */
 #ifndef MCQ_OPEN_HPP
 #define MCQ_OPEN_HPP
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mcq.h"
@@ -71,20 +75,39 @@ inline int mcq_make_db(mcq_refdb* rdb, bool streamed, const uint32_t* tgt2tax, u
     mcq_parts_builder* pb = nullptr;
     if (mcq_parts_builder_create(&bd, &pb)) { err = mcq_build_last_error(); return -1; }
     mcq_trace_rss("builder created (GPU runtime up)");
+    // the files are parsed by up to 8 host threads (one open stream and one 48 MB chunk each: record parsing is ~1 GB/s per thread),
+    // which take turns handing their chunks to the builder (MCQ_STREAM_LOAD_THREADS overrides; 1 = the calling thread alone)
     const uint64_t chunk = 1u << 22;
-    std::vector<uint32_t> cf(chunk), ct(chunk), cw(chunk);
-    for (uint32_t r = 0; r < info.n_ranks; ++r) {
-        mcq_shard_stream* st = nullptr;
-        if (mcq_shard_stream_open(rdb, r, &st)) { err = mcq_host_last_error(); mcq_parts_builder_free(pb); return -1; }
-        for (;;) {
-            uint64_t n = 0;
-            if (mcq_shard_stream_next(st, cf.data(), ct.data(), cw.data(), chunk, &n)) { err = mcq_host_last_error(); mcq_shard_stream_close(st); mcq_parts_builder_free(pb); return -1; }
-            if (!n) break;
-            if (mcq_parts_builder_add(pb, cf.data(), ct.data(), cw.data(), n, 0)) { err = mcq_build_last_error(); mcq_shard_stream_close(st); mcq_parts_builder_free(pb); return -1; }
+    unsigned n_thr = std::thread::hardware_concurrency();
+    if (const char* e = std::getenv("MCQ_STREAM_LOAD_THREADS")) n_thr = (unsigned)std::strtoul(e, nullptr, 10);
+    n_thr = std::max(1u, std::min(std::min(n_thr, 8u), info.n_ranks));
+    std::mutex mu; std::string first_err;
+    auto work = [&](unsigned tix) {
+        std::vector<uint32_t> cf(chunk), ct(chunk), cw(chunk);
+        for (uint32_t r = tix; r < info.n_ranks; r += n_thr) {
+            mcq_shard_stream* st = nullptr;
+            if (mcq_shard_stream_open(rdb, r, &st)) { std::lock_guard<std::mutex> g(mu); if (first_err.empty()) first_err = mcq_host_last_error(); return; }
+            for (;;) {
+                uint64_t n = 0;
+                if (mcq_shard_stream_next(st, cf.data(), ct.data(), cw.data(), chunk, &n)) {
+                    std::lock_guard<std::mutex> g(mu); if (first_err.empty()) first_err = mcq_host_last_error(); n = 0; mcq_shard_stream_close(st); return;
+                }
+                if (!n) break;
+                std::lock_guard<std::mutex> g(mu);
+                if (!first_err.empty()) { mcq_shard_stream_close(st); return; }           // (another thread failed: stop)
+                if (mcq_parts_builder_add(pb, cf.data(), ct.data(), cw.data(), n, 0)) { first_err = mcq_build_last_error(); mcq_shard_stream_close(st); return; }
+            }
+            mcq_shard_stream_close(st);
+            mcq_trace_rss("a shard file streamed");
         }
-        mcq_shard_stream_close(st);
-        mcq_trace_rss("a shard file streamed");
+    };
+    if (n_thr == 1) work(0);
+    else {
+        std::vector<std::thread> thr;
+        for (unsigned t = 0; t < n_thr; ++t) thr.emplace_back(work, t);
+        for (auto& t : thr) t.join();
     }
+    if (!first_err.empty()) { err = first_err; mcq_parts_builder_free(pb); return -1; }
     mcq_parts* parts = nullptr;
     if (mcq_parts_builder_finish(pb, &parts)) { err = mcq_build_last_error(); mcq_parts_builder_free(pb); return -1; }
     mcq_trace_rss("ranges sorted: parts made");

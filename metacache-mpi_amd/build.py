@@ -64,10 +64,12 @@ def build_host(force=False, verbose=False):
         subprocess.check_call(cmd)
     cli_src = os.path.join(_HERE, "csrc", "host", "mcq_query_cli.cpp")
     cli = cli_path()
+    open_hpp = os.path.join(os.path.dirname(_HERE), "include", "mcq_open.hpp")
     if force or not os.path.exists(cli) or os.path.getmtime(cli) < max(os.path.getmtime(cli_src), os.path.getmtime(out), os.path.getmtime(lib_path()),
-                                                                         os.path.getmtime(os.path.join(_HERE, "csrc", "host", "mcq_cli_common.hpp"))):
+                                                                         os.path.getmtime(os.path.join(_HERE, "csrc", "host", "mcq_cli_common.hpp")),
+                                                                         os.path.getmtime(open_hpp)):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc, "-std=c++14", "-O2", cli_src, "-o", cli, "-L" + _HERE, "-lmcq_hip", "-lmcq_host", "-Wl,-rpath,$ORIGIN"]
+        cmd = [hipcc, "-std=c++14", "-O2", "-pthread", cli_src, "-o", cli, "-L" + _HERE, "-lmcq_hip", "-lmcq_host", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
@@ -83,11 +85,11 @@ def build_host(force=False, verbose=False):
             if not os.path.lexists(dst) and os.path.exists(os.path.join(_MPI_ROOT, "lib", l)):
                 os.symlink(os.path.join(_MPI_ROOT, "lib", l), dst)
         mpi_cli = mpi_cli_path()
-        newest = max(os.path.getmtime(f) for f in (mpi_src, common, out, lib_path()))
+        newest = max(os.path.getmtime(f) for f in (mpi_src, common, out, lib_path(), open_hpp))
         if force or not os.path.exists(mpi_cli) or os.path.getmtime(mpi_cli) < newest:
             rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
             # plain g++ (host code only; hipcc would take libmpi.so.12 for a source file)
-            cmd = ["g++", "-std=c++14", "-O2", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(_MPI_ROOT, "include"),
+            cmd = ["g++", "-std=c++14", "-O2", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(_MPI_ROOT, "include"),
                    mpi_src, "-o", mpi_cli, "-L" + _HERE, "-lmcq_hip", "-lmcq_host", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", mpi_so,
                    "-Wl,-rpath-link," + os.path.join(_MPI_ROOT, "lib"), "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,$ORIGIN/_mpilib",
                    "-Wl,-rpath," + os.path.join(rocm, "lib")]
