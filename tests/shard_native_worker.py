@@ -58,6 +58,31 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if len(sys.argv) > 4 and sys.argv[4] == "mismatch":
+        # shards whose location words mean different things (rank 0: global-window words, the others: bit fields): the ranks compare
+        # a signature of the format before the first word travels and every one of them fails with MCQ_E_ARG -- nobody answers wrongly
+        db.close()
+        table = eng.Table(gb.data_ptr(), goff.data_ptr(), goff.numel() - 1, emulate_ranks=P, device=dev.index)
+        db = eng.Database(None, None, None, None, n_shards=world, shard_id=rank, device=dev.index,
+                          flags=(eng.MCQ_DB_LOCS_GW | eng.MCQ_DB_SLOTS_16) if rank == 0 else 0,
+                          device_ptrs=dict(keys=table.keys_ptr, list_off=table.list_off_ptr, locs=table.locs_ptr, tgt2tax=sp32.data_ptr(),
+                                           n_keys=table.n_keys, n_locs=table.n_locs, n_targets=sp32.numel()))
+        table.close()
+        r, ro, _ = synth.sample_reads(gb, goff, 2000, 150, 0.01, 0.002, seed=5)
+        sh = eng.Shard(db, world, rank, max_queries=2000, max_bases=r.numel(), max_seqs=2000)
+        sh.set_exchange(make_gloo_exchange())
+        cands = torch.zeros((2000, M, 4), dtype=torch.int32, device=dev); ncand = torch.zeros(2000, dtype=torch.int32, device=dev)
+        code, text = 0, ""
+        try:
+            sh.query(r.data_ptr(), ro.data_ptr(), 2000, False, cands.data_ptr(), ncand.data_ptr(), max_cand=M, emulate_ranks=P,
+                     stream=torch.cuda.current_stream(dev).cuda_stream)
+        except eng.McqError as e:
+            code, text = e.code, str(e)
+        np.savez(outp + ".%d.npz" % rank, code=np.array([code]), told=np.array(["location words" in text]))
+        dist.barrier()
+        sh.close()
+        dist.destroy_process_group()
+        return
     b0, b1 = batch(500 + 10 * rank), batch(900 + 10 * rank)
     n_seqs = b0[2]
     nq = n_seqs // 2 if paired else n_seqs

@@ -195,6 +195,26 @@ def test_two_ranks_on_the_bench_table_pairs_and_long_reads():
             assert (z["locs"] > 0).all()
 
 
+def test_shards_with_different_location_words_are_refused():
+    """two ranks whose handles store their locations in different forms (global-window words on rank 0, bit
+    fields on rank 1) -- the home side would decode what it receives with its own tables.  The first (exact) batch compares a
+    signature of the format across the ranks: MCQ_E_ARG on every rank, before any location word has travelled."""
+    with tempfile.TemporaryDirectory() as d:
+        outp = os.path.join(d, "res")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", "29979",
+               os.path.join(ROOT, "tests", "shard_native_worker.py"), outp, "0", "0", "mismatch"]
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:]
+        eng = importlib.import_module("metacache-mpi_amd.engine")
+        files = sorted(glob.glob(outp + ".*.npz"))
+        assert len(files) == 2
+        for f in files:
+            z = np.load(f)
+            assert int(z["code"][0]) == eng.MCQ_E_ARG and bool(z["told"][0]), (f, z["code"])
+
+
 def test_rccl_over_two_gpus_when_the_box_has_them():
     """mcq_shard_* over REAL RCCL between two GPUs (ncclSend / ncclRecv groups over xGMI): skipped on a one-GPU box, so that
     the driver's multi-GPU node runs it.  One rank per GPU, each its own reads, padded and exact mode, per-rank oracle check."""
