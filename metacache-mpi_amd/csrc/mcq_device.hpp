@@ -25,6 +25,10 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 #define MCQ_EMPTY 0xFFFFFFFFu
+#ifndef MCQ_BLOCK_LONG_FIRST
+#define MCQ_BLOCK_LONG_FIRST 16384u     // tuning knob: queries this long and longer are the workgroup kernels' first pass; 0 = one pass (measured on ONT-like reads, mean 8 kb:
+                                       // one pass 2.04, 8192: 1.92, 16384: 1.80 ms per 16 384 reads)
+#endif
 #define MCQ_Q_UNPROBED 0x80000000u     // back-queue entry of the direct mode: the second wave stage sketches and probes it itself (queries are < 2^31)
 #define MCQ_MAX_FOLD 64
 #define MCQ_BIGLIST_MAX 1024u        // 64 virtual ranks x 16 candidates
@@ -168,7 +172,10 @@ struct CountersDev {         // one block of u64/u32 words, zeroed per call
     // counters above are hammered by atomics, and a load from their line queues behind them.)
     unsigned long long n_short;       // direct mode: queued queries whose list the first wave stage would have kept (<= 512 locations)
     unsigned long long n_geom;        // queries with more than 128 features: the workgroup kernels' by their geometry alone
-    unsigned long long pad_[21];      // (diagnostic builds, -DMCQ_PHASE_CLOCK: phase clocks of the workgroup kernel)
+    u32 blk_cursor[4];                // the workgroup kernels' shared cursors over the front queue ([0,1] plain kernel: long queries first, then the rest; [2,3] two-class kernel)
+    u32 w_cursor[2];                  // (-DMCQ_WAVE_DYNQ) the same for the second / third wave stage
+    unsigned long long n_long;        // queries of MCQ_BLOCK_LONG_FIRST bases and more (the workgroup kernels take those first: a pass of its own)
+    unsigned long long pad_[17];      // (diagnostic builds, -DMCQ_PHASE_CLOCK: phase clocks of the workgroup kernel)
     unsigned long long* probe_buf;
     unsigned long long* probe_front;  // the same for FRONT-queue slots of queries with <= 64 features (third wave stage); a lane without
                                       // a feature holds 0xFFFF

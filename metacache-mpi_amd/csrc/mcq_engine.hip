@@ -896,7 +896,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
     u32* feat = hits + 64;
     const u64 nwaves = (u64)gridDim.x * 4;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0;
-    u32 st_geom = 0;
+    u32 st_geom = 0, st_long = 0;
 #ifdef MCQ_PROFILE_HOOKS
     const int stop = force_block >> 4;              // profiling builds: stop after stage 1..5 (results invalid); 0 = run everything
 #else
@@ -926,8 +926,8 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
             for (u64 q0 = ((u64)blockIdx.x * 4 + wave) * 64; q0 < b.nq; q0 += nwaves * 64) {
                 const u64 q = q0 + lane;
                 const bool valid = q < b.nq;
-                bool front = false;
-                if (valid) { const ReadGeom g = read_geom(db, b, q, 0); front = g.ovf && !g.wide; }
+                bool front = false, lng = false;
+                if (valid) { const ReadGeom g = read_geom(db, b, q, 0); front = g.ovf && !g.wide; lng = MCQ_BLOCK_LONG_FIRST && g.qlen >= MCQ_BLOCK_LONG_FIRST; }
 #pragma unroll
                 for (int back = 0; back < 2; ++back) {
                     const u64 m = __ballot(valid && (back ? !front : front));
@@ -941,7 +941,8 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
                     if (lane < padded - cnt) ovf_list[ovf_slot(b.nq, back, base + cnt + lane)] = MCQ_EMPTY;
                 }
                 const u32 nv = (u32)__builtin_popcountll(__ballot(valid)), nf = (u32)__builtin_popcountll(__ballot(valid && front));      // (by every lane)
-                if (lane == 0) { atomicAdd(&ctr->n_ovf, nv); if (nf) atomicAdd(&ctr->n_geom, (unsigned long long)nf); }
+                const u32 nl = (u32)__builtin_popcountll(__ballot(lng));
+                if (lane == 0) { atomicAdd(&ctr->n_ovf, nv); if (nf) atomicAdd(&ctr->n_geom, (unsigned long long)nf); if (nl) atomicAdd(&ctr->n_long, (unsigned long long)nl); }
             }
             return;
         }
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
         }
         if (ovf) {
             if (g.ovf && !g.wide) ++st_geom;
+            if (MCQ_BLOCK_LONG_FIRST && g.qlen >= MCQ_BLOCK_LONG_FIRST) ++st_long;
             // two queues in one array: 32-bit keys and either 513..1024 locations or 65..128 features from the back
             // (k_query_wave16: still one wave per query), everything else from the front (k_query_block)
             if (lane == 0) {
@@ -1082,6 +1084,7 @@ __global__ __launch_bounds__(256, sizeof(KeyT) == 4 ? (NL > 1 ? 5 : MCQ_WAVE_OCC
     }
     if (lane == 0) ovf_flush(s_ovf[wave], ctr, ovf_list, b.nq);
     if (lane == 0 && st_geom) atomicAdd(&ctr->n_geom, (unsigned long long)st_geom);
+    if (lane == 0 && st_long) atomicAdd(&ctr->n_long, (unsigned long long)st_long);
     if (lane == 0 && (st_feat | st_loc | st_hit)) {
         if (st_feat) atomicAdd(&ctr->n_features, st_feat);
         atomicAdd(&ctr->n_hit_features, st_hit);
@@ -1120,7 +1123,18 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     float word_space;
     if constexpr (GW) word_space = (float)gwd.off[db.n_targets];
     else word_space = (db.wb < 32 && ((u64)db.n_targets << db.wb) < 0xFFFFFFFFull) ? (float)((u64)db.n_targets << db.wb) : 4294967040.0f;
+    // (-DMCQ_WAVE_DYNQ, tuning knob: the waves take their entries from a shared cursor, MCQ_WAVE_DYNQ_CH at a time, instead of striding)
+#ifdef MCQ_WAVE_DYNQ
+    for (u32 cb = 0;;) {
+        if (lane == 0) cb = atomicAdd(&ctr->w_cursor[0], (u32)MCQ_WAVE_DYNQ_CH);
+        cb = bcast(cb, 0);
+        if (cb >= n_mid) break;
+        const u32 ce = cb + (u32)MCQ_WAVE_DYNQ_CH < n_mid ? cb + (u32)MCQ_WAVE_DYNQ_CH : n_mid;
+    for (u32 it = cb; it < ce; ++it) {
+#else
+    {
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
+#endif
         const u32 qe = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
         if (qe == MCQ_EMPTY) continue;                 // unused tail of a wave's reservation
         const u32 q32 = qe & ~MCQ_Q_UNPROBED;
@@ -1246,6 +1260,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         st_cand += topk_heads<JB, LCAP>(db, opt, out, buf, hits, T, numWindows, lf, q, lane);
         wave_sync();
     }
+    }
     if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
     if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
     if (lane == 0 && st_retry) atomicAdd(&ctr->n_two_class_retry, st_retry);
@@ -1291,7 +1306,17 @@ __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, O
     float word_space;
     if constexpr (GW) word_space = (float)gwd.off[db.n_targets];
     else word_space = (db.wb < 32 && ((u64)db.n_targets << db.wb) < 0xFFFFFFFFull) ? (float)((u64)db.n_targets << db.wb) : 4294967040.0f;
+#ifdef MCQ_WAVE_DYNQ
+    for (u32 cb = 0;;) {
+        if (lane == 0) cb = atomicAdd(&ctr->w_cursor[1], (u32)MCQ_WAVE_DYNQ_CH);
+        cb = bcast(cb, 0);
+        if (cb >= n_front) break;
+        const u32 ce = cb + (u32)MCQ_WAVE_DYNQ_CH < n_front ? cb + (u32)MCQ_WAVE_DYNQ_CH : n_front;
+    for (u32 it = cb; it < ce; ++it) {
+#else
+    {
     for (u32 it = blockIdx.x * 4 + wave; it < n_front; it += nwaves) {
+#endif
         const u32 slot = ovf_visit(it, n_front);
         const u32 q32 = ovf_list[slot];
         if (q32 == MCQ_EMPTY) continue;                // unused tail of a wave's reservation
@@ -1360,6 +1385,7 @@ __global__ __launch_bounds__(256, 2) void k_query_wave32(DbDev db, BatchDev b, O
             st_hit += (u32)__builtin_popcountll(__ballot(len0 > 0)) + (u32)__builtin_popcountll(__ballot(len1 > 0));
         }
         st_loc += T; st_cand += n2; st_two += 1;
+    }
     }
     if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
     if (lane == 0 && st_narrow) atomicAdd(&ctr->n_narrow, st_narrow);
@@ -1606,11 +1632,31 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
 #else
     u64* const ph = nullptr;
 #endif
-    for (u32 it0 = blockIdx.x; it0 < n_ovf; it0 += gridDim.x * 64u) {
-    __syncthreads();                                   // (the entries of the visits before are consumed)
-    if (tid < 64) { const u64 it = (u64)it0 + (u64)tid * gridDim.x; s_q[tid] = it < n_ovf ? ovf_list[ovf_visit((u32)it, n_ovf)] : MCQ_EMPTY; }
+    // The workgroups take their queue entries from a shared cursor, a chunk at a time (r04; until then entry k belonged to workgroup
+    // k mod 512): queries cost by their length -- ONT-like reads: log-normal, sigma 0.6 -- and of 512 workgroups with 32 reads each
+    // the unluckiest took a third longer than the average while the others had gone idle (2.55 -> 2.03 ms per 16 384 reads).  The
+    // chunk: 1/32 of a workgroup's even share, at most 64 (a RefSeq-scale batch of pairs leaves a million entries of which 99 %
+    // are empty markers: fetched 64 at a time), at least 1.  Two passes over the queue, each with its cursor: first the queries of
+    // MCQ_BLOCK_LONG_FIRST bases and more -- the longest ones take a workgroup many times the average, and one that is started last
+    // is what the whole grid then waits for -- then the others.  Every workgroup leaves a pass when its cursor has passed the end.
+    __shared__ u32 s_chunk;
+    const bool ctr_long = ctr->n_long != 0;            // (written by the first wave stage, which is done)
+#ifndef MCQ_BLOCK_QUEUE_DIV
+#define MCQ_BLOCK_QUEUE_DIV 32u                         // tuning knob: chunks per workgroup's even share (measured: 2 -> 2.45, 8 -> 2.11, 32 -> 2.03 ms)
+#endif
+    const u32 share = n_ovf / (gridDim.x * MCQ_BLOCK_QUEUE_DIV);
+    const u32 C1 = share < 1u ? 1u : (share > 64u ? 64u : share);
+    for (u32 pass = (MCQ_BLOCK_LONG_FIRST && ctr_long) ? 0u : 1u; pass < 2u; ++pass) {       // (no long queries in the batch: no first pass)
+    const u32 C = pass ? C1 : (C1 * 16u > 64u ? 64u : C1 * 16u);       // (the long ones are few: the first pass mostly skips)
+    for (;;) {
+    __syncthreads();                                   // (the entries of the chunk before are consumed)
+    if (tid == 0) s_chunk = atomicAdd(&ctr->blk_cursor[(TC ? 2 : 0) + pass], C);
     __syncthreads();
-    for (u32 k = 0; k < 64; ++k) {
+    const u32 it0 = s_chunk;
+    if (it0 >= n_ovf) break;                           // (uniform)
+    if (tid < C) { const u32 it = it0 + tid; s_q[tid] = it < n_ovf ? ovf_list[ovf_visit(it, n_ovf)] : MCQ_EMPTY; }
+    __syncthreads();
+    for (u32 k = 0; k < C; ++k) {
         const u32 q32 = s_q[k];
         if (q32 == MCQ_EMPTY) continue;                // answered, or the unused tail of a wave's reservation (uniform over the workgroup)
         const u64 q = q32;
@@ -1619,6 +1665,7 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         seq_bounds(b.seq_off, b.ranges, a, o0, e0);
         if (b.paired) seq_bounds(b.seq_off, b.ranges, a + 1, o1, e1); else { o1 = e0; e1 = e0; }
         const u64 n1 = e0 - o0, n2 = e1 - o1;
+        if (MCQ_BLOCK_LONG_FIRST && ctr_long && (n1 + n2 >= MCQ_BLOCK_LONG_FIRST) != (pass == 0u)) continue;      // (the other pass's)
         const u32 nw1 = num_windows(n1, W, S), nw2 = b.paired ? num_windows(n2, W, S) : 0;
         const u64 NW = (u64)nw1 + nw2;
         // which of the two workgroup kernels takes this query (uniform): narrow window ranges = short queries (opt.tc_limit: the
@@ -1756,9 +1803,10 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
         else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
     }
     }
+    }
 #ifdef MCQ_PHASE_CLOCK
     __syncthreads();
-    if (tid < 21 && s_ph[tid]) atomicAdd(&ctr->pad_[tid], (unsigned long long)s_ph[tid]);
+    if (tid < 17 && s_ph[tid]) atomicAdd(&ctr->pad_[tid], (unsigned long long)s_ph[tid]);
 #endif
 }
 
@@ -3010,7 +3058,7 @@ extern "C" int mcq_ws_sync(mcq_ws* ws, void* stream, mcq_stats* stats) {
 // synchronised by mcq_ws_sync (zeros in a normal build)
 extern "C" int mcq_debug_phase_clocks(mcq_ws* ws, uint64_t* out22) {
     if (!ws || !out22) return fail(MCQ_E_ARG, "null argument");
-    for (int i = 0; i < 22; ++i) out22[i] = i < 21 ? ws->ctr_host->pad_[i] : 0;
+    for (int i = 0; i < 22; ++i) out22[i] = i < 17 ? ws->ctr_host->pad_[i] : 0;
     return MCQ_OK;
 }
 
