@@ -925,7 +925,10 @@ __device__ __forceinline__ void bitonic_sort_block(KeyT* buf, u32 n2p, u32 npad,
 // search: hits(j) = j - lower_bound(tgt, win_j - numWindows + 1) + 1.  The run's best is
 // the maximum of (hits, -j): folded with an LDS atomic max into H[first entry of the run].
 //   H[j0] = (hits << JB) | (JMASK - jbest) for run heads, 0 elsewhere.
-template <class KeyT, class HT, int JB, class LF, class Sync>
+// PRE (H in global memory): the entries of a run are neighbours, so a wave first takes the maximum over each run's entries among its
+// 64 (segmented prefix maximum, six shuffle steps) and only the last lane of a run's segment issues the atomic -- a read's true
+// targets have runs of thousands of entries, which would otherwise queue on one address in L2.
+template <class KeyT, class HT, int JB, class LF, bool PRE = false, class Sync>
 __device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32 numWindows, const LF& lf, u32 tid, u32 G,
                                               u32* s_w /* G / 64 + 1 words of LDS */, Sync sync) {
     // The head of an entry's run: last run start at or before it -- a ballot of run starts inside the wave, the last
@@ -955,6 +958,18 @@ __device__ __forceinline__ void sweep_targets(const KeyT* buf, HT* H, u32 T, u32
         const KeyT lowkey = range_low<KeyT>(key, tb, numWindows);
         u32 lo = myhead, hi = valid ? j : myhead;
         while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (buf[mid] < lowkey) lo = mid + 1; else hi = mid; }
+        if constexpr (PRE) {
+            HT v = valid ? (((HT)(j - lo + 1) << JB) | (JMASK - (HT)j)) : (HT)0;
+            const u32 hd = valid ? myhead : 0xFFFFFFFFu;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const HT o = (HT)__shfl_up(v, d, 64);
+                const u32 oh = (u32)__shfl_up(hd, d, 64);
+                if (lane >= (u32)d && oh == hd && o > v) v = o;
+            }
+            const u32 nh = (u32)__shfl_down(hd, 1, 64);
+            if (valid && (lane == 63 || nh != hd)) atomicMax(&H[myhead], v);
+        } else
         if (valid) atomicMax(&H[myhead], ((HT)(j - lo + 1) << JB) | (JMASK - (HT)j));
         sync();                                                     // s_w has been read by everyone
         if (tid == G - 1) s_w[nwv] = mylast ? mylast : before;      // last run start so far

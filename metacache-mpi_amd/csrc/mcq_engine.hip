@@ -1462,7 +1462,7 @@ __device__ __forceinline__ u32 block_excl_scan4(u32* a, u32 n, u32 tid) {
 // HT/JB: packed (hits << JB | index) word of the sweep: u32 with JB = 13 when the list fits the workgroup's LDS
 // (<= 8192 entries, hits <= 8192), u64 with JB = 32 in global scratch
 // filled: B[0..T) holds the unsorted list already
-template <class KeyT, class HT, int JB, int BIG, bool RTLIN = false, class LF, class Fill>
+template <class KeyT, class HT, int JB, int BIG, bool RTLIN = false, class LF, class Fill, bool HGLOBAL = false>
 __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, const OutDev& out, CountersDev* ctr,
                                            KeyT* B, HT* H, u32 T, u32 numWindows, const LF& lf, u64 q, u32 tid,
                                            const DebugDev& dbg, u32* biglist, Fill fill, bool filled = false) {
@@ -1480,7 +1480,7 @@ __device__ __forceinline__ void block_tail(const DbDev& db, const OptDev& opt, c
         for (u32 t = tid; t < T; t += NTB) dbg.matches[dbg.match_off[q] + t] = key_expand<KeyT>(B[t], lf);
     }
     __shared__ TopkBlockScratch<HT> s_topk;
-    sweep_targets<KeyT, HT, JB>(B, H, T, numWindows, lf, tid, NTB, s_topk.fmx, [] { __syncthreads(); });
+    sweep_targets<KeyT, HT, JB, LF, HGLOBAL>(B, H, T, numWindows, lf, tid, NTB, s_topk.fmx, [] { __syncthreads(); });
     const u32 n = topk_block<KeyT, HT, JB, BIG, RTLIN>(db, opt, out, B, H, T, numWindows, lf, q, tid, NTB, &s_topk, biglist, [] { __syncthreads(); });
     if (tid == 0) atomicAdd(&ctr->n_cands, (unsigned long long)n);
     __syncthreads();
@@ -1599,8 +1599,10 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
     static_assert(LCAPB <= 8192, "packed sweep word: 13 index bits");
     const typename LocOf<KeyT, GW>::type lf = loc_format<KeyT, GW>(db, gwd);
     constexpr u32 NW16 = NT / 64;
-    __shared__ KeyT s_buf[LCAPB];
-    __shared__ u32 s_hits[LCAPB];
+    // the key segment and the hit words behind it, in ONE allocation: lists of 8193 .. 16384 32-bit words sort across both (r04)
+    __shared__ __attribute__((aligned(16))) unsigned char s_mem[(size_t)LCAPB * (sizeof(KeyT) + 4)];
+    KeyT* const s_buf = reinterpret_cast<KeyT*>(s_mem);
+    u32* const s_hits = reinterpret_cast<u32*>(s_mem + (size_t)LCAPB * sizeof(KeyT));
     __shared__ u32 s_w[20];
     __shared__ u32 s_biglist[BIG == 1 ? 2 * MCQ_BIGLIST_MAX : 1];  // P lists of M entries when they do not fit a wave (OptDev::big)
     const u32 tid = threadIdx.x, lane = tid & 63;
@@ -1775,6 +1777,11 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
                 }
             }
         };
+#ifdef MCQ_NO_BLOCK_MID                                // tuning knob (A/B)
+        constexpr bool mid_ok = false;
+#else
+        constexpr bool mid_ok = sizeof(KeyT) == 4 && BIG == 2;
+#endif
         // (the sort is padded to whole 128-key chunks only, so a list fits the LDS whenever that many keys do)
         if (((T + 127u) & ~127u) <= (u32)LCAPB && pow2ceil(T) <= 8192u) {
             int tc = TC_NOT_TRIED;
@@ -1799,6 +1806,14 @@ __global__ __launch_bounds__(NT, sizeof(KeyT) == 4 ? 8 : 4) void k_query_block(D
             }
             const bool done = tc == TC_DONE, filled = tc == TC_HEAVY;
             if (!done) { block_tail<KeyT, u32, 13, BIG>(db, opt, out, ctr, s_buf, s_hits, T, numWindows, lf, q, tid, dbg, s_biglist, fill, filled); PHCLK(ph, 10); }
+        }
+        // 8193 .. 16384 words (ONT-like reads of 27 .. 55 kb: one in a hundred, and until r04 a sixth of the kernel's time -- a workgroup
+        // took 23-27 us per kb of such a read against 6.5 below, everything in global scratch): the list sorts in the LDS of BOTH
+        // segments (32-bit words; the query's feature arrays are in global scratch at this size), only the sweep's packed words and
+        // the lists' scans go through global memory, the atomics reduced per run inside a wave first (sweep_targets<..., true>)
+        else if (mid_ok && !f_lds && dbg.mode == 0 && ((T + 127u) & ~127u) <= 2u * (u32)LCAPB) {
+            if constexpr (sizeof(KeyT) == 4 && BIG == 2)
+                block_tail<KeyT, u32, 14, BIG, false, decltype(lf), decltype(fill), true>(db, opt, out, ctr, s_buf, reinterpret_cast<u32*>(ghits), T, numWindows, lf, q, tid, dbg, s_biglist, fill);
         }
         else                           block_tail<KeyT, u64, 32, BIG>(db, opt, out, ctr, gbuf, ghits, T, numWindows, lf, q, tid, dbg, s_biglist, fill);
     }
