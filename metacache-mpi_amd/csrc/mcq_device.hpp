@@ -59,7 +59,7 @@ struct DbDev {
 // that followed cost it 2 % (+270 spill reloads).
 struct GwDev {
     const u32* off;          // [n_targets + 1] first global window of every target
-    const u32* blk;          // [(n_windows >> shift) + 2] target that holds window b << shift
+    const u32* blk;          // [(n_windows >> shift) + 2] pairs: target that holds window b << shift, its first window (LocGW)
     u32 shift;               // blk has one entry per 2^shift windows
     u32 on;
 };
@@ -84,15 +84,22 @@ struct LocShift {
 };
 struct LocGW {
     static constexpr bool lookup = true;       // tgt / tbeg cost memory accesses: callers keep what they looked up
-    const u32* __restrict__ off; const u32* __restrict__ blk; u32 shift;
+    const u32* __restrict__ off; const uint2* __restrict__ blk; u32 shift;
+    // blk[b] = (last target t with off[t] <= b << shift, off[t]): the target of k lies between blk[k >> shift] and the next entry,
+    // and is one of those two unless two or more targets start inside the block -- ONE round trip to memory then (two loads side by
+    // side) where a table of target numbers alone took two, three with the search (r04: the lists of the two-class tail wait for this)
     __device__ __forceinline__ void locate(u32 k, u32& t, u32& tb) const {
         const u32 b = k >> shift;
-        u32 lo = blk[b], hi = blk[b + 1];                // the target of k lies in [lo, hi]
-        u32 o = off[lo];
-        while (lo < hi) {                                // several targets start inside the block
-            const u32 mid = (lo + hi + 1) >> 1;
-            const u32 om = off[mid];
-            if (om <= k) { lo = mid; o = om; } else hi = mid - 1;
+        const uint2 a = blk[b], c = blk[b + 1];
+        u32 lo = a.x, hi = c.x, o = a.y;
+        if (c.y <= k) { lo = hi; o = c.y; }              // (also when both entries name the same target)
+        else {
+            --hi;                                        // c.y > k >= a.y: hi > lo
+            while (lo < hi) {                            // several targets start inside the block
+                const u32 mid = (lo + hi + 1) >> 1;
+                const u32 om = off[mid];
+                if (om <= k) { lo = mid; o = om; } else hi = mid - 1;
+            }
         }
         t = lo; tb = o;
     }
@@ -103,7 +110,7 @@ template <class KeyT, bool GW> struct LocOf { typedef LocShift<KeyT> type; };
 template <> struct LocOf<u32, true> { typedef LocGW type; };
 template <class KeyT, bool GW>
 __device__ __forceinline__ typename LocOf<KeyT, GW>::type loc_format(const DbDev& db, const GwDev& g) {
-    if constexpr (GW) { LocGW f; f.off = g.off; f.blk = g.blk; f.shift = g.shift; return f; }
+    if constexpr (GW) { LocGW f; f.off = g.off; f.blk = reinterpret_cast<const uint2*>(g.blk); f.shift = g.shift; return f; }
     else { LocShift<KeyT> f; f.wb = db.wb; return f; }
 }
 // smallest word of a window range of `numWindows` windows that ends at k (never below the target's first word)
@@ -1644,12 +1651,13 @@ __device__ __forceinline__ u32 two_class_lin_write(const OptDev& opt, const OutD
 
 // Top lists + fold + write from the heavy run heads (H[0..nheads) packed (hits << JB | JMASK - j), j indexing the sorted
 // distinct heavy words SK) and the light prefix (lkey: this lane's light word, MCQ_EMPTY = none; ascending or not does not
-// matter).  Entries are compared as 64-bit words (hits << 32 | ~word): heavy and light ones in one order.  NC chunks of 64
+// matter; lhits: its hits -- 1, unless the caller has put run heads into the light lanes: NC = 0, everything in one chunk).
+// Entries are compared as 64-bit words (hits << 32 | ~word): heavy and light ones in one order.  NC chunks of 64
 // heads.  light_omitted: light words >= theta exist that are not among the entries.  Returns the number of candidates
 // written, or ~0u when the lists cannot be proven exact (nothing written then).  scr: 192 words of LDS (64 x u64, 64 x u32).
 template <int JB, int NC, class LF>
 __device__ __forceinline__ u32 topk_two_class(const DbDev& db, const OptDev& opt, const OutDev& out, const u32* SK, u32 D, const u32* H, u32 nheads,
-                                              u32 lkey, bool light_omitted, u32 theta, u32 numWindows, const LF& lf, u64 q, u32 lane, u32* scr) {
+                                              u32 lkey, bool light_omitted, u32 theta, u32 numWindows, const LF& lf, u64 q, u32 lane, u32* scr, u32 lhits = 1) {
     const u32 M = opt.max_cand, P = opt.P, seg = opt.seg;
     const bool p2 = (P & (P - 1)) == 0;
     const u32 JMASK = (1u << JB) - 1;
@@ -1665,7 +1673,7 @@ __device__ __forceinline__ u32 topk_two_class(const DbDev& db, const OptDev& opt
             const u32 k = c * 64 + lane;
             const u32 v = (k < nheads) ? H[k] : 0u;
             if (v) { key = SK[JMASK - (v & JMASK)]; hits = v >> JB; }
-        } else if (lkey != MCQ_EMPTY) { key = lkey; hits = 1; }
+        } else if (lkey != MCQ_EMPTY) { key = lkey; hits = lhits; }
         const u32 tgt = lf.tgt(hits ? key : SK[0]);               // (idle lanes look up a real word)
         if (hits && tgt < db.n_targets) tax[c] = db.tgt2tax[tgt];
         rk[c] = (P > 1) ? (p2 ? (tgt & (P - 1)) : (tgt % P)) : 0;

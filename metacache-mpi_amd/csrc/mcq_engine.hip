@@ -216,14 +216,14 @@ __global__ void k_tgt_extent(const u64* locs, u64 n, u32 n_targets, u32* ext) {
         if (t < n_targets && w != 0xFFFFFFFFu && *reinterpret_cast<volatile const u32*>(&ext[t]) <= w) atomicMax(&ext[t], w + 1);
     }
 }
-// gw_blk[b] = last target t with gw_off[t] <= b << shift (targets without windows are skipped)
-__global__ void k_gw_blocks(const u32* gw_off, u32 n_targets, u32 shift, u64 n_blk, u32* blk) {
+// gw_blk[b] = (last target t with gw_off[t] <= b << shift, gw_off[t]) (targets without windows are skipped)
+__global__ void k_gw_blocks(const u32* gw_off, u32 n_targets, u32 shift, u64 n_blk, uint2* blk) {
     const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_blk) return;
     const u64 w = b << shift;
     u32 lo = 0, hi = n_targets ? n_targets - 1 : 0;
     while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if ((u64)gw_off[mid] <= w) lo = mid; else hi = mid - 1; }
-    blk[b] = lo;
+    blk[b] = make_uint2(lo, gw_off[lo]);
 }
 __global__ void k_u64_to_u32(const u64* in, u32* out, u64 n) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -521,6 +521,15 @@ __device__ __forceinline__ u32 topk_dedup(const DbDev& db, const OptDev& opt, co
 #endif
     return topk_fold_write_lds<9, LF::lookup>(db, opt, out, sk, H, D, numWindows, lf, q, lane, H + 256, t1);
 }
+// -DMCQ_PHASE_CLOCK (diagnostic builds only): lane 0 of every wave of the second wave stage adds the shader clocks between the marks
+// below into LDS (loads drained first), folded into CountersDev::pad_[3..9], [11] when the kernel ends
+#ifdef MCQ_PHASE_CLOCK
+__shared__ u64 g_wph[4][12];
+#define WCLK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); if ((threadIdx.x & 63) == 0) { const u64 t_ = __builtin_amdgcn_s_memtime(); \
+    u64* p_ = g_wph[threadIdx.x >> 6]; p_[i] += t_ - p_[11]; p_[11] = t_; } } while (0)
+#else
+#define WCLK(i) do { } while (0)
+#endif
 __device__ __forceinline__ u32 dedup_slot(u32 key) { return (key * 0x9E3779B1u) >> 23; }
 __device__ __forceinline__ u32* dedup_sk(u32* hits) { return hits + 256; }
 __device__ __forceinline__ u32* dedup_wp(u32* hits) { return hits; }
@@ -656,14 +665,12 @@ __device__ __forceinline__ u32 lds_dedup_insert(const u32* src, u32* buf, u32* h
 // Heavy words of the two-class tail: nH of them staged in hits[0..nH), E = registers per lane they need.  They repeat
 // (a true target is hit by up to s features per window), so the distinct-key table is tried first -- any number of words,
 // up to 256 distinct ones -- and only a list with more distinct words is sorted raw (E >= 8 then).  Either way the sweep
-// leaves the sorted words SK[0..D) and the run heads' packed words, which go, with the light prefix, into the lists.
+// leaves the sorted words SK[0..D) and the run heads' packed words H[0..D) (nine: packed with 9 index bits -- the distinct-key
+// sweeps -- or 10), which go, with the light prefix, into the lists (heavy_lists).  false: not sorted here.
 template <int E, class LF>
-__device__ __forceinline__ u32 heavy_tail(const DbDev& db, const OptDev& opt, const OutDev& out, u32 nH, u32 lkey, bool omitted, u32 theta, u32 safe,
-                                          u32 numWindows, const LF& lf, u64 q, u32 lane, u32* buf, u32* hits) {
+__device__ __forceinline__ bool heavy_sweep(u32 nH, u32 numWindows, const LF& lf, u32 lane, u32* buf, u32* hits, u32& D, u32*& SK, u32*& H, bool& nine) {
     constexpr int JB = 10;                                   // entry index of the lists: up to 1024 sorted words
-    u32 D = 0;
-    u32 *SK = dedup_sk(hits), *H = buf;
-    bool nine = true;                                        // H packed with 9 index bits (distinct-key sweeps) or JB
+    D = 0; SK = dedup_sk(hits); H = buf; nine = true;
     if (nH) {
         u32 rh[E];
 #pragma unroll
@@ -671,7 +678,8 @@ __device__ __forceinline__ u32 heavy_tail(const DbDev& db, const OptDev& opt, co
         wave_sync();
         u32 k1 = MCQ_EMPTY, incl1 = 0, t1 = 0, tb1 = 0;
         const u32 Dd = dedup_insert<E>(rh, buf, hits, nH, lane);
-        if (E > 16 && Dd > MCQ_DEDUP_MAX_D) return ~1u;       // (32 registers of heavy words with more than 256 distinct ones: not sorted here)
+        WCLK(4);
+        if (E > 16 && Dd > MCQ_DEDUP_MAX_D) return false;     // (32 registers of heavy words with more than 256 distinct ones: not sorted here)
         if (E <= 4 || Dd <= MCQ_DEDUP_MAX_D) {
             D = dedup_finish(Dd, buf, hits, lane, lf, k1, incl1, t1, tb1);
             if (D <= 64 && numWindows <= 8) sweep_targets_regs(k1, incl1, tb1, H, D, numWindows, lf, lane);
@@ -686,6 +694,14 @@ __device__ __forceinline__ u32 heavy_tail(const DbDev& db, const OptDev& opt, co
             sweep_targets_wave<u32, JB>(SK, H, D, numWindows, lf, lane);
         }
     } else wave_sync();
+    return true;
+}
+// The lists from what heavy_sweep left (one copy of this code per kernel, whatever E was)
+template <class LF>
+__device__ __forceinline__ u32 heavy_lists(const DbDev& db, const OptDev& opt, const OutDev& out, u32 D, u32* SK, u32* H, bool nine, u32 lkey, bool omitted,
+                                           u32 theta, u32 safe, u32 numWindows, const LF& lf, u64 q, u32 lane) {
+    constexpr int JB = 10;
+    WCLK(5);
     // run heads to the front of H (in place: writes trail reads), re-packed with JB index bits.  A head with ONE hit is no
     // better than a light word: it stays only below theta -- the others join the omitted light words (same proof: one hit,
     // word >= theta)
@@ -706,7 +722,18 @@ __device__ __forceinline__ u32 heavy_tail(const DbDev& db, const OptDev& opt, co
     wave_sync();
     if (nheads > 256) return ~1u;                            // (heads with two or more hits, or below theta: a dozen or two)
     // scratch of the lists: 192 words of H's segment that neither the heads (<= 256 words) nor, in the other segment, SK touch
-    const u32 n = topk_two_class<JB, 4>(db, opt, out, SK, D, H, nheads, lkey, omitted || dropped, theta, numWindows, lf, q, lane, H + 512 + 64);
+    u32 n;
+    const u32 nP = (u32)__builtin_popcountll(__ballot(lkey != MCQ_EMPTY));      // (the light prefix sits in lanes [0, nP))
+    if (nheads + nP <= 64u) {
+        // the usual case -- a dozen or two heads, ~40 light words: ONE chunk of entries, heads in the lanes behind the light words
+        // (one look-up of targets and taxa instead of two in a row, a fifth of the list rounds' compares)
+        const u32 i = lane - nP;
+        const u32 v = (lane >= nP && i < nheads) ? H[i] : 0u;
+        const u32 mkey = v ? SK[((1u << JB) - 1) - (v & ((1u << JB) - 1))] : lkey;
+        n = topk_two_class<JB, 0>(db, opt, out, SK, D, H, 0u, mkey, omitted || dropped, theta, numWindows, lf, q, lane, H + 512 + 64, v ? v >> JB : 1u);
+    } else
+        n = topk_two_class<JB, 4>(db, opt, out, SK, D, H, nheads, lkey, omitted || dropped, theta, numWindows, lf, q, lane, H + 512 + 64);
+    WCLK(6);
     return n == ~0u ? ~1u : n;
 }
 
@@ -736,6 +763,7 @@ __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt
 #pragma unroll
     for (int e = 0; e < E; ++e) if ((u32)(e * 64) < T && (u32)(e * 64) + lane < T && cells_heavy<LOG>(r[e], cs, occ, multi)) hm |= (decltype(hm))1 << e;
     wave_sync();                                             // the maps are dead: heavy words -> hits[0..nH), light prefix -> buf[0..nP)
+    WCLK(2);
     const float th = word_space * MCQ_TWO_CLASS_EXPECT * __builtin_amdgcn_rcpf((float)T);
     const u32 theta = th >= 4294967040.0f ? 0xFFFFFFFEu : (u32)th;
     u32 nH = 0, nL = 0, nP = 0;
@@ -754,18 +782,22 @@ __device__ __forceinline__ u32 two_class_tail(const DbDev& db, const OptDev& opt
     }
     nL = T - nH;                                             // (every word is one or the other)
     wave_sync();
+    WCLK(3);
     if (nP > 64) return ~0u;                                 // theta too generous for this read (words far from uniform)
     const u32 safe = bcast(r[0], 0);                         // any real word (T >= 1)
     const u32 lkey = lane < nP ? buf[lane] : MCQ_EMPTY;
     const bool omitted = nL > nP;
     // from here on r[] is spent: the heavy words come back from LDS into as many registers as they need
-    if (nH <= 64)  return heavy_tail<1>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
-    if (nH <= 128) return heavy_tail<2>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
-    if (nH <= 256) return heavy_tail<4>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
-    if (nH <= 512) return heavy_tail<8>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits);
-    if constexpr (E > 8) { if (nH <= 1024) return heavy_tail<16>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits); }
-    if constexpr (E > 16) { if (nH <= 2048) return heavy_tail<32>(db, opt, out, nH, lkey, omitted, theta, safe, numWindows, lf, q, lane, buf, hits); }
-    return ~1u;
+    u32 D, *SK, *H; bool nine, ok;
+    if (nH <= 64)       ok = heavy_sweep<1>(nH, numWindows, lf, lane, buf, hits, D, SK, H, nine);
+    else if (nH <= 128) ok = heavy_sweep<2>(nH, numWindows, lf, lane, buf, hits, D, SK, H, nine);
+    else if (nH <= 256) ok = heavy_sweep<4>(nH, numWindows, lf, lane, buf, hits, D, SK, H, nine);
+    else if (nH <= 512) ok = heavy_sweep<8>(nH, numWindows, lf, lane, buf, hits, D, SK, H, nine);
+    else if (E > 8 && nH <= 1024) { if constexpr (E > 8) ok = heavy_sweep<16>(nH, numWindows, lf, lane, buf, hits, D, SK, H, nine); }
+    else if (E > 16 && nH <= 2048) { if constexpr (E > 16) ok = heavy_sweep<32>(nH, numWindows, lf, lane, buf, hits, D, SK, H, nine); }
+    else return ~1u;
+    if (!ok) return ~1u;
+    return heavy_lists(db, opt, out, D, SK, H, nine, lkey, omitted, theta, safe, numWindows, lf, q, lane);
 }
 
 // geometry of one read (or pair) on the wave path
@@ -1118,6 +1150,10 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     const u32 nwaves = gridDim.x * 4;
     const u32 n_mid = ctr->ovf_mid_count;
     unsigned long long st_feat = 0, st_hit = 0, st_loc = 0, st_cand = 0, st_two = 0, st_retry = 0, st_short = 0;
+#ifdef MCQ_PHASE_CLOCK
+    if (lane < 12) g_wph[wave][lane] = lane == 11 ? (u64)__builtin_amdgcn_s_memtime() : 0;
+    wave_sync();
+#endif
     u32 fq_next = 0, fq_left = 0;                      // this wave's reservation in the front queue (wide reads with > 1024 locations)
     // size of the space the location words live in (for the light-word threshold of the two-class tail)
     float word_space;
@@ -1135,6 +1171,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
     {
     for (u32 it = blockIdx.x * 4 + wave; it < n_mid; it += nwaves) {
 #endif
+        WCLK(7);
         const u32 qe = ovf_list[ovf_slot(b.nq, 1, ovf_visit(it, n_mid))];
         if (qe == MCQ_EMPTY) continue;                 // unused tail of a wave's reservation
         const u32 q32 = qe & ~MCQ_Q_UNPROBED;
@@ -1176,6 +1213,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         const u32 incl1 = wave_incl_scan_dpp(len1) + T0;
         const u32 pos0 = incl0 - len0, pos1 = incl1 - len1;
         const u32 T = bcast(incl1, 63);                // <= 1024 for the queries queued by their length
+        WCLK(0);
         if (T > (u32)LCAP) {                           // a longer list than this stage takes: on to the front queue
             if (fq_left == 0) {
                 u32 base = 0;
@@ -1224,6 +1262,7 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         {
             u32 r[16];
             gather_regs2<16>(db, r, T, pos0, len0, off0, pos1, len1, off1, two, lane, hits);
+            WCLK(1);
             if constexpr (!TAP) {                       // (the taps want the whole sorted list)
                 const u32 n2 = two_class_tail<16>(db, opt, out, r, T, numWindows, word_space, lf, q, lane, buf, hits);
                 if (n2 == ~1u) {                        // given up after the registers were spent: the workgroup kernel takes it
@@ -1261,6 +1300,11 @@ __global__ __launch_bounds__(256, MCQ_WAVE16_OCC) void k_query_wave16(DbDev db, 
         wave_sync();
     }
     }
+#ifdef MCQ_PHASE_CLOCK
+    WCLK(7);
+    wave_sync();
+    if (lane < 8 && g_wph[wave][lane]) atomicAdd(&ctr->pad_[lane < 7 ? 3 + lane : 11], (unsigned long long)g_wph[wave][lane]);
+#endif
     if (lane == 0) for (; fq_left; --fq_left, ++fq_next) ovf_list[fq_next] = MCQ_EMPTY;
     if (lane == 0 && st_two) atomicAdd(&ctr->n_two_class, st_two);
     if (lane == 0 && st_retry) atomicAdd(&ctr->n_two_class_retry, st_retry);
@@ -2397,13 +2441,13 @@ static int make_gw_tables(const u32* d_ext, u32 nt, DevTemps& tmp, u32** gw_off,
     HIPCHK(hipMemcpy(n_windows, d_off64 + nt, 8, hipMemcpyDeviceToHost));
     *gw_off = nullptr; *gw_blk = nullptr;
     if (*n_windows >= 0xFFFFFFFFull) return MCQ_OK;       // does not fit 32 bits: the caller decides
-    // block table: at most 2^18 entries (1 MB: stays in L2), at least 64 windows per block
+    // block table: at most 2^18 entries (2 MB: stays in L2), at least 64 windows per block
     u32 sh = 6; while ((*n_windows >> sh) > (1ull << 18)) ++sh;
     const u64 n_blk = (*n_windows >> sh) + 2;
     HIPCHK(hipMalloc(gw_off, ((u64)nt + 1) * 4));
     hipLaunchKernelGGL(k_u64_to_u32, dim3((u32)((nt + 1 + TB - 1) / TB)), dim3(TB), 0, 0, (const u64*)d_off64, *gw_off, (u64)nt + 1);
-    if (hipMalloc(gw_blk, n_blk * 4) != hipSuccess) { (void)hipFree(*gw_off); *gw_off = nullptr; return fail(MCQ_E_HIP, "hipMalloc of the window block table failed"); }
-    hipLaunchKernelGGL(k_gw_blocks, dim3((u32)((n_blk + TB - 1) / TB)), dim3(TB), 0, 0, (const u32*)*gw_off, nt, sh, n_blk, *gw_blk);
+    if (hipMalloc(gw_blk, n_blk * 8) != hipSuccess) { (void)hipFree(*gw_off); *gw_off = nullptr; return fail(MCQ_E_HIP, "hipMalloc of the window block table failed"); }
+    hipLaunchKernelGGL(k_gw_blocks, dim3((u32)((n_blk + TB - 1) / TB)), dim3(TB), 0, 0, (const u32*)*gw_off, nt, sh, n_blk, reinterpret_cast<uint2*>(*gw_blk));
     *gw_shift = sh;
     return MCQ_OK;
 }
