@@ -511,6 +511,114 @@ __device__ __forceinline__ u32 wave_sort32_low(u32 v, u32 lane) {
     return wave_sort_blocks32(v);
 }
 
+// ---- the same networks as ONE asm block each (r04) ------------------------------------------------------------------------
+// Stage by stage (above) every compare-exchange is its own asm statement: it opens with the two wait states a DPP read needs
+// behind a VALU write, and the compiler closes it with another `s_nop 0` (it does not look inside and assumes the worst) --
+// a third of the instructions of a sort were wait states, and the kernels that sort are short of issue slots.
+// Written as one block the chain needs a wait only where a stage reads what the instruction before it wrote; and TWO
+// registers sorted side by side (wave_sort64_x2, cx_chain6_x2: stage by stage, a's instructions, then b's) need none at all --
+// each register's DPP read sits two or more instructions behind its own last write -- and share the lane-mask moves.
+// Registers ping-pong (x -> y -> x ...): min and max write disjoint lanes of the destination while both read the source.
+// -DMCQ_SORT_STAGEWISE (A/B knob): the stage-by-stage forms.
+#define MQ_ALL " row_mask:0xf bank_mask:0xf"
+#define MQ_NOP2 "s_nop 1\n\t"
+#define MQ_NOP1 "s_nop 0\n\t"
+#define MQ_VCC(M) "s_mov_b32 vcc_lo, " M "\n\ts_mov_b32 vcc_hi, " M "\n\t"
+#define MQ_M3 "0x33333333"
+#define MQ_M5 "0x55555555"
+#define MQ_CX2(D, S, PMIN, PMAX) "v_min_u32_dpp " D ", " S ", " S " " PMIN "\n\tv_max_u32_dpp " D ", " S ", " S " " PMAX "\n\t"
+#define MQ_CX3(D, S, T, P) "v_min_u32_dpp " D ", " S ", " S " " P MQ_ALL "\n\tv_max_u32_dpp " T ", " S ", " S " " P MQ_ALL "\n\t" \
+                           "v_cndmask_b32_e32 " D ", " T ", " D ", vcc\n\t"
+#define MQ_J8(D, S)  MQ_CX2(D, S, "row_ror:8 row_mask:0xf bank_mask:0x3", "row_ror:8 row_mask:0xf bank_mask:0xc")
+#define MQ_J4(D, S)  MQ_CX2(D, S, "row_shl:4 row_mask:0xf bank_mask:0x5", "row_shr:4 row_mask:0xf bank_mask:0xa")
+#define MQ_F8(D, S)  MQ_CX2(D, S, "row_half_mirror row_mask:0xf bank_mask:0x5", "row_half_mirror row_mask:0xf bank_mask:0xa")
+#define MQ_F16(D, S) MQ_CX2(D, S, "row_mirror row_mask:0xf bank_mask:0x3", "row_mirror row_mask:0xf bank_mask:0xc")
+#define MQ_J2(D, S, T) MQ_CX3(D, S, T, "quad_perm:[2,3,0,1]")          /* lane mask 0x33333333 */
+#define MQ_J1(D, S, T) MQ_CX3(D, S, T, "quad_perm:[1,0,3,2]")          /* lane mask 0x55555555 */
+#define MQ_F4(D, S, T) MQ_CX3(D, S, T, "quad_perm:[3,2,1,0]")          /* lane mask 0x33333333 */
+#define MQ_NOT23(S) "v_not_b32_dpp " S ", " S " quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf\n\t"
+// the tails of the permlane stages (after the swaps): flip of 32-lane blocks; lane ^ 32; lane ^ 16
+#define MQ_F32_TAIL(D, S, T0, T1) "v_min_u32_dpp " D ", " T1 ", " S " row_mirror row_mask:0x5 bank_mask:0xf\n\t" \
+                                  "v_max_u32_dpp " D ", " T0 ", " S " row_mirror row_mask:0xa bank_mask:0xf\n\t"
+#define MQ_J32_TAIL(D, S, T) "v_min_u32_e32 " D ", " S ", " T "\n\tv_max_u32_dpp " D ", " S ", " T " quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf\n\t"
+#define MQ_J16_TAIL(D, S, T) "v_min_u32_e32 " D ", " S ", " T "\n\tv_max_u32_dpp " D ", " S ", " T " quad_perm:[0,1,2,3] row_mask:0xa bank_mask:0xf\n\t"
+#define MQ_MOV(D, S) "v_mov_b32 " D ", " S "\n\t"
+#define MQ_SWAP16(A, B) "v_permlane16_swap_b32 " A ", " B "\n\t"
+#define MQ_SWAP32(A, B) "v_permlane32_swap_b32 " A ", " B "\n\t"
+// one register: X -> result in Y (15 stages); temporaries Z, W
+#define MQ_BLOCKS32_1(X, Y, Z, W) \
+    MQ_VCC(MQ_M5) MQ_J1(Y, X, Z) \
+    MQ_VCC(MQ_M3) MQ_F4(X, Y, Z)  MQ_VCC(MQ_M5) MQ_J1(Y, X, Z) \
+    MQ_NOP2 MQ_F8(X, Y)  MQ_VCC(MQ_M3) MQ_J2(Y, X, Z)  MQ_VCC(MQ_M5) MQ_J1(X, Y, Z) \
+    MQ_NOP2 MQ_F16(Y, X) MQ_NOP2 MQ_J4(X, Y)  MQ_VCC(MQ_M3) MQ_J2(Y, X, Z)  MQ_VCC(MQ_M5) MQ_J1(X, Y, Z) \
+    MQ_MOV(Z, X) MQ_MOV(W, X) MQ_NOP2 MQ_SWAP16(Z, W) MQ_NOP2 MQ_F32_TAIL(Y, X, Z, W) \
+    MQ_NOP2 MQ_J8(X, Y) MQ_NOP2 MQ_J4(Y, X)  MQ_VCC(MQ_M3) MQ_J2(X, Y, Z)  MQ_VCC(MQ_M5) MQ_J1(Y, X, Z)
+// one register, the half-cleaners 32 .. 1: X -> result in X; temporaries Y, Z (X, Y are both written on the way)
+#define MQ_CHAIN6_1(X, Y, Z) \
+    MQ_MOV(Z, X) MQ_NOP2 MQ_SWAP32(X, Z) MQ_NOP2 MQ_J32_TAIL(Y, X, Z) \
+    MQ_MOV(Z, Y) MQ_NOP2 MQ_SWAP16(Y, Z) MQ_NOP2 MQ_J16_TAIL(X, Y, Z) \
+    MQ_NOP2 MQ_J8(Y, X) MQ_NOP2 MQ_J4(X, Y)  MQ_VCC(MQ_M3) MQ_J2(Y, X, Z)  MQ_VCC(MQ_M5) MQ_J1(X, Y, Z)
+// two registers side by side: no wait states between the stages
+#define MQ_CX3_2(M, DA, SA, TA, DB, SB, TB, ST) MQ_VCC(M) ST(DA, SA, TA) ST(DB, SB, TB)
+#define MQ_CX2_2(DA, SA, DB, SB, ST) ST(DA, SA) ST(DB, SB)
+#define MQ_BLOCKS32_2(XA, YA, ZA, WA, XB, YB, ZB, WB) \
+    MQ_CX3_2(MQ_M5, YA, XA, ZA, YB, XB, ZB, MQ_J1) \
+    MQ_CX3_2(MQ_M3, XA, YA, ZA, XB, YB, ZB, MQ_F4) MQ_CX3_2(MQ_M5, YA, XA, ZA, YB, XB, ZB, MQ_J1) \
+    MQ_CX2_2(XA, YA, XB, YB, MQ_F8) MQ_CX3_2(MQ_M3, YA, XA, ZA, YB, XB, ZB, MQ_J2) MQ_CX3_2(MQ_M5, XA, YA, ZA, XB, YB, ZB, MQ_J1) \
+    MQ_CX2_2(YA, XA, YB, XB, MQ_F16) MQ_CX2_2(XA, YA, XB, YB, MQ_J4) MQ_CX3_2(MQ_M3, YA, XA, ZA, YB, XB, ZB, MQ_J2) MQ_CX3_2(MQ_M5, XA, YA, ZA, XB, YB, ZB, MQ_J1) \
+    MQ_MOV(ZA, XA) MQ_MOV(WA, XA) MQ_MOV(ZB, XB) MQ_MOV(WB, XB) MQ_SWAP16(ZA, WA) MQ_NOP1 MQ_SWAP16(ZB, WB) \
+    MQ_F32_TAIL(YA, XA, ZA, WA) MQ_F32_TAIL(YB, XB, ZB, WB) \
+    MQ_CX2_2(XA, YA, XB, YB, MQ_J8) MQ_CX2_2(YA, XA, YB, XB, MQ_J4) MQ_CX3_2(MQ_M3, XA, YA, ZA, XB, YB, ZB, MQ_J2) MQ_CX3_2(MQ_M5, YA, XA, ZA, YB, XB, ZB, MQ_J1)
+#define MQ_CHAIN6_2(XA, YA, ZA, XB, YB, ZB) \
+    MQ_MOV(ZA, XA) MQ_MOV(ZB, XB) MQ_NOP1 MQ_SWAP32(XA, ZA) MQ_SWAP32(XB, ZB) MQ_J32_TAIL(YA, XA, ZA) MQ_J32_TAIL(YB, XB, ZB) \
+    MQ_MOV(ZA, YA) MQ_MOV(ZB, YB) MQ_NOP1 MQ_SWAP16(YA, ZA) MQ_SWAP16(YB, ZB) MQ_J16_TAIL(XA, YA, ZA) MQ_J16_TAIL(XB, YB, ZB) \
+    MQ_CX2_2(YA, XA, YB, XB, MQ_J8) MQ_CX2_2(XA, YA, XB, YB, MQ_J4) MQ_CX3_2(MQ_M3, YA, XA, ZA, YB, XB, ZB, MQ_J2) MQ_CX3_2(MQ_M5, XA, YA, ZA, XB, YB, ZB, MQ_J1)
+
+#ifndef MCQ_SORT_STAGEWISE
+// every aligned block of 32 lanes sorted ascending
+__device__ __forceinline__ u32 wave_sort_blocks32_1(u32 v) {
+    u32 y, z, w;
+    asm(MQ_BLOCKS32_1("%[x]", "%[y]", "%[z]", "%[w]") : [x] "+v"(v), [y] "=&v"(y), [z] "=&v"(z), [w] "=&v"(w) : : "vcc");
+    return y;
+}
+// ascending sort of one u32 per lane across the wave
+__device__ __forceinline__ u32 wave_sort64_1(u32 v) {
+    u32 y, z, w;
+    asm(MQ_NOP2 MQ_NOT23("%[x]") MQ_BLOCKS32_1("%[x]", "%[y]", "%[z]", "%[w]") MQ_NOP2 MQ_NOT23("%[y]")
+        // (MQ_CHAIN6_1 with the roles of x and y exchanged: y -> y)
+        MQ_CHAIN6_1("%[y]", "%[x]", "%[z]")
+        : [x] "+v"(v), [y] "=&v"(y), [z] "=&v"(z), [w] "=&v"(w) : : "vcc");
+    return y;
+}
+// half-cleaners at lane distance 32 .. 1 (ascending)
+__device__ __forceinline__ u32 cx_chain6_1(u32 v) {
+    u32 y, z;
+    asm(MQ_CHAIN6_1("%[x]", "%[y]", "%[z]") : [x] "+v"(v), [y] "=&v"(y), [z] "=&v"(z) : : "vcc");
+    return v;
+}
+// the same for two registers at once
+__device__ __forceinline__ void wave_sort64_x2(u32& a, u32& b) {
+    u32 ya, za, wa, yb, zb, wb;
+    asm(MQ_NOP2 MQ_NOT23("%[xa]") MQ_NOP1 MQ_NOT23("%[xb]")
+        MQ_BLOCKS32_2("%[xa]", "%[ya]", "%[za]", "%[wa]", "%[xb]", "%[yb]", "%[zb]", "%[wb]")
+        MQ_NOT23("%[ya]") MQ_NOP1 MQ_NOT23("%[yb]")
+        MQ_CHAIN6_2("%[ya]", "%[xa]", "%[za]", "%[yb]", "%[xb]", "%[zb]")
+        : [xa] "+v"(a), [ya] "=&v"(ya), [za] "=&v"(za), [wa] "=&v"(wa), [xb] "+v"(b), [yb] "=&v"(yb), [zb] "=&v"(zb), [wb] "=&v"(wb) : : "vcc");
+    a = ya; b = yb;
+}
+__device__ __forceinline__ void cx_chain6_x2(u32& a, u32& b) {
+    u32 ya, za, yb, zb;
+    asm(MQ_CHAIN6_2("%[xa]", "%[ya]", "%[za]", "%[xb]", "%[yb]", "%[zb]")
+        : [xa] "+v"(a), [ya] "=&v"(ya), [za] "=&v"(za), [xb] "+v"(b), [yb] "=&v"(yb), [zb] "=&v"(zb) : : "vcc");
+}
+#else
+__device__ __forceinline__ u32 wave_sort_blocks32_1(u32 v) { return wave_sort_blocks32(v); }
+__device__ __forceinline__ u32 wave_sort64_1(u32 v) { return wave_sort64(v, 0); }
+__device__ __forceinline__ u32 cx_chain6_1(u32 v) { v = cx_j32(v); v = cx_j16(v); v = cx_j8(v); v = cx_j4(v); v = cx_j2(v); return cx_j1(v); }
+__device__ __forceinline__ void wave_sort64_x2(u32& a, u32& b) { a = wave_sort64(a, 0); b = wave_sort64(b, 0); }
+__device__ __forceinline__ void cx_chain6_x2(u32& a, u32& b) { a = cx_chain6_1(a); b = cx_chain6_1(b); }
+#endif
+
 // Sketch of seq[0..n), n <= 128, by one full wave.  Lane l encodes bases 2l and 2l+1;
 // 8 lanes form one 16-base word (2 bits per base, first base in the top bits), 16 lanes
 // one 32-base ambiguity word.  Lane l then owns the k-mers starting at l and l+64.
@@ -613,7 +721,7 @@ __device__ __forceinline__ u32 wave_sketch_words(u32 w, u32 am, u32 n, u32 k, u3
         if (s1) tmp[n0 + lane_rank(m1)] = h[1];
         wave_sync();
         u32 v = lane < cnt ? tmp[lane] : MCQ_EMPTY;
-        v = (cnt <= 32) ? wave_sort32_low(v, lane) : wave_sort64(v, lane);     // 15 stages when the low half suffices
+        v = (cnt <= 32) ? wave_sort_blocks32_1(v) : wave_sort64_1(v);          // 15 stages when the low half suffices
         asm("s_nop 1" : "+v"(v));                 // v was written inside an asm block: 2 wait states before a DPP read
         const u32 prev = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);    // wave_shr:1
         bool keep = (v != MCQ_EMPTY) && (lane == 0 || v != prev);
@@ -822,11 +930,11 @@ __device__ __forceinline__ void regsort_levels_u32(u32 (&r)[E], u32 lane) {
     if constexpr (K >= 256) regsort_merge_regs<E, K, K / 2>(r, lane);
     else regsort_stage<u32, E, K, 64>(r, lane);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const bool up = ((e * 64) & K) == 0;
-        u32 v = up ? r[e] : ~r[e];
-        v = cx_j32(v); v = cx_j16(v); v = cx_j8(v); v = cx_j4(v); v = cx_j2(v); v = cx_j1(v);
-        r[e] = up ? v : ~v;
+    for (int e = 0; e < E; e += 2) {                  // (E is even: two registers side by side, see cx_chain6_x2)
+        const bool up0 = ((e * 64) & K) == 0, up1 = (((e + 1) * 64) & K) == 0;
+        u32 v0 = up0 ? r[e] : ~r[e], v1 = up1 ? r[e + 1] : ~r[e + 1];
+        cx_chain6_x2(v0, v1);
+        r[e] = up0 ? v0 : ~v0; r[e + 1] = up1 ? v1 : ~v1;
     }
 }
 #ifndef MCQ_REGSORT_U32_MIN_E
@@ -836,11 +944,12 @@ template <class KeyT, int E>
 __device__ __forceinline__ void wave_regsort(KeyT (&r)[E], u32 lane) {
 #ifndef MCQ_REGSORT_GENERIC     // tuning knob (A/B)
     if constexpr (sizeof(KeyT) == 4 && E >= MCQ_REGSORT_U32_MIN_E) {
+        static_assert(E % 2 == 0, "registers are sorted in pairs");
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            u32 v = (e & 1) ? ~r[e] : r[e];
-            v = wave_sort64(v, lane);
-            r[e] = (e & 1) ? ~v : v;
+        for (int e = 0; e < E; e += 2) {
+            u32 v0 = r[e], v1 = ~r[e + 1];
+            wave_sort64_x2(v0, v1);
+            r[e] = v0; r[e + 1] = ~v1;
         }
         regsort_levels_u32<E, 64 * E>(r, lane);
     } else
@@ -864,8 +973,7 @@ __device__ __forceinline__ void merge128(KeyT& r0, KeyT& r1, u32 lane, bool up) 
 #ifndef MCQ_REGSORT_GENERIC
     if constexpr (sizeof(KeyT) == 4) {          // min/max half-cleaners (ascending; complemented keys for descending)
         u32 a = up ? (u32)r0 : ~(u32)r0, b = up ? (u32)r1 : ~(u32)r1;
-        a = cx_j32(a); a = cx_j16(a); a = cx_j8(a); a = cx_j4(a); a = cx_j2(a); a = cx_j1(a);
-        b = cx_j32(b); b = cx_j16(b); b = cx_j8(b); b = cx_j4(b); b = cx_j2(b); b = cx_j1(b);
+        cx_chain6_x2(a, b);
         r0 = (KeyT)(up ? a : ~a); r1 = (KeyT)(up ? b : ~b);
         return;
     }

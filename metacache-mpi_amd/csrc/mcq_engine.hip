@@ -586,7 +586,7 @@ __device__ __forceinline__ u32 dedup_finish(u32 D, u32* buf, u32* hits, u32 lane
     if (D > MCQ_DEDUP_MAX_D) return ~0u;
     if (D <= 64) {
         u32 k = lane < D ? list[lane] : MCQ_EMPTY;
-        k = (D <= 32) ? wave_sort32_low(k, lane) : wave_sort64(k, lane);
+        k = (D <= 32) ? wave_sort_blocks32_1(k) : wave_sort64_1(k);
         if constexpr (LF::lookup) lf.locate(lane < D ? k : list[0], t1, tb1);      // (padding lanes look up a real word)
         const u32 c = lane < D ? dedup_count(tabkey, tabcnt, k) : 0u;
         const u32 incl = wave_incl_scan_dpp(c);
